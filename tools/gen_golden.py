@@ -1,0 +1,464 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors under tests/golden/ by IMPORTING the reference
+(/root/reference, read-only) in this container and recording its outputs.
+
+The reference is Python and cannot travel to the GPU box; these small .npz
+fixtures (inputs + expected outputs only -- no reference source text) can.
+Vector list: SURVEY.md section 8(c), items 1-11.
+
+cv2 / imageio are not installed here.  The reference imports them at module
+level (simulations/simulations.py:4-5, simulations/sensor_manipulations.py:1),
+so stub modules are injected.  The cv2.resize stub is this repo's own
+restatement of INTER_AREA (oracle.ipp_oracle.area_resize); therefore every
+fixture value that passed through it (rf=2 observations ``z`` and anything
+downstream of them) is tagged ``unpinned_*`` -- it pins nothing about OpenCV.
+
+Usage:  python tools/gen_golden.py        (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+if not os.path.isdir(REF):
+    sys.exit("reference checkout not present: golden vectors can only be generated in the build container")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import yaml  # noqa: E402
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+
+from oracle import ipp_oracle as orc  # noqa: E402
+
+cv2 = types.ModuleType("cv2")
+cv2.INTER_AREA = 3
+RESIZE_CALLS = []
+
+
+def _resize(src, dsize=None, interpolation=None):
+    RESIZE_CALLS.append((tuple(src.shape), tuple(int(v) for v in dsize)))
+    return orc.area_resize(np.asarray(src, dtype=np.float64), dsize)
+
+
+cv2.resize = _resize
+sys.modules["cv2"] = cv2
+sys.modules["imageio"] = types.ModuleType("imageio")
+
+from mapping.grid_maps import GridMap  # noqa: E402
+from mapping.mappings import Mapping  # noqa: E402
+from sensors.models.sensor_model_factories import SensorModelFactory  # noqa: E402
+from sensors.sensor_factories import SensorFactory  # noqa: E402
+from simulations.simulation_factories import SimulationFactory  # noqa: E402
+from simulations import ground_truths  # noqa: E402
+from planning.common.optimization import simulate_prediction_step, greedy_search  # noqa: E402
+from planning.common.rewards import compute_adaptive_msk, compute_reward  # noqa: E402
+from planning.common import actions as ref_actions  # noqa: E402
+from planning import evaluation_metrics as ref_metrics  # noqa: E402
+
+
+def load_params(x_dim, y_dim, resolution=4):
+    with open(os.path.join(REF, "config", "example.yaml")) as fh:
+        params = yaml.safe_load(fh)
+    params["environment"].update(x_dim=x_dim, y_dim=y_dim, resolution=resolution)
+    return params
+
+
+def build(params, seed=None, shuffle_prior_cov=False):
+    if seed is not None:
+        np.random.seed(seed)
+    gm = GridMap(params)
+    sm = SensorModelFactory(params).create_sensor_model()
+    sensor = SensorFactory(params, sm, gm).create_sensor()
+    sim = SimulationFactory(params, sensor).create_sensor_simulation()
+    sensor.set_sensor_simulation(sim)
+    mapping = Mapping(gm, sensor, shuffle_prior_cov=shuffle_prior_cov)
+    return gm, sensor, sim, mapping
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(arrays)} arrays)")
+
+
+# ----------------------------------------------------------------------------- 1. footprint table
+def gen_footprints():
+    rows = []
+    for res in (1, 4):
+        params = load_params(400, 400, res)
+        gm = GridMap(params)
+        sm = SensorModelFactory(params).create_sensor_model()
+        sensor = SensorFactory(params, sm, gm).create_sensor()
+        for alt in range(4, 31):
+            pos = np.array([200.0 * res + 0.5 * res, 200.0 * res + 0.5 * res, float(alt)])
+            rx, ry = sensor.field_of_view_range(pos[2])
+            xl, xr, yu, yd = sensor.project_field_of_view(pos)
+            rows.append([res, alt, rx, ry, (xr - xl) // 2, (yd - yu) // 2, sensor.get_resolution_factor(pos),
+                         sm.get_noise_variance(pos)])
+    table = np.array(rows, dtype=np.float64)
+
+    params = load_params(50, 50, 4)
+    gm = GridMap(params)
+    sm = SensorModelFactory(params).create_sensor_model()
+    sensor = SensorFactory(params, sm, gm).create_sensor()
+    positions, fovs = [], []
+    W = 50 * 4
+    xy = [2.0, 6.0, 98.0, 102.0, 190.0, 194.0, 198.0, 199.99, float(W), 0.0, 3.999, 4.0, 57.3, 123.456]
+    for alt in (5.0, 8.0, 10.0, 10.000001, 11.0, 13.0, 14.0, 20.0, 27.0, 30.0):
+        for x in xy:
+            for y in (2.0, 102.0, 198.0, float(W), 0.0, 77.7):
+                p = np.array([x, y, alt])
+                positions.append(p)
+                fovs.append(sensor.project_field_of_view(p))
+    save("footprints", table=table, positions=np.array(positions), fovs=np.array(fovs, dtype=np.int64))
+
+
+# ----------------------------------------------------------------------------- 2. H rows
+def gen_measurement_model():
+    params = load_params(10, 12, 4)  # non-square on purpose: flat index = x_dim * row + col
+    gm = GridMap(params)
+    sm = SensorModelFactory(params).create_sensor_model()
+    fovs, rfs, ms, Hs, R00 = [], [], [], [], []
+    for rf in (1, 2):
+        for w in range(1, 6):
+            for h in range(1, 6):
+                xl, yu = 2, 3
+                fov = (xl, xl + w - 1, yu, yu + h - 1)
+                m = int(np.ceil(w / rf) * np.ceil(h / rf))
+                H = sm.measurement_model_matrix(gm, fov, m, rf)
+                pos = np.array([0.0, 0.0, 14.0 if rf == 2 else 8.0])
+                R = sm.measurement_variance_matrix(pos, m, rf)
+                fovs.append(fov)
+                rfs.append(rf)
+                ms.append(m)
+                Hpad = np.zeros((25, gm.num_grid_cells))
+                Hpad[:m] = H
+                Hs.append(Hpad)
+                R00.append(R[0, 0])
+    save("measurement_model", fovs=np.array(fovs), rfs=np.array(rfs), ms=np.array(ms), H=np.array(Hs),
+         R00=np.array(R00), x_dim=np.array(10), y_dim=np.array(12))
+
+
+# ----------------------------------------------------------------------------- 3. priors
+def gen_priors():
+    _, _, _, mp10 = build(load_params(10, 10), seed=0)
+    _, _, _, mp50 = build(load_params(50, 50), seed=0)
+    P50 = mp50.grid_map.cov_matrix
+    draws = []
+    for seed in range(4):
+        np.random.seed(seed)
+        params = load_params(10, 10)
+        gm = GridMap(params)
+        sm = SensorModelFactory(params).create_sensor_model()
+        sensor = SensorFactory(params, sm, gm).create_sensor()
+        sim = SimulationFactory(params, sensor).create_sensor_simulation()
+        sensor.set_sensor_simulation(sim)
+        np.random.seed(100 + seed)
+        mp = Mapping(gm, sensor, shuffle_prior_cov=True)
+        # recover the drawn (sigma^2, l): P0[0,0] = sigma^2 ; then solve l from P0[0,1]
+        np.random.seed(100 + seed)
+        sv = np.random.uniform(low=0.8 * 1.82, high=1.2 * 1.82)
+        ls = np.random.uniform(low=0.8 * 3.67, high=1.2 * 3.67)
+        draws.append([sv, ls, mp.grid_map.cov_matrix[0, 0], mp.grid_map.cov_matrix[0, 1], mp.grid_map.cov_matrix[0, 11],
+                      mp.grid_map.cov_matrix[5, 99]])
+    # non-GP branch (mappings.py:219-233) on a tiny grid
+    params = load_params(6, 6)
+    params["mapping"]["fit_gaussian_process"] = False
+    np.random.seed(7)
+    _, _, _, mp_rand = build(params)  # GRF draw first, then the N x N normal draw
+    save("priors", P0_10=mp10.grid_map.cov_matrix, mean_10=mp10.grid_map.mean, P0_50_rows=P50[[0, 1234, 2499]],
+         P0_50_diag=np.diag(P50).copy(), shuffle=np.array(draws), P0_rand_6=mp_rand.grid_map.cov_matrix)
+
+
+# ----------------------------------------------------------------------------- 4. predict steps
+def action_list(x_dim, y_dim, res, n, seed, altitudes):
+    rs = np.random.RandomState(seed)
+    acts = []
+    for _ in range(n):
+        j, i = rs.randint(0, x_dim), rs.randint(0, y_dim)
+        acts.append([res * j + 0.5 * res, res * i + 0.5 * res, float(altitudes[rs.randint(0, len(altitudes))])])
+    return np.array(acts)
+
+
+def gen_predict():
+    uav = {"max_v": 2, "max_a": 2}
+    for tag, dim, n in (("10", 10, 36), ("50", 50, 8)):
+        params = load_params(dim, dim)
+        gm, sensor, sim, mapping = build(params, seed=11)
+        acts = action_list(dim, dim, 4, n, 5, list(range(5, 15)))
+        # border / corner / boundary cases up front
+        acts[0] = [2, 2, 14]
+        acts[1] = [4 * dim - 2, 4 * dim - 2, 14]
+        acts[2] = [2, 4 * dim - 2, 8]
+        acts[3] = [4 * dim - 2, 2, 11]
+        acts[4] = [4 * (dim // 2) + 2, 2, 13]
+        acts[5] = [2, 4 * (dim // 2) + 2, 5]
+        P = gm.cov_matrix.copy()
+        mean = gm.mean.copy()
+        rs = np.random.RandomState(3)
+        prev = np.array([2.0, 2.0, 14.0])
+        rec = {k: [] for k in ("reward", "mask", "S", "Wc", "diag", "trace", "cost", "m", "fov", "rf", "mode")}
+        P_seq = []
+        sample_rows = np.array([0, dim, dim * dim // 2 + 3, dim * dim - 1, 7, 3 * dim + 1, dim * dim // 3, dim * dim - dim])
+        rows_seq = []
+        for t, a in enumerate(acts):
+            mode = t % 4
+            # mode 0: adaptive k=0 + flight time; 1: non-adaptive + distance; 2: adaptive k=2 + flight time; 3: adaptive k=0 + distance
+            mean_t = np.clip(mean + 0.25 * rs.standard_normal(mean.shape), 0, 1) if mode != 1 else mean
+            info = None
+            if mode in (0, 3):
+                info = {"mean": mean_t, "value_threshold": 0.4, "interval_factor": 0}
+            elif mode == 2:
+                info = {"mean": mean_t, "value_threshold": 0.9, "interval_factor": 2}
+            u = uav if mode in (0, 2) else None
+            reward, _, P_next = simulate_prediction_step(P, prev, a, mapping, u, info)
+            mask = np.ones(dim * dim, bool) if info is None else compute_adaptive_msk(
+                info["mean"], P, info["value_threshold"], info["interval_factor"])
+            rf = sensor.get_resolution_factor(a)
+            fov = sensor.project_field_of_view(a)
+            xl, xr, yu, yd = fov
+            m = int(np.ceil((xr - xl + 1) / rf) * np.ceil((yd - yu + 1) / rf))
+            H = sensor.sensor_model.measurement_model_matrix(gm, fov, m, rf)
+            R = sensor.sensor_model.measurement_variance_matrix(a, m, rf)
+            S = H @ P @ H.T + R
+            S = 0.5 * (S + S.T)
+            Lu = np.linalg.cholesky(S).T
+            Wc = P @ (H.T @ np.linalg.inv(Lu))
+            Wpad = np.zeros((dim * dim, 9))
+            Wpad[:, :m] = Wc
+            Spad = np.zeros((9, 9))
+            Spad[:m, :m] = S
+            rec["reward"].append(reward)
+            rec["mask"].append(mask)
+            rec["S"].append(Spad)
+            rec["Wc"].append(Wpad)
+            rec["diag"].append(np.diag(P_next).copy())
+            rec["trace"].append(np.trace(P_next))
+            rec["cost"].append(ref_actions.action_costs(a, prev, u))
+            rec["m"].append(m)
+            rec["fov"].append(fov)
+            rec["rf"].append(rf)
+            rec["mode"].append(mode)
+            rows_seq.append(P_next[sample_rows].copy())
+            if dim == 10 and t < 12:
+                P_seq.append(P_next.copy())
+            rec.setdefault("mean_used", []).append(mean_t.copy())
+            P, prev = P_next, a
+        out = {k: np.array(v) for k, v in rec.items()}
+        out.update(actions=acts, P0=gm.cov_matrix if dim == 10 else gm.cov_matrix[sample_rows],
+                   sample_rows=sample_rows, rows=np.array(rows_seq), checksum=np.array([P.sum(), (P ** 2).sum()]))
+        if dim == 10:
+            out["P_seq"] = np.array(P_seq)
+            out["P_final"] = P
+        save(f"predict_{tag}", **out)
+
+
+# ----------------------------------------------------------------------------- 5/6. episodes (predict + observe + update)
+def run_episode(dim, seed, steps, altitudes, tag):
+    params = load_params(dim, dim)
+    np.random.seed(seed)
+    st0 = np.random.get_state()
+    gm, sensor, sim, mapping = build(params)  # consumes dim*dim normals for the GRF
+    np.random.set_state(st0)
+    white = np.random.normal(size=(dim, dim))  # identical draw, now observed
+    acts = action_list(dim, dim, 4, steps, 1000 + seed, altitudes)
+    uav = {"max_v": 2, "max_a": 2}
+    prev = np.array([2.0, 2.0, 14.0])
+    rec = {k: [] for k in ("reward", "trace", "diag", "mean", "z", "eps", "m", "rf", "unpinned_z")}
+    Wcs = []
+    for a in acts:
+        info = {"mean": gm.mean, "value_threshold": 0.4, "interval_factor": 0}
+        reward, _, P_pred = simulate_prediction_step(gm.cov_matrix, prev, a, mapping, uav, info)
+        rf = sensor.get_resolution_factor(a)
+        st = np.random.get_state()
+        z = sensor.take_measurement(a, verbose=False)
+        np.random.set_state(st)
+        eps = np.random.normal(0, 1, z.shape)  # same stream position: z = clip(ds + nv * eps)
+        P_before = gm.cov_matrix
+        mapping.update_grid_map(a, z)
+        assert np.array_equal(gm.cov_matrix, P_pred)
+        d = np.diag(P_before) - np.diag(gm.cov_matrix)
+        zp, ep = np.zeros(9), np.zeros(9)
+        zp[: z.size], ep[: z.size] = z.ravel(), eps.ravel()
+        rec["reward"].append(reward)
+        rec["trace"].append(np.trace(gm.cov_matrix))
+        rec["diag"].append(np.diag(gm.cov_matrix).copy())
+        rec["mean"].append(gm.mean.copy())
+        rec["z"].append(zp)
+        rec["eps"].append(ep)
+        rec["m"].append(z.size)
+        rec["rf"].append(rf)
+        rec["unpinned_z"].append(rf > 1)
+        Wcs.append(d)
+        prev = a
+    gt = sim.ground_truth_map
+    m_rmse = ref_metrics.root_mean_squared_error(gt, gm.mean)
+    msk = gt.flatten(order="C") >= 0.4
+    metrics = np.array([
+        m_rmse,
+        ref_metrics.root_mean_squared_error(gt, gm.mean, msk),
+        ref_metrics.weighted_root_mean_squared_error(gt, gm.mean),
+        ref_metrics.mean_log_loss(gt, gm.mean, gm.cov_matrix),
+        ref_metrics.weighted_mean_log_loss(gt, gm.mean, gm.cov_matrix),
+        ref_metrics.map_uncertainty(gm.cov_matrix),
+        ref_metrics.map_uncertainty(gm.cov_matrix, msk),
+        ref_metrics.map_uncertainty_difference(gm.cov_matrix, msk),
+    ])
+    out = {k: np.array(v) for k, v in rec.items()}
+    sample_rows = np.array([0, dim + 1, dim * dim // 2 + 3, dim * dim - 1])
+    out.update(actions=acts, white=white, gt=gt, metrics=metrics, P_final_rows=gm.cov_matrix[sample_rows],
+               sample_rows=sample_rows, seed=np.array(seed))
+    if dim <= 20 and seed in (0, 4):
+        out["P_final"] = gm.cov_matrix
+    save(tag, **out)
+
+
+def gen_episodes():
+    for seed in range(4):
+        run_episode(20, seed, 40, list(range(5, 11)), f"episode_rf1_20_s{seed}")  # fully pinned (rf = 1 only)
+    run_episode(20, 4, 40, list(range(5, 15)), "episode_mixed_20_s4")  # rf=2 observations unpinned
+    run_episode(50, 0, 40, list(range(5, 11)), "episode_rf1_50_s0")
+    run_episode(50, 1, 40, list(range(5, 15)), "episode_mixed_50_s1")
+
+
+# ----------------------------------------------------------------------------- 7. GRF
+def gen_grf():
+    out = {}
+    for n in (10, 50, 100):
+        np.random.seed(20 + n)
+        st = np.random.get_state()
+        fld = ground_truths.gaussian_random_field(lambda k: k ** (-5), n, n)
+        np.random.set_state(st)
+        white = np.random.normal(size=(n, n))
+        out[f"white_{n}"] = white
+        out[f"field_{n}"] = fld
+    # odd size: last row / column of the amplitude stay zero (ground_truths.py:7-11)
+    np.random.seed(77)
+    st = np.random.get_state()
+    fld = ground_truths.gaussian_random_field(lambda k: k ** (-5), 9, 9)
+    np.random.set_state(st)
+    out["white_9"] = np.random.normal(size=(9, 9))
+    out["field_9"] = fld
+    out["fft_indices_8"] = np.array(ground_truths.fft_indices(8))
+    out["fft_indices_9"] = np.array(ground_truths.fft_indices(9))
+    save("grf", **out)
+
+
+# ----------------------------------------------------------------------------- 10. Cholesky fallback
+def gen_fallback():
+    params = load_params(6, 6)
+    gm, sensor, sim, mapping = build(params, seed=5)
+    P = gm.cov_matrix.copy()
+    H = np.zeros((3, 36))
+    H[0, [7, 8]] = 0.5
+    H[1, [7, 8]] = 0.5  # duplicated row
+    H[2, 14] = 1.0
+    R = np.zeros((3, 3))  # R = 0 -> S singular -> LinAlgError or garbage-free fallback
+    mean = gm.mean.copy()
+    z = np.array([0.7, 0.7, 0.2])
+    # make S exactly singular-indefinite so cholesky raises deterministically
+    R[0, 0] = -1e-3
+    import logging
+    logging.disable(logging.CRITICAL)
+    x, Pn = Mapping.kalman_filter_update(P, H, R, grid_mean=mean, observation=z, cov_only=False)
+    logging.disable(logging.NOTSET)
+    save("fallback", P=P, H=H, R=R, mean=mean, z=z, x_new=x, P_new=Pn)
+
+
+# ----------------------------------------------------------------------------- 11. greedy harness pin (config 1 plumbing)
+def gen_greedy():
+    out = {}
+    for dim, seed in ((10, 3), (20, 3)):
+        params = load_params(dim, dim)
+        gm, sensor, sim, mapping = build(params, seed=seed)
+        uav = {"max_v": 2, "max_a": 2}
+        info = {"mean": gm.mean, "value_threshold": 0.4, "interval_factor": 0}
+        prev = np.array([2.0, 2.0, 14.0])
+        wps = greedy_search(prev, 200, gm.cov_matrix, 3, mapping, 8, 14, 6, uav, info)
+        cands = ref_actions.get_actions(prev, 200, gm, 8, 14, 6, uav)
+        rewards = [simulate_prediction_step(gm.cov_matrix, prev, a, mapping, uav, info)[0] for a in cands]
+        out[f"waypoints_{dim}"] = np.array(wps)
+        out[f"candidates_{dim}"] = np.array(cands)
+        out[f"rewards_{dim}"] = np.array(rewards)
+
+    # full rf=1-only greedy mission loop (planning/greedy_mission.py:73-110 restated as a driver; budget 60)
+    dim = 10
+    params = load_params(dim, dim)
+    np.random.seed(9)
+    st0 = np.random.get_state()
+    gm, sensor, sim, mapping = build(params)
+    np.random.set_state(st0)
+    white = np.random.normal(size=(dim, dim))
+    uav = {"max_v": 2, "max_a": 2}
+    prev = np.array([2.0, 2.0, 14.0])
+    budget = 60.0
+    wps, traces, rmses, budgets, eps_all = [], [], [], [], []
+    while budget >= 0:
+        info = {"mean": gm.mean, "value_threshold": 0.4, "interval_factor": 0}
+        w = greedy_search(prev, budget, gm.cov_matrix, 1, mapping, 6, 10, 2, uav, info)
+        if len(w) == 0:
+            break
+        nxt = np.array(w[0])
+        st = np.random.get_state()
+        z = sensor.take_measurement(nxt, verbose=False)
+        np.random.set_state(st)
+        eps = np.random.normal(0, 1, z.shape)
+        mapping.update_grid_map(nxt, z)
+        budget -= ref_actions.action_costs(nxt, prev, uav)
+        prev = nxt
+        wps.append(nxt)
+        traces.append(np.trace(gm.cov_matrix))
+        rmses.append(ref_metrics.root_mean_squared_error(sim.ground_truth_map, gm.mean))
+        budgets.append(budget)
+        ep = np.zeros(9)
+        ep[: eps.size] = eps.ravel()
+        eps_all.append(ep)
+    out.update(mission_white=white, mission_waypoints=np.array(wps), mission_traces=np.array(traces),
+               mission_rmse=np.array(rmses), mission_budget=np.array(budgets), mission_eps=np.array(eps_all),
+               mission_final_mean=gm.mean)
+    save("greedy", **out)
+
+
+# ----------------------------------------------------------------------------- flight time table (a13)
+def gen_costs():
+    rs = np.random.RandomState(2)
+    a = rs.uniform(0, 200, size=(64, 3))
+    b = rs.uniform(0, 200, size=(64, 3))
+    b[:8] = a[:8] + rs.uniform(-0.5, 0.5, size=(8, 3))  # short hops: d/2 < v^2/(2a)
+    b[8] = a[8]  # zero distance
+    uav = {"max_v": 2, "max_a": 2}
+    uav2 = {"max_v": 5.0, "max_a": 1.5}
+    save("costs", a=a, b=b,
+         dist=np.array([ref_actions.action_costs(x, y, None) for x, y in zip(a, b)]),
+         t_v2a2=np.array([ref_actions.action_costs(x, y, uav) for x, y in zip(a, b)]),
+         t_v5a15=np.array([ref_actions.action_costs(x, y, uav2) for x, y in zip(a, b)]),
+         t_vec=ref_actions.compute_flight_times(a, b[0], uav))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    print("writing golden vectors to", OUT)
+    gen_footprints()
+    gen_measurement_model()
+    gen_priors()
+    gen_predict()
+    gen_episodes()
+    gen_grf()
+    gen_fallback()
+    gen_greedy()
+    gen_costs()
+    shapes = sorted(set(RESIZE_CALLS))
+    print("cv2.resize stub was called with (src shape, dsize):", shapes)
+
+
+if __name__ == "__main__":
+    main()
