@@ -1,0 +1,210 @@
+/*
+ * ipp_engine.h -- C-ABI of the MI355X-native batched IPP environment-step engine.
+ *
+ * The reference (dmar-bonn/ipp-rl) has no FFI boundary: its hot path is plain Python/NumPy
+ * behind the Mapping / Sensor / Simulation classes.  This header declares the entry points a
+ * ctypes binding of that path would bind (INTEGRATION.md shows the stub); every function names
+ * the reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no exceptions; every function returns int: 0 = OK, < 0 = error
+ *     (ipp_last_error() returns a thread-local message).
+ *   - every pointer marked [dev] is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); the caller
+ *     owns all buffers including the state arena.  [host] marks host pointers.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it and nothing synchronises unless stated.
+ *   - grid is H x W = y_dim x x_dim, N = H*W cells, flat cell = x_dim*row + col (C order),
+ *     position = [x (col axis), y (row axis), altitude] in metres (float64, like the reference).
+ *   - one engine per device; calls on one engine are not re-entrant.
+ */
+#ifndef IPP_ENGINE_H
+#define IPP_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPP_ABI_VERSION 1
+
+/* covariance state representation */
+#define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
+#define IPP_FACTOR 1 /* P = P0(sigma^2, l) - U U^T, U[N][r] fp32 grows by m columns per step         */
+
+/* ipp_step flags */
+#define IPP_COV_ONLY        1u /* no observation / mean update     (mappings.py:114 cov_only=True)        */
+#define IPP_PREDICT_ONLY    2u /* reward only, nothing is written  (mappings.py:114 predict_only=True)    */
+#define IPP_ADAPTIVE        4u /* masked reward                    (planning/common/rewards.py:8-12)      */
+#define IPP_USE_FLIGHT_TIME 8u /* cost = flight time, else distance (planning/common/actions.py:8-12)     */
+
+/* per-item status written by ipp_step */
+#define IPP_STATUS_OK            0
+#define IPP_STATUS_CHOL_FALLBACK 1 /* S not PD: inverse formula used (mappings.py:200-215), dense only  */
+#define IPP_STATUS_NOT_PD        2 /* S not PD in factor form: step not applied, reward = NaN           */
+#define IPP_STATUS_RANK_FULL     3 /* factor rank_cap exceeded: reward valid, state not written         */
+#define IPP_STATUS_BAD_FOOTPRINT 4 /* m or f above the engine's compiled caps / unsupported resize      */
+
+#define IPP_MAX_MEAS 25 /* largest supported measurement count m per step */
+
+typedef struct ipp_config {
+    int32_t x_dim;            /* W [cells]   environment.x_dim    (mapping/grid_maps.py:13-24)   */
+    int32_t y_dim;            /* H [cells]   environment.y_dim    (mapping/grid_maps.py:26-37)   */
+    double  resolution;       /* [m/cell]    environment.resolution (grid_maps.py:39-50)         */
+    double  tan_half_fov_x;   /* tan(0.5*radians(angle_x)) computed by the host in fp64 (sensors/cameras.py:44) */
+    double  tan_half_fov_y;   /* tan(0.5*radians(angle_y))                               (sensors/cameras.py:45) */
+    double  rf_altitude;      /* resolution factor is 2 strictly above this altitude: 10.0 (cameras.py:125)    */
+    double  coeff_a;          /* sensor.model.coeff_a (sensors/models/sensor_models.py:27-30) */
+    double  coeff_b;          /* sensor.model.coeff_b                                          */
+    double  signal_variance;  /* mapping.signal_variance: nominal Matern sigma^2 (mapping/mappings.py:235-244) */
+    double  length_scale;     /* mapping.length_scale:   nominal Matern l                                      */
+    double  max_v;            /* experiment.uav.max_v (planning/common/actions.py:32-41) */
+    double  max_a;            /* experiment.uav.max_a                                     */
+    double  value_threshold;  /* experiment.scenario.value_threshold (rewards.py:11)     */
+    double  interval_factor;  /* experiment.scenario.interval_factor (rewards.py:11)     */
+    double  cluster_radius;   /* sensor.simulation.cluster_radius (simulations/simulations.py:43-47) */
+    int32_t state_repr;       /* IPP_DENSE or IPP_FACTOR */
+    int32_t capacity;         /* number of env state slots */
+    int32_t rank_cap;         /* IPP_FACTOR: max columns of U per env (>= steps per episode * max m) */
+    int32_t max_batch;        /* largest n of one ipp_step / ipp_reset call */
+    int32_t max_measurements; /* compile-time cap on m: 9 (default config) or 25 */
+    int32_t tile_threads;     /* 0 = auto; threads per streaming workgroup (multiple of 64, <= 640) */
+} ipp_config;
+
+typedef struct ipp_info {
+    int32_t abi_version;
+    int32_t n_cells;      /* N */
+    int32_t n_pad;        /* padded row length of every per-cell array [floats] */
+    int32_t tile_threads; /* threads per streaming workgroup */
+    int32_t n_tiles;      /* streaming workgroups per env */
+    int32_t meas_cap;     /* compiled m cap in use (9 or 25) */
+    int32_t fp_cap;       /* compiled footprint-cell cap in use (4 * meas_cap) */
+    int32_t reserved;
+    uint64_t arena_bytes;     /* total bytes the engine carves from the caller's arena */
+    uint64_t cov_slot_bytes;  /* bytes of covariance state per env slot */
+} ipp_info;
+
+/* Debug / test view of the last ipp_step's per-item prologue (host struct, filled by ipp_debug_step_item). */
+typedef struct ipp_step_item {
+    int32_t env, dst, rank_before, status;
+    int32_t xl, xr, yu, yd;   /* sensors/cameras.py:49-75 */
+    int32_t rf, m, f, pad;    /* cameras.py:122-125, mappings.py:125-126 */
+    double  cost;             /* actions.py:8-41 */
+    double  noise_var;        /* sensor_models.py:27-30 */
+    double  S[IPP_MAX_MEAS * IPP_MAX_MEAS];     /* row-major m x m (mappings.py:182-183) */
+    double  Linv[IPP_MAX_MEAS * IPP_MAX_MEAS];  /* upper-triangular inverse (mappings.py:185-186), or S^-1 on fallback */
+    double  z[IPP_MAX_MEAS];  /* observation after noise + clip (simulations/sensor_manipulations.py:44-57) */
+    double  y[IPP_MAX_MEAS];  /* L^-T (z - H x)  (mappings.py:189,195-196) */
+} ipp_step_item;
+
+int         ipp_abi_version(void);
+const char* ipp_last_error(void);
+
+/*
+ * Size of the device arena the engine needs for `cfg` (state slabs for `capacity` envs + per-call
+ * scratch for `max_batch` items).  Replaces: the per-object NumPy allocations of GridMap.mean /
+ * GridMap.cov_matrix (mapping/grid_maps.py:10-11, mapping/mappings.py:259-261).
+ */
+int ipp_engine_arena_bytes(const ipp_config* cfg, uint64_t* bytes /*[host]*/);
+
+/*
+ * Create an engine on HIP device `device` over a caller-owned arena (256-byte aligned).
+ * Replaces: GridMap(params) + Mapping(grid_map, sensor) construction (mapping/mappings.py:16-21),
+ * Camera / AltitudeSensorModel parameter capture (sensors/cameras.py:13-32, sensor_models.py:14-25).
+ */
+int ipp_engine_create(const ipp_config* cfg, int device, void* arena /*[dev]*/, uint64_t arena_bytes,
+                      void** engine /*[host] out*/);
+int ipp_engine_destroy(void* engine);
+int ipp_engine_info(void* engine, ipp_info* out /*[host]*/);
+
+/*
+ * Episode reset of `n` env slots: mean <- 0.5, covariance <- prior, rank <- 0, ground truth <- gt / GRF.
+ * Replaces: Mapping.init_priors GP branch (mapping/mappings.py:235-261) incl. shuffle_prior_cov draws
+ * passed in as prior_scale; GaussianRandomField.create_ground_truth_map -> gaussian_random_field
+ * (simulations/simulations.py:37-47, simulations/ground_truths.py:14-33).
+ *   env_ids     [dev] int32[n] or NULL (= 0..n-1)
+ *   prior_scale [dev] double[n][2] = (sigma^2, l) per env, or NULL (= nominal)
+ *   gt          [dev] float[n][H][W] ground truth to install, or NULL
+ *   white_noise [dev] float[n][H][W] standard normals -> device GRF (used when gt == NULL), or NULL
+ *   (both NULL: ground truth left unchanged)
+ */
+int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
+              const float* white_noise, void* stream);
+
+/*
+ * One fused environment step for `n` items.  Replaces, per item:
+ *   simulate_prediction_step            (planning/common/optimization.py:14-30)
+ *     compute_adaptive_msk              (planning/common/rewards.py:8-12)
+ *     Mapping.update_grid_map predict   (mapping/mappings.py:114-153, 156-215)
+ *       project_field_of_view           (sensors/cameras.py:49-75), get_resolution_factor (:122-125)
+ *       measurement_variance_matrix / measurement_model_matrix (sensors/models/sensor_models.py:32-81)
+ *     compute_reward / action_costs     (planning/common/rewards.py:15-31, planning/common/actions.py:8-41)
+ *   Sensor.take_measurement             (sensors/cameras.py:108-116 -> simulations/simulations.py:26-34,
+ *                                        simulations/sensor_manipulations.py:7-57)
+ *   Mapping.update_grid_map execute     (mapping/mappings.py:114-153: mean + covariance commit)
+ *
+ *   env_ids     [dev] int32[n] source slots (may repeat when IPP_PREDICT_ONLY), NULL = 0..n-1
+ *   dst_ids     [dev] int32[n] slots that receive the updated state (tree-search expansion: the
+ *               source slot is left untouched), or NULL = update in place
+ *   action      [dev] double[n][3]   measurement position
+ *   prev_action [dev] double[n][3]   previous waypoint (cost term)
+ *   meas_noise  [dev] float[n][max_measurements] standard normals, C order of the downsampled
+ *               observation, scaled in-kernel by the noise "variance" used as std
+ *               (sensor_manipulations.py:56-57); NULL = noise-free.  Ignored with IPP_COV_ONLY.
+ *   reward      [dev] float[n] out
+ *   status      [dev] int32[n] out (IPP_STATUS_*), may be NULL
+ */
+int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
+             const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
+             void* stream);
+
+/* Change the adaptive-mask parameters used by subsequent steps.  The reference passes them per call in
+ * adaptive_info = {"mean", "value_threshold", "interval_factor"} (planning/common/optimization.py:22-25). */
+int ipp_set_adaptive(void* engine, double value_threshold, double interval_factor);
+
+/* Copy state slots src[i] -> dst[i] (tree-search children keep their parent's belief: the reference
+ * keeps one dense P per node, planning/mcts_mission.py:25-31, planning/mcts_zero/mcts.py:16-21). */
+int ipp_fork(void* engine, const int32_t* src_ids /*[dev]*/, const int32_t* dst_ids /*[dev]*/, int32_t n,
+             void* stream);
+
+/* Materialise per-env state for callers / tests (reference: grid_map.mean, np.diag(cov_matrix),
+ * cov_matrix, sensor_simulation.ground_truth_map; planning/missions.py:176-203). out is [dev]. */
+int ipp_read_mean(void* engine, int32_t env_id, float* out /*[N]*/, void* stream);
+int ipp_read_diag(void* engine, int32_t env_id, float* out /*[N]*/, void* stream);
+int ipp_read_gt(void* engine, int32_t env_id, float* out /*[N]*/, void* stream);
+int ipp_read_cov_dense(void* engine, int32_t env_id, float* out /*[N][N]*/, void* stream);
+int ipp_read_rank(void* engine, int32_t env_id, int32_t* rank /*[host] out*/, void* stream); /* synchronises */
+
+/* Inject state (reference callers assign grid_map.mean / grid_map.cov_matrix directly:
+ * planning/mcts_mission.py:395,413; adaptive_info["mean"], planning/common/optimization.py:22-25).
+ * mean / P are [dev] float arrays; P (N x N, row-major) is accepted only by IPP_DENSE engines. */
+int ipp_write_mean(void* engine, int32_t env_id, const float* mean /*[N]*/, void* stream);
+int ipp_write_gt(void* engine, int32_t env_id, const float* gt /*[N]*/, void* stream);
+int ipp_write_cov_dense(void* engine, int32_t env_id, const float* P /*[N][N]*/, void* stream);
+
+/*
+ * Per-env evaluation metrics after a step (planning/evaluation_metrics.py:4-58 as called from
+ * planning/missions.py:176-203): out[i][0..7] = rmse, masked rmse, wrmse, mll, wmll, trace,
+ * masked trace, uncertainty difference (mask = ground truth >= value_threshold).
+ */
+int ipp_metrics(void* engine, const int32_t* env_ids /*[dev]*/, int32_t n, float* out /*[dev] [n][8]*/, void* stream);
+
+/* Philox4x32-10 + Box-Muller standard normals into a caller buffer (throughput runs; parity runs feed
+ * NumPy legacy-stream normals instead).  out[i] depends only on (seed, subsequence, i). */
+int ipp_fill_normal(void* engine, float* out /*[dev]*/, uint64_t count, uint64_t seed, uint64_t subsequence,
+                    void* stream);
+
+/* Copy the prologue record of item `idx` of the most recent ipp_step to the host (synchronises). */
+int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out /*[host]*/, void* stream);
+
+/* Average duration [ms] of the streaming kernels of ipp_step launched since the last call with
+ * reset != 0 (hipEvent pairs recorded on the caller's stream; bench.py's roofline leg).
+ * kind: 0 = gain kernel, 1 = dense downdate kernel, 2 = prologue kernel.  Synchronises. */
+int ipp_profile_enable(void* engine, int32_t enable);
+int ipp_profile_read(void* engine, int32_t kind, double* avg_ms /*[host]*/, int64_t* launches /*[host]*/, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPP_ENGINE_H */

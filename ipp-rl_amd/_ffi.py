@@ -1,0 +1,115 @@
+"""
+ctypes binding of the C-ABI in include/ipp_engine.h (lib/libipp_hip.so, built by csrc/Makefile).
+
+There is no CPU fallback: if the HIP library is missing or does not load, importing the engine fails
+loudly (build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C ipp-rl_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libipp_hip.so")
+
+IPP_DENSE, IPP_FACTOR = 0, 1
+IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME = 1, 2, 4, 8
+STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
+IPP_MAX_MEAS = 25
+ABI_VERSION = 1
+
+
+class IppConfig(C.Structure):
+    _fields_ = [
+        ("x_dim", C.c_int32), ("y_dim", C.c_int32),
+        ("resolution", C.c_double),
+        ("tan_half_fov_x", C.c_double), ("tan_half_fov_y", C.c_double),
+        ("rf_altitude", C.c_double),
+        ("coeff_a", C.c_double), ("coeff_b", C.c_double),
+        ("signal_variance", C.c_double), ("length_scale", C.c_double),
+        ("max_v", C.c_double), ("max_a", C.c_double),
+        ("value_threshold", C.c_double), ("interval_factor", C.c_double),
+        ("cluster_radius", C.c_double),
+        ("state_repr", C.c_int32), ("capacity", C.c_int32), ("rank_cap", C.c_int32), ("max_batch", C.c_int32),
+        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32),
+    ]
+
+
+class IppInfo(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_cells", C.c_int32), ("n_pad", C.c_int32), ("tile_threads", C.c_int32),
+        ("n_tiles", C.c_int32), ("meas_cap", C.c_int32), ("fp_cap", C.c_int32), ("reserved", C.c_int32),
+        ("arena_bytes", C.c_uint64), ("cov_slot_bytes", C.c_uint64),
+    ]
+
+
+class IppStepItem(C.Structure):
+    _fields_ = [
+        ("env", C.c_int32), ("dst", C.c_int32), ("rank_before", C.c_int32), ("status", C.c_int32),
+        ("xl", C.c_int32), ("xr", C.c_int32), ("yu", C.c_int32), ("yd", C.c_int32),
+        ("rf", C.c_int32), ("m", C.c_int32), ("f", C.c_int32), ("pad", C.c_int32),
+        ("cost", C.c_double), ("noise_var", C.c_double),
+        ("S", C.c_double * (IPP_MAX_MEAS * IPP_MAX_MEAS)),
+        ("Linv", C.c_double * (IPP_MAX_MEAS * IPP_MAX_MEAS)),
+        ("z", C.c_double * IPP_MAX_MEAS),
+        ("y", C.c_double * IPP_MAX_MEAS),
+    ]
+
+
+_P = C.c_void_p
+# name -> (restype, argtypes); exactly the symbols include/ipp_engine.h declares
+PROTOTYPES = {
+    "ipp_abi_version": (C.c_int, []),
+    "ipp_last_error": (C.c_char_p, []),
+    "ipp_engine_arena_bytes": (C.c_int, [C.POINTER(IppConfig), C.POINTER(C.c_uint64)]),
+    "ipp_engine_create": (C.c_int, [C.POINTER(IppConfig), C.c_int, _P, C.c_uint64, C.POINTER(_P)]),
+    "ipp_engine_destroy": (C.c_int, [_P]),
+    "ipp_engine_info": (C.c_int, [_P, C.POINTER(IppInfo)]),
+    "ipp_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
+    "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
+    "ipp_set_adaptive": (C.c_int, [_P, C.c_double, C.c_double]),
+    "ipp_fork": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "ipp_read_mean": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_read_diag": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_read_gt": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_read_cov_dense": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_read_rank": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P]),
+    "ipp_write_mean": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_write_gt": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_write_cov_dense": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_metrics": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "ipp_fill_normal": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
+    "ipp_debug_step_item": (C.c_int, [_P, C.c_int32, C.POINTER(IppStepItem), _P]),
+    "ipp_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "ipp_profile_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+}
+
+_lib = None
+
+
+class IppError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libipp_hip.so once; raise (never fall back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IppError(
+            f"HIP engine library not found at {LIB_PATH}: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ipp_abi_version() != ABI_VERSION:
+        raise IppError(f"libipp_hip.so ABI {lib.ipp_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IppError(f"ipp engine error {rc}: {load().ipp_last_error().decode(errors='replace')}")

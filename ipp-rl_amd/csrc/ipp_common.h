@@ -1,0 +1,114 @@
+// Shared device-side definitions of the IPP step engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ipp_engine.h"
+
+namespace ipp {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kPrepThreads = 256;  // prologue workgroup
+constexpr int kMaxTileThreads = 640;
+constexpr int kQChunk = 128;       // rows of Q staged in LDS per pass of the streaming loop
+constexpr int kBandRows = 20;      // rows of P per dense-downdate workgroup
+constexpr double kSqrt3 = 1.7320508075688772;
+
+// Per-item record written by the prologue kernel and consumed by the streaming kernels.
+struct ItemHdr {
+    int env, dst, rank, status;
+    int xl, xr, yu, yd;
+    int w, h, nx, ny;
+    int rf, m, f, rows;      // rows = rank (factor) or f (dense): length of the streaming loop
+    int fallback, commit, pad0, pad1;
+    float cost, sv, ls, nv;
+    double cost_d, nv_d;
+};
+
+// Everything the kernels need, passed by value.
+struct View {
+    int W, H, N, Npad, T, n_tiles, vec, pad_;
+    int mode, cap, rank_cap, max_batch;
+    int meas_cap, fp_cap, q_stride, q_rows;
+    double res, tanx, tany, rf_alt, coeff_a, coeff_b, sv0, ls0, vmax, amax, thr, kf;
+    // state slabs
+    float* mean;     // [cap][Npad]
+    float* diag;     // [cap][Npad]
+    float* gt;       // [cap][Npad]
+    double* prior;   // [cap][2]  (sigma^2, l)
+    int* rank;       // [cap]
+    float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]
+    uint64_t cov_slot;  // floats per env slot
+    // per-call scratch
+    ItemHdr* hdr;    // [max_batch]
+    float* linv;     // [max_batch][MC*MC]  upper-triangular L^-1 (or S^-1 on fallback), fp32 for the stream
+    float* yv;       // [max_batch][MC]
+    float* q;        // [max_batch][q_rows][q_stride]
+    float* wc;       // dense: [max_batch][MC][Npad]
+    double* partial; // [max_batch][n_tiles]
+    double* dbg;     // [max_batch][2*MC*MC + 2*MC]   S, Linv, z, y in fp64 (tests)
+    double* grf_h;   // [H][W] circular-convolution kernel of the GRF
+    float* grf_raw;  // [max_batch][Npad] un-normalised field
+};
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+__device__ __forceinline__ float wave_min(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, kWave));
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, kWave));
+    return x;
+}
+
+// Matern nu=3/2 prior between two cells (mapping/mappings.py:242-258 == analytic kernel).
+__device__ __forceinline__ double matern_d(int dr, int dc, double res, double sv, double ls) {
+    const double d = res * sqrt((double)(dr * dr + dc * dc));
+    const double t = kSqrt3 * d / ls;
+    return sv * (1.0 + t) * exp(-t);
+}
+__device__ __forceinline__ float matern_f(int dr, int dc, float res_s3_over_ls, float sv) {
+    const float t = res_s3_over_ls * sqrtf((float)(dr * dr + dc * dc));
+    return sv * (1.0f + t) * __expf(-t);
+}
+
+// Measurement block i of the footprint (sensors/models/sensor_models.py:57-79).
+struct Block {
+    int x0, y0, bw, bh;
+    double weight;
+    __device__ __forceinline__ int count() const { return bw * bh; }
+};
+__device__ __forceinline__ Block block_of(int i, int nx, int rf, int w, int h) {
+    Block b;
+    const int by = i / nx, bx = i - by * nx;
+    const int x1 = min(bx * rf + rf, w), y1 = min(by * rf + rf, h);
+    b.x0 = min(bx * rf, x1);
+    b.y0 = min(by * rf, y1);
+    b.bw = x1 - b.x0;
+    b.bh = y1 - b.y0;
+    b.weight = (b.bw * b.bh < rf * rf) ? 1.0 / rf : 1.0 / (rf * rf);
+    return b;
+}
+
+// XCD-aware block -> (item, part) map: blocks b, b+8, b+16.. run on one XCD (observed b % 8), so the
+// parts of one item are laid out on consecutive slots of the same XCD and share its L2 (Q, Wc, header).
+__device__ __forceinline__ bool decode_block(int b, int n_items, int parts, int& item, int& part) {
+    const int xcd = b & 7, slot = b >> 3;
+    item = (slot / parts) * 8 + xcd;
+    part = slot - (slot / parts) * parts;
+    return item < n_items;
+}
+inline int grid_for(int n_items, int parts) { return ((n_items + 7) / 8) * 8 * parts; }
+
+}  // namespace ipp

@@ -1,0 +1,572 @@
+// C-ABI of the MI355X-native batched IPP environment-step engine (see include/ipp_engine.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ipp_engine.hip -o libipp_hip.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ipp_common.h"
+#include "k_gain.h"
+#include "k_misc.h"
+#include "k_prepare.h"
+
+using namespace ipp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(-2, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr uint64_t kAlign = 256;
+inline uint64_t up(uint64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+struct ProfSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct Engine {
+    ipp_config cfg;
+    int device;
+    View v;
+    int n_bands;
+    uint64_t used_bytes;
+    size_t prep_lds;
+    size_t gain_lds;
+    int q_chunk;
+    bool profile = false;
+    ProfSlot prof[3];
+    int last_n = 0;
+};
+
+struct Layout {
+    int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
+    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
+        off_partial, off_dbg, off_grfh, off_grfraw, total, cov_slot_floats;
+};
+
+int plan(const ipp_config& c, Layout& L) {
+    if (c.x_dim <= 0 || c.y_dim <= 0) return fail(-1, "x_dim/y_dim must be positive");
+    if (!(c.resolution > 0)) return fail(-1, "resolution must be positive");
+    if (c.state_repr != IPP_DENSE && c.state_repr != IPP_FACTOR) return fail(-1, "state_repr must be IPP_DENSE or IPP_FACTOR");
+    if (c.capacity <= 0 || c.max_batch <= 0) return fail(-1, "capacity and max_batch must be positive");
+    if (c.state_repr == IPP_FACTOR && c.rank_cap <= 0) return fail(-1, "rank_cap must be positive for IPP_FACTOR");
+    if (!(c.signal_variance > 0) || !(c.length_scale > 0)) return fail(-1, "signal_variance and length_scale must be positive");
+    if (!(c.max_v > 0) || !(c.max_a > 0)) return fail(-1, "max_v and max_a must be positive");
+    L.MC = (c.max_measurements <= 0 || c.max_measurements <= 9) ? 9 : 25;
+    if (c.max_measurements > IPP_MAX_MEAS) return fail(-1, "max_measurements above %d is not compiled in", IPP_MAX_MEAS);
+    L.FC = 4 * L.MC;
+    L.QS = (L.MC + 3) & ~3;
+    L.VEC = (L.MC == 9) ? 4 : 2;  // cells per thread of the streaming kernels (register budget)
+    L.N = c.x_dim * c.y_dim;
+    const int n4 = (L.N + L.VEC - 1) / L.VEC;
+    if (c.tile_threads > 0) {
+        if (c.tile_threads % 64 != 0 || c.tile_threads > kMaxTileThreads) return fail(-1, "tile_threads must be a multiple of 64 and <= %d", kMaxTileThreads);
+        L.T = c.tile_threads;
+    } else {
+        // least padding first; then the largest workgroup <= 320 threads (5 waves: several workgroups
+        // stay resident per CU so one's prologue / epilogue overlaps another's streaming loop)
+        int best_t = 64;
+        long best_pad = -1;
+        for (int t = 64; t <= 320; t += 64) {
+            const long tiles = (n4 + t - 1) / t, padded = tiles * t;
+            if (best_pad < 0 || padded < best_pad || (padded == best_pad && t > best_t)) { best_pad = padded; best_t = t; }
+        }
+        L.T = best_t;
+    }
+    L.n_tiles = (n4 + L.T - 1) / L.T;
+    L.Npad = L.n_tiles * L.T * L.VEC;
+    L.q_rows = (c.state_repr == IPP_FACTOR) ? c.rank_cap : L.FC;
+    L.cov_slot_floats = (c.state_repr == IPP_FACTOR) ? (uint64_t)c.rank_cap * L.Npad : (uint64_t)L.N * L.Npad;
+    uint64_t o = 0;
+    const uint64_t cap = c.capacity, mb = c.max_batch, np = L.Npad;
+    L.off_mean = o; o += up(cap * np * 4);
+    L.off_diag = o; o += up(cap * np * 4);
+    L.off_gt = o; o += up(cap * np * 4);
+    L.off_prior = o; o += up(cap * 2 * 8);
+    L.off_rank = o; o += up(cap * 4);
+    L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
+    L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
+    L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
+    L.off_yv = o; o += up(mb * L.MC * 4);
+    L.off_q = o; o += up(mb * (uint64_t)L.q_rows * L.QS * 4);
+    L.off_wc = o; o += (c.state_repr == IPP_DENSE) ? up(mb * L.MC * np * 4) : 0;
+    L.off_partial = o; o += up(mb * L.n_tiles * 8);
+    L.off_dbg = o; o += up(mb * (2 * L.MC * L.MC + 2 * L.MC) * 8);
+    L.off_grfh = o; o += up((uint64_t)L.N * 8);
+    L.off_grfraw = o; o += up(mb * np * 4);
+    L.total = o;
+    return 0;
+}
+
+size_t prep_lds_bytes(const Layout& L, const ipp_config& c) {
+    const size_t MC = L.MC, FC = L.FC, LD = MC + 1;
+    size_t b = (3 * MC * LD + 3 * MC + FC) * sizeof(double) + sizeof(ItemHdr) + 16;
+    if (c.state_repr == IPP_FACTOR)
+        b += MC * (size_t)((c.rank_cap + 3) & ~3) * sizeof(float);
+    else
+        b += FC * (FC + 1) * sizeof(float);
+    return (b + 15) & ~(size_t)15;
+}
+
+// h = Re ifft2(amp) with the reference's amplitude table (simulations/ground_truths.py:7-29), on the host.
+void grf_kernel_host(int H, int W, double c, std::vector<double>& h) {
+    auto idx_list = [](int n) {
+        std::vector<int> a;
+        const int half = n / 2;
+        for (int i = 0; i <= half; ++i) a.push_back(i);
+        for (int i = half - 1; i >= 1; --i) a.push_back(-i);
+        return a;  // one entry short for odd n, like the reference
+    };
+    const std::vector<int> ky = idx_list(H), kx = idx_list(W);
+    std::vector<double> amp((size_t)H * W, 0.0);
+    for (size_t i = 0; i < ky.size(); ++i)
+        for (size_t j = 0; j < kx.size(); ++j) {
+            if (ky[i] == 0 && kx[j] == 0) continue;
+            const double k = std::sqrt((double)ky[i] * ky[i] + (double)kx[j] * kx[j]);
+            amp[i * W + j] = std::sqrt(std::pow(k, -c));
+        }
+    // separable inverse DFT, real part only (amp is real; imaginary parts cancel for even amp)
+    std::vector<double> are((size_t)H * W), aim((size_t)H * W);
+    for (int u = 0; u < H; ++u)
+        for (int x = 0; x < W; ++x) {
+            double re = 0, im = 0;
+            for (int q = 0; q < W; ++q) {
+                const double ang = 2.0 * M_PI * (double)((long)q * x % W) / W;
+                re += amp[(size_t)u * W + q] * std::cos(ang);
+                im += amp[(size_t)u * W + q] * std::sin(ang);
+            }
+            are[(size_t)u * W + x] = re;
+            aim[(size_t)u * W + x] = im;
+        }
+    h.assign((size_t)H * W, 0.0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            double re = 0;
+            for (int u = 0; u < H; ++u) {
+                const double ang = 2.0 * M_PI * (double)((long)u * y % H) / H;
+                re += are[(size_t)u * W + x] * std::cos(ang) - aim[(size_t)u * W + x] * std::sin(ang);
+            }
+            h[(size_t)y * W + x] = re / ((double)H * W);
+        }
+}
+
+struct ProfScope {
+    Engine* e;
+    int kind;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(Engine* e_, int kind_, hipStream_t s_) : e(e_), kind(kind_), s(s_) {
+        if (e->profile) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (e->profile) {
+            (void)hipEventRecord(b, s);
+            e->prof[kind].pending.emplace_back(a, b);
+        }
+    }
+};
+
+void prof_drain(ProfSlot& p) {
+    for (auto& pr : p.pending) {
+        (void)hipEventSynchronize(pr.second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            p.total_ms += ms;
+            p.launches += 1;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    p.pending.clear();
+}
+
+size_t gain_lds_bytes(const View& v, int q_chunk) {
+    const size_t MC = v.meas_cap, QS = v.q_stride;
+    size_t b = (size_t)(q_chunk + 2 * kPipe) * QS * 4 + ((MC * MC + 3) & ~(size_t)3) * 4 + ((MC + 3) & ~(size_t)3) * 4 + 16 * 8;
+    if (v.mode == IPP_DENSE) b += (size_t)q_chunk * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int MC, int VEC>
+int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
+                const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s) {
+    const View& v = e->v;
+    {
+        ProfScope ps(e, 2, s);
+        if (v.mode == IPP_FACTOR)
+            hipLaunchKernelGGL((k_prepare<MC, IPP_FACTOR>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
+                               action, prev, noise, flags, status);
+        else
+            hipLaunchKernelGGL((k_prepare<MC, IPP_DENSE>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
+                               action, prev, noise, flags, status);
+    }
+    {
+        ProfScope ps(e, 0, s);
+        const int grid = grid_for(n, v.n_tiles);
+        if (v.mode == IPP_FACTOR)
+            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, reward);
+        else
+            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_DENSE>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, reward);
+    }
+    if (v.n_tiles > 1) hipLaunchKernelGGL(k_reward_finalize, dim3((n + 255) / 256), dim3(256), 0, s, v, n, reward);
+    if (v.mode == IPP_DENSE && !(flags & IPP_PREDICT_ONLY)) {
+        ProfScope ps(e, 1, s);
+        const int grid = grid_for(n, e->n_bands * v.n_tiles);
+        hipLaunchKernelGGL((k_downdate<MC, VEC>), dim3(grid), dim3(v.T), 0, s, v, n, e->n_bands);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+Engine* as_engine(void* p) { return reinterpret_cast<Engine*>(p); }
+
+int check_env(Engine* e, int env) {
+    if (env < 0 || env >= e->v.cap) return fail(-1, "env_id %d outside [0, %d)", env, e->v.cap);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipp_abi_version(void) { return IPP_ABI_VERSION; }
+const char* ipp_last_error(void) { return g_err.c_str(); }
+
+int ipp_engine_arena_bytes(const ipp_config* cfg, uint64_t* bytes) {
+    if (!cfg || !bytes) return fail(-1, "null argument");
+    Layout L;
+    if (int rc = plan(*cfg, L)) return rc;
+    *bytes = L.total;
+    return 0;
+}
+
+int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t arena_bytes, void** engine) {
+    if (!cfg || !arena || !engine) return fail(-1, "null argument");
+    Layout L;
+    if (int rc = plan(*cfg, L)) return rc;
+    if (arena_bytes < L.total) return fail(-1, "arena too small: %llu < %llu", (unsigned long long)arena_bytes, (unsigned long long)L.total);
+    if ((reinterpret_cast<uintptr_t>(arena) & (kAlign - 1)) != 0) return fail(-1, "arena must be %llu-byte aligned", (unsigned long long)kAlign);
+    HIP_TRY(hipSetDevice(device));
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return fail(-3, "out of host memory");
+    e->cfg = *cfg;
+    e->device = device;
+    e->used_bytes = L.total;
+    View& v = e->v;
+    v.W = cfg->x_dim; v.H = cfg->y_dim; v.N = L.N; v.Npad = L.Npad; v.T = L.T; v.n_tiles = L.n_tiles; v.vec = L.VEC; v.pad_ = 0;
+    v.mode = cfg->state_repr; v.cap = cfg->capacity; v.rank_cap = cfg->rank_cap; v.max_batch = cfg->max_batch;
+    v.meas_cap = L.MC; v.fp_cap = L.FC; v.q_stride = L.QS; v.q_rows = L.q_rows;
+    v.res = cfg->resolution; v.tanx = cfg->tan_half_fov_x; v.tany = cfg->tan_half_fov_y; v.rf_alt = cfg->rf_altitude;
+    v.coeff_a = cfg->coeff_a; v.coeff_b = cfg->coeff_b; v.sv0 = cfg->signal_variance; v.ls0 = cfg->length_scale;
+    v.vmax = cfg->max_v; v.amax = cfg->max_a; v.thr = cfg->value_threshold; v.kf = cfg->interval_factor;
+    char* base = reinterpret_cast<char*>(arena);
+    v.mean = reinterpret_cast<float*>(base + L.off_mean);
+    v.diag = reinterpret_cast<float*>(base + L.off_diag);
+    v.gt = reinterpret_cast<float*>(base + L.off_gt);
+    v.prior = reinterpret_cast<double*>(base + L.off_prior);
+    v.rank = reinterpret_cast<int*>(base + L.off_rank);
+    v.cov = reinterpret_cast<float*>(base + L.off_cov);
+    v.cov_slot = L.cov_slot_floats;
+    v.hdr = reinterpret_cast<ItemHdr*>(base + L.off_hdr);
+    v.linv = reinterpret_cast<float*>(base + L.off_linv);
+    v.yv = reinterpret_cast<float*>(base + L.off_yv);
+    v.q = reinterpret_cast<float*>(base + L.off_q);
+    v.wc = reinterpret_cast<float*>(base + L.off_wc);
+    v.partial = reinterpret_cast<double*>(base + L.off_partial);
+    v.dbg = reinterpret_cast<double*>(base + L.off_dbg);
+    v.grf_h = reinterpret_cast<double*>(base + L.off_grfh);
+    v.grf_raw = reinterpret_cast<float*>(base + L.off_grfraw);
+    e->n_bands = (L.N + kBandRows - 1) / kBandRows;
+    e->prep_lds = prep_lds_bytes(L, *cfg);
+    e->q_chunk = std::min(1024, (L.q_rows + 2 * kPipe - 1) / (2 * kPipe) * (2 * kPipe));
+    e->gain_lds = gain_lds_bytes(v, e->q_chunk);
+    if (e->prep_lds > 160 * 1024) {
+        delete e;
+        return fail(-1, "prologue needs %zu B of LDS (> 160 KiB): lower rank_cap or max_measurements", e->prep_lds);
+    }
+    // opt in to > 64 KiB dynamic LDS for the prologue instantiations
+    const int lds = (int)e->prep_lds;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<9, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<9, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int glds = (int)e->gain_lds;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipGetLastError();
+    // state starts zeroed (rank 0, padding 0); envs must still be ipp_reset before use
+    HIP_TRY(hipMemset(base, 0, L.off_cov));
+    HIP_TRY(hipMemset(base + L.off_hdr, 0, L.total - L.off_hdr));
+    if (cfg->x_dim == cfg->y_dim) {
+        std::vector<double> h;
+        grf_kernel_host(cfg->y_dim, cfg->x_dim, cfg->cluster_radius, h);
+        HIP_TRY(hipMemcpy(v.grf_h, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    *engine = e;
+    return 0;
+}
+
+int ipp_engine_destroy(void* engine) {
+    Engine* e = as_engine(engine);
+    if (!e) return 0;
+    for (auto& p : e->prof) prof_drain(p);
+    delete e;
+    return 0;
+}
+
+int ipp_engine_info(void* engine, ipp_info* out) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    out->abi_version = IPP_ABI_VERSION;
+    out->n_cells = e->v.N;
+    out->n_pad = e->v.Npad;
+    out->tile_threads = e->v.T;
+    out->n_tiles = e->v.n_tiles;
+    out->meas_cap = e->v.meas_cap;
+    out->fp_cap = e->v.fp_cap;
+    out->reserved = 0;
+    out->arena_bytes = e->used_bytes;
+    out->cov_slot_bytes = e->v.cov_slot * 4;
+    return 0;
+}
+
+int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
+              const float* white_noise, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    if (!env_ids && n > e->v.cap) return fail(-1, "n exceeds capacity");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const View& v = e->v;
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_reset_small, dim3((v.Npad + 255) / 256, n), dim3(256), 0, s, v, env_ids, n, prior_scale, gt);
+    if (!gt && white_noise) {
+        if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
+        hipLaunchKernelGGL(k_grf_conv, dim3((v.N + 255) / 256, n), dim3(256), 0, s, v, n, white_noise);
+        hipLaunchKernelGGL(k_grf_norm, dim3(n), dim3(256), 0, s, v, env_ids, n);
+    }
+    if (v.mode == IPP_DENSE) {
+        const int n_ctiles = (v.Npad + 1023) / 1024;
+        const int grid = grid_for(n, e->n_bands * n_ctiles);
+        hipLaunchKernelGGL(k_reset_dense, dim3(grid), dim3(256), 0, s, v, env_ids, n, e->n_bands, n_ctiles);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
+             const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
+             void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (!action || !prev_action || !reward) return fail(-1, "action, prev_action and reward are required");
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    if (!env_ids && n > e->v.cap) return fail(-1, "n exceeds capacity");
+    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME)) return fail(-1, "unknown flag bits 0x%x", flags);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    e->last_n = n;
+    if (e->v.mode == IPP_FACTOR && dst_ids && !(flags & IPP_PREDICT_ONLY)) {
+        // factor state: an out-of-place step is a slot copy followed by an in-place step on the copy
+        // (the dense downdate kernel writes P_dst = P_src - Wc Wc^T directly instead)
+        if (!env_ids) return fail(-1, "dst_ids needs explicit env_ids");
+        if (int rc = ipp_fork(engine, env_ids, dst_ids, n, stream)) return rc;
+        env_ids = dst_ids;
+        dst_ids = nullptr;
+    }
+    if (e->v.meas_cap == 9)
+        return launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
+    return launch_step<25, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
+}
+
+int ipp_set_adaptive(void* engine, double value_threshold, double interval_factor) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    e->v.thr = value_threshold;
+    e->v.kf = interval_factor;
+    return 0;
+}
+
+int ipp_fork(void* engine, const int32_t* src_ids, const int32_t* dst_ids, int32_t n, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !src_ids || !dst_ids) return fail(-1, "null argument");
+    if (n <= 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t n4 = e->v.cov_slot / 4;
+    int chunks = (int)std::min<uint64_t>(512, (n4 + 1023) / 1024);
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(k_fork, dim3(chunks, n), dim3(256), 0, s, e->v, src_ids, dst_ids, n);
+    hipLaunchKernelGGL(k_fork_rank, dim3((n + 255) / 256), dim3(256), 0, s, e->v, src_ids, dst_ids, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int read_row(Engine* e, const float* slab, int env, float* out, void* stream) {
+    if (!e || !out) return fail(-1, "null argument");
+    if (int rc = check_env(e, env)) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(out, slab + (size_t)env * e->v.Npad, (size_t)e->v.N * 4, hipMemcpyDeviceToDevice,
+                           reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+}
+int ipp_read_mean(void* engine, int32_t env_id, float* out, void* stream) { Engine* e = as_engine(engine); return read_row(e, e ? e->v.mean : nullptr, env_id, out, stream); }
+int ipp_read_diag(void* engine, int32_t env_id, float* out, void* stream) { Engine* e = as_engine(engine); return read_row(e, e ? e->v.diag : nullptr, env_id, out, stream); }
+int ipp_read_gt(void* engine, int32_t env_id, float* out, void* stream) { Engine* e = as_engine(engine); return read_row(e, e ? e->v.gt : nullptr, env_id, out, stream); }
+
+int ipp_read_cov_dense(void* engine, int32_t env_id, float* out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (int rc = check_env(e, env_id)) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const View& v = e->v;
+    if (v.mode == IPP_DENSE) {
+        HIP_TRY(hipMemcpy2DAsync(out, (size_t)v.N * 4, v.cov + (size_t)env_id * v.cov_slot, (size_t)v.Npad * 4,
+                                 (size_t)v.N * 4, v.N, hipMemcpyDeviceToDevice, s));
+    } else {
+        hipLaunchKernelGGL(k_read_cov_factor, dim3((v.N + 255) / 256, v.N), dim3(256), 0, s, v, env_id, out);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int ipp_read_rank(void* engine, int32_t env_id, int32_t* rank, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !rank) return fail(-1, "null argument");
+    if (int rc = check_env(e, env_id)) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(rank, e->v.rank + env_id, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int write_row(Engine* e, float* slab, int env, const float* in, void* stream) {
+    if (!e || !in) return fail(-1, "null argument");
+    if (int rc = check_env(e, env)) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(slab + (size_t)env * e->v.Npad, in, (size_t)e->v.N * 4, hipMemcpyDeviceToDevice,
+                           reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+}
+int ipp_write_mean(void* engine, int32_t env_id, const float* mean, void* stream) { Engine* e = as_engine(engine); return write_row(e, e ? e->v.mean : nullptr, env_id, mean, stream); }
+int ipp_write_gt(void* engine, int32_t env_id, const float* gt, void* stream) { Engine* e = as_engine(engine); return write_row(e, e ? e->v.gt : nullptr, env_id, gt, stream); }
+
+int ipp_write_cov_dense(void* engine, int32_t env_id, const float* P, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !P) return fail(-1, "null argument");
+    if (int rc = check_env(e, env_id)) return rc;
+    const View& v = e->v;
+    if (v.mode != IPP_DENSE) return fail(-1, "ipp_write_cov_dense needs an IPP_DENSE engine (a factor state cannot hold an arbitrary P)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy2DAsync(v.cov + (size_t)env_id * v.cov_slot, (size_t)v.Npad * 4, P, (size_t)v.N * 4, (size_t)v.N * 4,
+                             v.N, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_dense_fixup, dim3((v.N + 255) / 256), dim3(256), 0, s, v, env_id);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_metrics(void* engine, const int32_t* env_ids, int32_t n, float* out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (n <= 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_metrics, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, env_ids, n, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_fill_normal(void* engine, float* out, uint64_t count, uint64_t seed, uint64_t subsequence, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t quads = (count + 3) / 4;
+    hipLaunchKernelGGL(k_fill_normal, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), out, count, seed, subsequence);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (idx < 0 || idx >= e->last_n) return fail(-1, "item %d outside the last step's batch of %d", idx, e->last_n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const int MC = e->v.meas_cap;
+    ItemHdr h;
+    std::vector<double> d((size_t)2 * MC * MC + 2 * MC);
+    HIP_TRY(hipMemcpyAsync(&h, e->v.hdr + idx, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(d.data(), e->v.dbg + (size_t)idx * d.size(), d.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memset(out, 0, sizeof *out);
+    out->env = h.env; out->dst = h.dst; out->rank_before = h.rank; out->status = h.status;
+    out->xl = h.xl; out->xr = h.xr; out->yu = h.yu; out->yd = h.yd;
+    out->rf = h.rf; out->m = h.m; out->f = h.f;
+    out->cost = h.cost_d;
+    out->noise_var = h.nv_d;
+    for (int i = 0; i < h.m; ++i)
+        for (int j = 0; j < h.m; ++j) {
+            out->S[i * h.m + j] = d[(size_t)i * MC + j];
+            out->Linv[i * h.m + j] = d[(size_t)MC * MC + i * MC + j];
+        }
+    for (int i = 0; i < h.m; ++i) {
+        out->z[i] = d[(size_t)2 * MC * MC + i];
+        out->y[i] = d[(size_t)2 * MC * MC + MC + i];
+    }
+    return 0;
+}
+
+int ipp_profile_enable(void* engine, int32_t enable) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    e->profile = enable != 0;
+    return 0;
+}
+
+int ipp_profile_read(void* engine, int32_t kind, double* avg_ms, int64_t* launches, int32_t reset) {
+    Engine* e = as_engine(engine);
+    if (!e || kind < 0 || kind > 2) return fail(-1, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    ProfSlot& p = e->prof[kind];
+    prof_drain(p);
+    if (avg_ms) *avg_ms = p.launches ? p.total_ms / (double)p.launches : 0.0;
+    if (launches) *launches = p.launches;
+    if (reset) { p.total_ms = 0.0; p.launches = 0; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,349 @@
+// Streaming kernels of the env step.
+//
+// k_gain: Wc = base + rows * Q for one tile of cells of one item, fused with everything that consumes Wc
+// (mapping/mappings.py:188-197, planning/common/rewards.py:8-31):
+//   factor state : rows = U[k][:] (k < rank), base = P0[:,F] H_F^T L^-1 evaluated from the analytic prior
+//   dense state  : rows = P[F_f][:] (f footprint rows; P symmetric so rows == columns), base = 0
+//   epilogue     : masked trace reduction -> reward, diag -= |Wc_i|^2, mean += Wc y, append Wc to U
+//                  (factor) or park Wc for the downdate kernel (dense).
+// k_downdate (dense only): P -= Wc Wc^T, one pass over P (mapping/mappings.py:190).
+//
+// Both are HBM-bound: every streamed 16 B feed 4*MC FMAs, the small operand (Q / Wc rows) is broadcast
+// from LDS, consecutive lanes read consecutive 16 B (1 KiB per wave instruction), and the row loads are
+// software-pipelined kPipe deep so each wave keeps kPipe KiB in flight.
+#pragma once
+#include "ipp_common.h"
+
+namespace ipp {
+
+constexpr int kPipe = 4;  // row loads in flight per wave
+
+template <int VEC> struct VecIO;
+template <> struct VecIO<4> {
+    using T = float4;
+    static __device__ __forceinline__ void unpack(const float4& a, float (&o)[4]) { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+    static __device__ __forceinline__ float4 pack(const float (&o)[4]) { return make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct VecIO<2> {
+    using T = float2;
+    static __device__ __forceinline__ void unpack(const float2& a, float (&o)[2]) { o[0] = a.x; o[1] = a.y; }
+    static __device__ __forceinline__ float2 pack(const float (&o)[2]) { return make_float2(o[0], o[1]); }
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&o)[VEC]) {
+    VecIO<VEC>::unpack(*reinterpret_cast<const typename VecIO<VEC>::T*>(p), o);
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&o)[VEC]) {
+    *reinterpret_cast<typename VecIO<VEC>::T*>(p) = VecIO<VEC>::pack(o);
+}
+
+// acc[c][j] += sum_k row_k[cell0 + c] * Q[k][j] over the `cnt` rows whose Q is staged in Qs (the prologue
+// stores Q with the sign of the update folded in).
+// rowidx (LDS) maps the streaming index to the row of the covariance slab (dense: footprint cell).
+template <int MC, int VEC, int MODE>
+__device__ __forceinline__ void stream_rows(const float* __restrict__ cov_src,
+                                            const int* rowidx, int k0, int cnt, int last_row, size_t npad, int cell0,
+                                            const float* Qs, float (&acc)[VEC][MC]) {
+    constexpr int QS = (MC + 3) & ~3;
+    // the row base is wave-uniform (SGPR pair); only the 32-bit cell offset is per lane
+    auto row_base = [&](int k) -> size_t {
+        const int kc = min(k, last_row);  // rows past the end re-read the last row against a zero Q row
+        const int ridx = (MODE == IPP_FACTOR) ? kc : __builtin_amdgcn_readfirstlane(rowidx[kc]);
+        return (size_t)ridx * npad;
+    };
+    // ping-pong register buffers: while one group of kPipe rows is consumed the next is in flight
+    auto consume = [&](const float (&u)[kPipe][VEC], int kbase) {
+#pragma unroll
+        for (int i = 0; i < kPipe; ++i) {
+            float qv[QS];
+#pragma unroll
+            for (int t4 = 0; t4 < QS / 4; ++t4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&Qs[(kbase + i) * QS + 4 * t4]);
+                qv[4 * t4 + 0] = q4.x; qv[4 * t4 + 1] = q4.y; qv[4 * t4 + 2] = q4.z; qv[4 * t4 + 3] = q4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(u[i][c], qv[j], acc[c][j]);
+        }
+    };
+    float ua[kPipe][VEC], ub[kPipe][VEC];
+#pragma unroll
+    for (int i = 0; i < kPipe; ++i) load_vec<VEC>(cov_src + row_base(k0 + i) + cell0, ua[i]);
+    for (int kk = 0; kk < cnt; kk += 2 * kPipe) {
+#pragma unroll
+        for (int i = 0; i < kPipe; ++i) load_vec<VEC>(cov_src + row_base(k0 + kk + kPipe + i) + cell0, ub[i]);
+        consume(ua, kk);
+#pragma unroll
+        for (int i = 0; i < kPipe; ++i) load_vec<VEC>(cov_src + row_base(k0 + kk + 2 * kPipe + i) + cell0, ua[i]);
+        consume(ub, kk + kPipe);
+    }
+}
+
+template <int MC, int VEC, int MODE>
+__global__ __launch_bounds__(kMaxTileThreads, 4) void k_gain(View v, int n_items, unsigned flags, int q_chunk,
+                                                             float* __restrict__ reward_out) {
+    constexpr int QS = (MC + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gain[];
+    // LDS carve: Qs[q_chunk + 2*kPipe][QS] | Ls[MC*MC] | ys[MC] (padded) | red[16] doubles | rowidx[q_chunk] (dense)
+    float* Qs = reinterpret_cast<float*>(smem_gain);
+    float* Ls = Qs + (size_t)(q_chunk + 2 * kPipe) * QS;
+    float* ys = Ls + ((MC * MC + 3) & ~3);
+    double* red = reinterpret_cast<double*>(ys + ((MC + 3) & ~3));
+    int* rowidx = reinterpret_cast<int*>(red + 16);
+
+    int item, tile;
+    if (!decode_block(blockIdx.x, n_items, v.n_tiles, item, tile)) return;
+    const int tid = threadIdx.x;
+    const ItemHdr h = v.hdr[item];
+    const int m = h.m;
+    const int T = blockDim.x;
+
+    if (m == 0 || h.status == IPP_STATUS_NOT_PD) {
+        if (tid == 0) {
+            const double bad = (h.status == IPP_STATUS_NOT_PD) ? (double)NAN : 0.0;
+            if (v.n_tiles == 1) reward_out[item] = (float)bad; else v.partial[(size_t)item * v.n_tiles + tile] = bad;
+        }
+        return;
+    }
+
+    const int cell0 = tile * VEC * T + VEC * tid;
+    const float* __restrict__ qg = v.q + (size_t)item * v.q_rows * v.q_stride;
+    const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
+    float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
+    const int rows = h.rows;
+
+    for (int i = tid; i < MC * MC; i += T) Ls[i] = v.linv[(size_t)item * MC * MC + i];
+    if (tid < MC) ys[tid] = v.yv[(size_t)item * MC + tid];
+    if (MODE == IPP_DENSE)
+        for (int i = tid; i < rows; i += T) rowidx[i] = (h.yu + i / h.w) * v.W + h.xl + i % h.w;
+    __syncthreads();
+
+    float acc[VEC][MC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c)
+#pragma unroll
+        for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+
+    // ------------------------------------------------------------------ base term from the analytic prior
+    if (MODE == IPP_FACTOR) {
+        const float s3 = (float)(kSqrt3 * v.res) / h.ls;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const int cell = cell0 + c;
+            const int row = cell / v.W, col = cell - row * v.W;
+            for (int b = 0; b < m; ++b) {
+                const Block blk = block_of(b, h.nx, h.rf, h.w, h.h);
+                float cb = 0.f;
+                for (int a = 0; a < blk.count(); ++a) {
+                    const int ly = blk.y0 + a / blk.bw, lx = blk.x0 + a % blk.bw;
+                    cb += matern_f(row - (h.yu + ly), col - (h.xl + lx), s3, h.sv);
+                }
+                cb *= (float)blk.weight;
+#pragma unroll
+                for (int j = 0; j < MC; ++j) acc[c][j] = fmaf(cb, Ls[b * MC + j], acc[c][j]);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ streaming loop
+    for (int k0 = 0; k0 < rows; k0 += q_chunk) {
+        const int cnt = min(q_chunk, rows - k0);
+        if (k0 > 0) __syncthreads();
+        {
+            const float4* src = reinterpret_cast<const float4*>(qg + (size_t)k0 * QS);
+            float4* dst = reinterpret_cast<float4*>(Qs);
+            const int n4 = cnt * (QS / 4), tot4 = (cnt + 2 * kPipe) * (QS / 4);
+            for (int i = tid; i < tot4; i += T) dst[i] = (i < n4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        stream_rows<MC, VEC, MODE>(cov_src, rowidx, k0, cnt, rows - 1, (size_t)v.Npad, cell0, Qs, acc);
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    float mean_in[VEC], diag_in[VEC];
+    load_vec<VEC>(v.mean + (size_t)h.env * v.Npad + cell0, mean_in);
+    load_vec<VEC>(v.diag + (size_t)h.env * v.Npad + cell0, diag_in);
+    float dred[VEC], dmean[VEC];
+    double part = 0.0;
+    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const bool valid = (cell0 + c) < v.N;
+        float w2 = 0.f, dm = 0.f;
+        if (h.fallback) {
+            // acc = Y = P H^T ; Z = Y S^-1 ; diag(P - Y S^-1 Y^T), x + Y S^-1 v   (mappings.py:204-212)
+            for (int j = 0; j < m; ++j) {
+                float zj = 0.f;
+#pragma unroll
+                for (int i = 0; i < MC; ++i) zj = fmaf(acc[c][i], Ls[i * MC + j], zj);
+                float aj = 0.f;
+#pragma unroll
+                for (int i = 0; i < MC; ++i) aj = (i == j) ? acc[c][i] : aj;
+                w2 = fmaf(aj, zj, w2);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
+        }
+#pragma unroll
+        for (int j = 0; j < MC; ++j) dm = fmaf(acc[c][j], ys[j], dm);
+        if (!valid) {
+            w2 = 0.f; dm = 0.f;
+#pragma unroll
+            for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+        }
+        dred[c] = w2;
+        dmean[c] = dm;
+        // rewards.py:11 mask from the pre-step mean and pre-step diag(P); rewards.py:23-30 trace reduction
+        const bool in_mask = !adaptive || ((double)mean_in[c] + v.kf * (double)diag_in[c] >= v.thr);
+        if (valid && in_mask) part += (double)w2;
+    }
+    part = wave_sum(part);
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (T + kWave - 1) / kWave; ++w) tot += red[w];
+        if (v.n_tiles == 1)
+            reward_out[item] = (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
+        else
+            v.partial[(size_t)item * v.n_tiles + tile] = tot;
+    }
+
+    if (!h.commit) return;
+    float outv[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
+    store_vec<VEC>(v.diag + (size_t)h.dst * v.Npad + cell0, outv);
+    if (!(flags & IPP_COV_ONLY)) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) outv[c] = mean_in[c] + dmean[c];
+        store_vec<VEC>(v.mean + (size_t)h.dst * v.Npad + cell0, outv);
+    } else if (h.dst != h.env) {
+        store_vec<VEC>(v.mean + (size_t)h.dst * v.Npad + cell0, mean_in);
+    }
+    if (h.dst != h.env) {
+        float g[VEC];
+        load_vec<VEC>(v.gt + (size_t)h.env * v.Npad + cell0, g);
+        store_vec<VEC>(v.gt + (size_t)h.dst * v.Npad + cell0, g);
+        if (tile == 0 && tid == 0) {
+            v.prior[2 * h.dst + 0] = v.prior[2 * h.env + 0];
+            v.prior[2 * h.dst + 1] = v.prior[2 * h.env + 1];
+        }
+    }
+    if (MODE == IPP_FACTOR) {
+        // append the m new columns (rows of the [k][cell] layout): coalesced row writes
+#pragma unroll
+        for (int j = 0; j < MC; ++j)
+            if (j < m) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
+                store_vec<VEC>(cov_dst + (size_t)(h.rank + j) * v.Npad + cell0, outv);
+            }
+        if (tile == 0 && tid == 0) v.rank[h.dst] = h.rank + m;
+    } else {
+        float* wc = v.wc + (size_t)item * MC * v.Npad + cell0;
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
+            store_vec<VEC>(wc + (size_t)j * v.Npad, outv);
+        }
+    }
+}
+
+// Sum the per-tile reward partials in a fixed order (bit-reproducible regardless of GPU count).
+__global__ void k_reward_finalize(View v, int n_items, float* __restrict__ reward_out) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    double tot = 0.0;
+    for (int t = 0; t < v.n_tiles; ++t) tot += v.partial[(size_t)item * v.n_tiles + t];
+    reward_out[item] = (float)(tot / (v.hdr[item].cost_d + 1.0));
+}
+
+// Dense state: P_dst = P_src - Wc Wc^T (mapping/mappings.py:190), or P - Y S^-1 Y^T on the fallback
+// path (:206).  One workgroup = kBandRows rows x one column tile; in place when dst == src.
+template <int MC, int VEC>
+__global__ __launch_bounds__(kMaxTileThreads, 4) void k_downdate(View v, int n_items, int n_bands) {
+    constexpr int QS = (MC + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float wi[(kBandRows + 2 * kPipe) * QS];
+    __shared__ float Ss[MC * MC];
+    int item, part;
+    if (!decode_block(blockIdx.x, n_items, n_bands * v.n_tiles, item, part)) return;
+    const ItemHdr h = v.hdr[item];
+    if (!h.commit || h.m == 0) return;
+    const int band = part / v.n_tiles, tile = part - band * v.n_tiles;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int cell0 = tile * VEC * T + VEC * tid;
+    const int row0 = band * kBandRows;
+    const int nrows = min(kBandRows, v.N - row0);
+    const float* wc = v.wc + (size_t)item * MC * v.Npad;
+
+    for (int i = tid; i < (kBandRows + 2 * kPipe) * QS; i += T) {
+        const int rr = i / QS, j = i - rr * QS;
+        wi[i] = (rr < nrows && j < MC) ? -wc[(size_t)j * v.Npad + row0 + rr] : 0.f;  // negated once here
+    }
+    if (h.fallback)
+        for (int i = tid; i < MC * MC; i += T) Ss[i] = v.linv[(size_t)item * MC * MC + i];
+
+    float wj[VEC][MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+        float t[VEC];
+        load_vec<VEC>(wc + (size_t)j * v.Npad + cell0, t);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) wj[c][j] = t[c];
+    }
+    __syncthreads();
+    if (h.fallback) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float zj[MC];
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < MC; ++i) s = fmaf(wj[c][i], Ss[i * MC + j], s);
+                zj[j] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j) wj[c][j] = zj[j];
+        }
+    }
+    const float* psrc = v.cov + (size_t)h.env * v.cov_slot + (size_t)row0 * v.Npad + cell0;
+    float* pdst = v.cov + (size_t)h.dst * v.cov_slot + (size_t)row0 * v.Npad + cell0;
+    const int last = nrows - 1;
+    auto apply = [&](float (&p)[kPipe][VEC], int rbase) {
+#pragma unroll
+        for (int i = 0; i < kPipe; ++i) {
+            float a[QS];
+#pragma unroll
+            for (int t4 = 0; t4 < QS / 4; ++t4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&wi[(rbase + i) * QS + 4 * t4]);
+                a[4 * t4 + 0] = q4.x; a[4 * t4 + 1] = q4.y; a[4 * t4 + 2] = q4.z; a[4 * t4 + 3] = q4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) p[i][c] = fmaf(a[j], wj[c][j], p[i][c]);
+            if (rbase + i < nrows) store_vec<VEC>(pdst + (size_t)(rbase + i) * v.Npad, p[i]);
+        }
+    };
+    float pa[kPipe][VEC], pb[kPipe][VEC];
+#pragma unroll
+    for (int i = 0; i < kPipe; ++i) load_vec<VEC>(psrc + (size_t)min(i, last) * v.Npad, pa[i]);
+    for (int rr = 0; rr < nrows; rr += 2 * kPipe) {
+#pragma unroll
+        for (int i = 0; i < kPipe; ++i) load_vec<VEC>(psrc + (size_t)min(rr + kPipe + i, last) * v.Npad, pb[i]);
+        apply(pa, rr);
+#pragma unroll
+        for (int i = 0; i < kPipe; ++i) load_vec<VEC>(psrc + (size_t)min(rr + 2 * kPipe + i, last) * v.Npad, pa[i]);
+        apply(pb, rr + kPipe);
+    }
+}
+
+}  // namespace ipp

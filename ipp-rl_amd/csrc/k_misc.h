@@ -1,0 +1,249 @@
+// Episode reset, ground-truth generation, state copies, materialisation, metrics and RNG kernels.
+#pragma once
+#include "ipp_common.h"
+
+namespace ipp {
+
+// mean <- 0.5, diag <- sigma^2, rank <- 0, prior <- (sigma^2, l); optional ground-truth install.
+// mapping/mappings.py:235-240,259-261.
+__global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_items,
+                              const double* __restrict__ prior_scale, const float* __restrict__ gt_in) {
+    const int item = blockIdx.y;
+    if (item >= n_items) return;
+    const int env = env_ids ? env_ids[item] : item;
+    if (env < 0 || env >= v.cap) return;
+    const double sv = prior_scale ? prior_scale[2 * item + 0] : v.sv0;
+    const double ls = prior_scale ? prior_scale[2 * item + 1] : v.ls0;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell == 0) {
+        v.rank[env] = 0;
+        v.prior[2 * env + 0] = sv;
+        v.prior[2 * env + 1] = ls;
+    }
+    if (cell >= v.Npad) return;
+    const bool valid = cell < v.N;
+    v.mean[(size_t)env * v.Npad + cell] = valid ? 0.5f : 0.f;
+    v.diag[(size_t)env * v.Npad + cell] = valid ? (float)sv : 0.f;
+    if (gt_in) v.gt[(size_t)env * v.Npad + cell] = valid ? gt_in[(size_t)item * v.N + cell] : 0.f;
+}
+
+// Dense state: P <- Matern prior (mapping/mappings.py:242-261).  Workgroup = kBandRows rows x 1024 columns.
+__global__ __launch_bounds__(256) void k_reset_dense(View v, const int* __restrict__ env_ids, int n_items, int n_bands,
+                                                     int n_ctiles) {
+    int item, part;
+    if (!decode_block(blockIdx.x, n_items, n_bands * n_ctiles, item, part)) return;
+    const int env = env_ids ? env_ids[item] : item;
+    if (env < 0 || env >= v.cap) return;
+    const int band = part / n_ctiles, tile = part - band * n_ctiles;
+    const int cell0 = tile * 1024 + 4 * threadIdx.x;
+    if (cell0 >= v.Npad) return;
+    const double sv = v.prior[2 * env + 0], ls = v.prior[2 * env + 1];
+    int cr[4], cc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cr[c] = (cell0 + c) / v.W; cc[c] = (cell0 + c) - cr[c] * v.W; }
+    float* P = v.cov + (size_t)env * v.cov_slot;
+    const int row0 = band * kBandRows, nrows = min(kBandRows, v.N - row0);
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int i = row0 + rr, ri = i / v.W, ci = i - ri * v.W;
+        float out[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            out[c] = (cell0 + c < v.N) ? (float)matern_d(ri - cr[c], ci - cc[c], v.res, sv, ls) : 0.f;
+        *reinterpret_cast<float4*>(P + (size_t)i * v.Npad + cell0) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// GRF as a circular convolution: field = white (*) h, h = Re ifft2(amp) (simulations/ground_truths.py:14-31;
+// amp is real and even so Re ifft2(fft2(white) * amp) is exactly this convolution).  fp64 accumulate.
+__global__ __launch_bounds__(256) void k_grf_conv(View v, int n_items, const float* __restrict__ white) {
+    const int item = blockIdx.y;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items || cell >= v.N) return;
+    const int y = cell / v.W, x = cell - y * v.W;
+    const float* wn = white + (size_t)item * v.N;
+    double acc = 0.0;
+    for (int yp = 0; yp < v.H; ++yp) {
+        int hy = y - yp;
+        if (hy < 0) hy += v.H;
+        const double* hrow = v.grf_h + (size_t)hy * v.W;
+        const float* wrow = wn + (size_t)yp * v.W;
+        for (int xp = 0; xp < v.W; ++xp) {
+            int hx = x - xp;
+            if (hx < 0) hx += v.W;
+            acc = fma((double)wrow[xp], hrow[hx], acc);
+        }
+    }
+    v.grf_raw[(size_t)item * v.Npad + cell] = (float)acc;
+}
+
+// min-max normalisation to [0, 1] (simulations/ground_truths.py:31).
+__global__ __launch_bounds__(256) void k_grf_norm(View v, const int* __restrict__ env_ids, int n_items) {
+    __shared__ float smin[4], smax[4];
+    const int item = blockIdx.x;
+    const int env = env_ids ? env_ids[item] : item;
+    if (env < 0 || env >= v.cap) return;
+    const float* raw = v.grf_raw + (size_t)item * v.Npad;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < v.N; i += blockDim.x) { lo = fminf(lo, raw[i]); hi = fmaxf(hi, raw[i]); }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    lo = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    hi = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    const double dlo = lo, span = (double)hi - (double)lo;
+    float* gt = v.gt + (size_t)env * v.Npad;
+    for (int i = threadIdx.x; i < v.Npad; i += blockDim.x) gt[i] = (i < v.N) ? (float)(((double)raw[i] - dlo) / span) : 0.f;
+}
+
+// State slot copy (tree-search children).  grid = (chunks, n); float4 grid-stride over the covariance slab.
+__global__ __launch_bounds__(256) void k_fork(View v, const int* __restrict__ src_ids, const int* __restrict__ dst_ids,
+                                              int n_items) {
+    const int item = blockIdx.y;
+    if (item >= n_items) return;
+    const int s = src_ids[item], d = dst_ids[item];
+    if (s < 0 || s >= v.cap || d < 0 || d >= v.cap || s == d) return;
+    const int r = (v.mode == IPP_FACTOR) ? v.rank[s] : v.N;
+    const size_t n4 = (size_t)r * v.Npad / 4;
+    const float4* cs = reinterpret_cast<const float4*>(v.cov + (size_t)s * v.cov_slot);
+    float4* cd = reinterpret_cast<float4*>(v.cov + (size_t)d * v.cov_slot);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) cd[i] = cs[i];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < v.Npad; i += blockDim.x) {
+            v.mean[(size_t)d * v.Npad + i] = v.mean[(size_t)s * v.Npad + i];
+            v.diag[(size_t)d * v.Npad + i] = v.diag[(size_t)s * v.Npad + i];
+            v.gt[(size_t)d * v.Npad + i] = v.gt[(size_t)s * v.Npad + i];
+        }
+        if (threadIdx.x == 0) {
+            v.prior[2 * d + 0] = v.prior[2 * s + 0];
+            v.prior[2 * d + 1] = v.prior[2 * s + 1];
+        }
+    }
+}
+// rank is written by a second tiny launch so that k_fork never reads a rank another block already replaced
+__global__ void k_fork_rank(View v, const int* __restrict__ src_ids, const int* __restrict__ dst_ids, int n_items) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const int s = src_ids[item], d = dst_ids[item];
+    if (s < 0 || s >= v.cap || d < 0 || d >= v.cap) return;
+    v.rank[d] = v.rank[s];
+}
+
+// Factor state -> dense P = P0 - U U^T for callers that need the matrix (np.diag(state), feature planes).
+__global__ __launch_bounds__(256) void k_read_cov_factor(View v, int env, float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.N || j >= v.N) return;
+    const double sv = v.prior[2 * env + 0], ls = v.prior[2 * env + 1];
+    const int ri = i / v.W, ci = i - ri * v.W, rj = j / v.W, cj = j - rj * v.W;
+    double acc = matern_d(ri - rj, ci - cj, v.res, sv, ls);
+    const float* U = v.cov + (size_t)env * v.cov_slot;
+    const int r = v.rank[env];
+    for (int k = 0; k < r; ++k) acc -= (double)U[(size_t)k * v.Npad + i] * (double)U[(size_t)k * v.Npad + j];
+    out[(size_t)i * v.N + j] = (float)acc;
+}
+
+// diag <- diag(P) after a dense injection; also clears the row padding.
+__global__ void k_dense_fixup(View v, int env) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.N) return;
+    float* P = v.cov + (size_t)env * v.cov_slot;
+    v.diag[(size_t)env * v.Npad + i] = P[(size_t)i * v.Npad + i];
+    for (int j = v.N; j < v.Npad; ++j) P[(size_t)i * v.Npad + j] = 0.f;
+}
+
+// planning/evaluation_metrics.py:4-58 fused into one pass pair per env (mask = gt >= value_threshold,
+// planning/missions.py:179).  out[item][8] = rmse, masked rmse, wrmse, mll, wmll, trace, masked trace, diff.
+__global__ __launch_bounds__(256) void k_metrics(View v, const int* __restrict__ env_ids, int n_items,
+                                                 float* __restrict__ out) {
+    __shared__ double red[4][8];
+    const int item = blockIdx.x;
+    const int env = env_ids ? env_ids[item] : item;
+    if (env < 0 || env >= v.cap) return;
+    const float* gt = v.gt + (size_t)env * v.Npad;
+    const float* est = v.mean + (size_t)env * v.Npad;
+    const float* dg = v.diag + (size_t)env * v.Npad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pass 1: extrema and the weight normaliser
+    float gmin = INFINITY, gmax = -INFINITY, emin = INFINITY;
+    double gsum = 0.0;
+    for (int i = tid; i < v.N; i += blockDim.x) {
+        gmin = fminf(gmin, gt[i]); gmax = fmaxf(gmax, gt[i]); emin = fminf(emin, est[i]);
+        gsum += (double)gt[i];
+    }
+    gmin = wave_min(gmin); gmax = wave_max(gmax); emin = wave_min(emin); gsum = wave_sum(gsum);
+    if (lane == 0) { red[wave][0] = gmin; red[wave][1] = gmax; red[wave][2] = emin; red[wave][3] = gsum; }
+    __syncthreads();
+    const double g_lo = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+    const double g_hi = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+    const double e_lo = fmin(fmin(red[0][2], red[1][2]), fmin(red[2][2], red[3][2]));
+    const double g_sum = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+    __syncthreads();
+    const double range = g_hi - g_lo;
+    const double wsum = (g_sum - v.N * e_lo) / range;  // sum of (gt - min(est)) / range
+    // pass 2
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // se, se_mask, n_mask, w*se, ll, w*ll, tr, tr_mask
+    for (int i = tid; i < v.N; i += blockDim.x) {
+        const double g = gt[i], e = est[i], p = dg[i];
+        const double se = (g - e) * (g - e);
+        const double w = ((g - e_lo) / range) / wsum;
+        const double ll = 0.5 * log(2.0 * M_PI * p) + se / 2.0 * p;  // precedence as in evaluation_metrics.py:44
+        const bool mk = (double)gt[i] >= v.thr;
+        s[0] += se; s[3] += w * se; s[4] += ll; s[5] += w * ll; s[6] += p;
+        if (mk) { s[1] += se; s[2] += 1.0; s[7] += p; }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = wave_sum(s[q]);
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) red[wave][q] = s[q];
+    __syncthreads();
+    if (tid == 0) {
+        double t[8];
+        for (int q = 0; q < 8; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        const double n = v.N, nm = t[2], nu = n - nm;
+        float* o = out + (size_t)item * 8;
+        o[0] = (float)sqrt(t[0] / n);
+        o[1] = (float)sqrt(t[1] / nm);
+        o[2] = (float)sqrt(t[3] / n);
+        o[3] = (float)(t[4] / n);
+        o[4] = (float)(t[5] / n);
+        o[5] = (float)t[6];
+        o[6] = (float)t[7];
+        const double mu_u = (t[6] - t[7]) / nu, mu_i = t[7] / nm;
+        o[7] = (float)((mu_u - mu_i) / mu_u);
+    }
+}
+
+// Philox4x32-10 counter-based generator + Box-Muller.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__global__ void k_fill_normal(float* __restrict__ out, uint64_t count, uint64_t seed, uint64_t subseq) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= count) return;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)subseq, (uint32_t)(subseq >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    float nrm[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u0 = ((float)c[2 * p] + 0.5f) * 2.3283064365386963e-10f;
+        const float u1 = ((float)c[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.0f * logf(fmaxf(u0, 1e-30f)));
+        float sn, cs;
+        sincosf(6.283185307179586f * u1, &sn, &cs);
+        nrm[2 * p] = rad * cs;
+        nrm[2 * p + 1] = rad * sn;
+    }
+    for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < count) out[q * 4 + e] = nrm[e];
+}
+
+}  // namespace ipp

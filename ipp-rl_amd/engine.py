@@ -1,0 +1,277 @@
+"""
+Python handle on the HIP step engine (C-ABI in include/ipp_engine.h).
+
+PyTorch-ROCm is used only as the device-memory container (one uint8 arena tensor + I/O tensors whose
+``data_ptr()`` crosses the ABI) and for the current HIP stream; every computation happens in the HIP
+kernels of ``csrc/``.  There is no CPU path: constructing an engine without the library or without a
+GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _ffi
+
+
+@dataclass
+class EngineConfig:
+    """Hot-path parameters (the YAML keys of SURVEY section 5; reference config/example.yaml)."""
+
+    x_dim: int = 50
+    y_dim: int = 50
+    resolution: float = 4.0
+    angle_x: float = 60.0
+    angle_y: float = 60.0
+    rf_altitude: float = 10.0  # sensors/cameras.py:125
+    coeff_a: float = 0.05
+    coeff_b: float = 0.2
+    signal_variance: float = 1.82
+    length_scale: float = 3.67
+    max_v: float = 2.0
+    max_a: float = 2.0
+    value_threshold: float = 0.4
+    interval_factor: float = 0.0
+    cluster_radius: float = 5.0
+
+    @property
+    def n_cells(self) -> int:
+        return self.x_dim * self.y_dim
+
+    @classmethod
+    def from_params(cls, params: Dict) -> "EngineConfig":
+        env, sen, mp = params["environment"], params["sensor"], params["mapping"]
+        exp = params.get("experiment", {})
+        uav, scen = exp.get("uav", {}), exp.get("scenario", {})
+        return cls(
+            x_dim=int(env["x_dim"]), y_dim=int(env["y_dim"]), resolution=float(env["resolution"]),
+            angle_x=float(sen["field_of_view"]["angle_x"]), angle_y=float(sen["field_of_view"]["angle_y"]),
+            coeff_a=float(sen["model"]["coeff_a"]), coeff_b=float(sen["model"]["coeff_b"]),
+            signal_variance=float(mp["signal_variance"]), length_scale=float(mp["length_scale"]),
+            max_v=float(uav.get("max_v", 2.0)), max_a=float(uav.get("max_a", 2.0)),
+            value_threshold=float(scen.get("value_threshold", 0.4)),
+            interval_factor=float(scen.get("interval_factor", 0.0)),
+            cluster_radius=float(sen.get("simulation", {}).get("cluster_radius", 5.0)),
+        )
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class IPPEngine:
+    """B environment slots on one GPU; state lives in one caller-owned arena tensor."""
+
+    def __init__(self, cfg: EngineConfig, capacity: int, state: str = "factor", rank_cap: int = 360,
+                 max_batch: Optional[int] = None, device: str = "cuda:0", max_measurements: int = 9,
+                 tile_threads: int = 0):
+        torch = _torch()
+        self._lib = _ffi.load()
+        if not torch.cuda.is_available():
+            raise _ffi.IppError("IPPEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.capacity = int(capacity)
+        self.state = state
+        self.max_batch = int(max_batch or capacity)
+        c = _ffi.IppConfig()
+        c.x_dim, c.y_dim, c.resolution = cfg.x_dim, cfg.y_dim, cfg.resolution
+        # tan(0.5 * radians(angle)) in fp64 on the host, exactly as sensors/cameras.py:44-45 evaluates it
+        c.tan_half_fov_x = float(np.tan(0.5 * np.radians(cfg.angle_x)))
+        c.tan_half_fov_y = float(np.tan(0.5 * np.radians(cfg.angle_y)))
+        c.rf_altitude = cfg.rf_altitude
+        c.coeff_a, c.coeff_b = cfg.coeff_a, cfg.coeff_b
+        c.signal_variance, c.length_scale = cfg.signal_variance, cfg.length_scale
+        c.max_v, c.max_a = cfg.max_v, cfg.max_a
+        c.value_threshold, c.interval_factor = cfg.value_threshold, cfg.interval_factor
+        c.cluster_radius = cfg.cluster_radius
+        c.state_repr = _ffi.IPP_FACTOR if state == "factor" else _ffi.IPP_DENSE
+        if state not in ("factor", "dense"):
+            raise ValueError("state must be 'factor' or 'dense'")
+        c.capacity, c.rank_cap, c.max_batch = self.capacity, int(rank_cap), self.max_batch
+        c.max_measurements, c.tile_threads = int(max_measurements), int(tile_threads)
+        self._c = c
+        nbytes = C.c_uint64(0)
+        _ffi.check(self._lib.ipp_engine_arena_bytes(C.byref(c), C.byref(nbytes)))
+        self.arena = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+        base = (self.arena.data_ptr() + 255) // 256 * 256
+        handle = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _ffi.check(self._lib.ipp_engine_create(C.byref(c), dev_index, C.c_void_p(base), nbytes.value, C.byref(handle)))
+        self._h = handle
+        info = _ffi.IppInfo()
+        _ffi.check(self._lib.ipp_engine_info(self._h, C.byref(info)))
+        self.info = info
+        self.n_cells, self.n_pad, self.meas_cap = info.n_cells, info.n_pad, info.meas_cap
+        self.rank_cap = int(rank_cap)
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ipp_engine_destroy(self._h)
+            self._h = None
+            self.arena = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype, shape=None):
+        """Device tensor of `dtype` (contiguous) from a tensor / ndarray / list; None passes through."""
+        torch = _torch()
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=dtype).contiguous()
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=self.device)
+        if shape is not None:
+            t = t.reshape(shape)
+        return t
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    # ------------------------------------------------------------------ C-ABI calls
+    def reset(self, env_ids=None, prior_scale=None, gt=None, white_noise=None, n: Optional[int] = None):
+        torch = _torch()
+        ids = self._dev(env_ids, torch.int32)
+        n = int(ids.numel()) if ids is not None else int(n if n is not None else self.capacity)
+        ps = self._dev(prior_scale, torch.float64, (n, 2))
+        g = self._dev(gt, torch.float32, (n, self.n_cells))
+        w = self._dev(white_noise, torch.float32, (n, self.n_cells))
+        _ffi.check(self._lib.ipp_reset(self._h, self._ptr(ids), n, self._ptr(ps), self._ptr(g), self._ptr(w), self.stream))
+        self._keep = (ids, ps, g, w)
+
+    def step(self, actions, prev_actions, env_ids=None, dst_ids=None, meas_noise=None, *, cov_only=False,
+             predict_only=False, adaptive=True, use_flight_time=True, reward_out=None, status_out=None):
+        torch = _torch()
+        a = self._dev(actions, torch.float64).reshape(-1, 3)
+        p = self._dev(prev_actions, torch.float64).reshape(-1, 3)
+        n = a.shape[0]
+        ids = self._dev(env_ids, torch.int32)
+        dst = self._dev(dst_ids, torch.int32)
+        nz = self._dev(meas_noise, torch.float32)
+        if nz is not None:
+            nz = nz.reshape(n, -1)
+            if nz.shape[1] != self.meas_cap:
+                pad = torch.zeros((n, self.meas_cap), dtype=torch.float32, device=self.device)
+                pad[:, : min(nz.shape[1], self.meas_cap)] = nz[:, : self.meas_cap]
+                nz = pad
+        reward = reward_out if reward_out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        status = status_out if status_out is not None else torch.empty(n, dtype=torch.int32, device=self.device)
+        flags = (_ffi.IPP_COV_ONLY if cov_only else 0) | (_ffi.IPP_PREDICT_ONLY if predict_only else 0) | \
+                (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0)
+        _ffi.check(self._lib.ipp_step(self._h, self._ptr(ids), self._ptr(dst), n, self._ptr(a), self._ptr(p), self._ptr(nz),
+                                      flags, self._ptr(reward), self._ptr(status), self.stream))
+        self._keep = (a, p, ids, dst, nz)
+        return reward, status
+
+    def step_raw(self, n, actions, prev_actions, meas_noise, flags, reward, status, env_ids=None):
+        """Zero-overhead variant for the benchmark loop: all arguments are preallocated device tensors."""
+        _ffi.check(self._lib.ipp_step(self._h, self._ptr(env_ids), C.c_void_p(0), n, self._ptr(actions), self._ptr(prev_actions),
+                                      self._ptr(meas_noise), flags, self._ptr(reward), self._ptr(status), self.stream))
+
+    def set_adaptive(self, value_threshold: float, interval_factor: float):
+        _ffi.check(self._lib.ipp_set_adaptive(self._h, float(value_threshold), float(interval_factor)))
+
+    def fork(self, src_ids, dst_ids):
+        torch = _torch()
+        s, d = self._dev(src_ids, torch.int32), self._dev(dst_ids, torch.int32)
+        _ffi.check(self._lib.ipp_fork(self._h, self._ptr(s), self._ptr(d), int(s.numel()), self.stream))
+        self._keep = (s, d)
+
+    def _read(self, fn, env, numel):
+        torch = _torch()
+        out = torch.empty(numel, dtype=torch.float32, device=self.device)
+        _ffi.check(fn(self._h, int(env), self._ptr(out), self.stream))
+        return out
+
+    def read_mean(self, env):
+        return self._read(self._lib.ipp_read_mean, env, self.n_cells).reshape(self.cfg.y_dim, self.cfg.x_dim)
+
+    def read_diag(self, env):
+        return self._read(self._lib.ipp_read_diag, env, self.n_cells)
+
+    def read_gt(self, env):
+        return self._read(self._lib.ipp_read_gt, env, self.n_cells).reshape(self.cfg.y_dim, self.cfg.x_dim)
+
+    def read_cov(self, env):
+        n = self.n_cells
+        return self._read(self._lib.ipp_read_cov_dense, env, n * n).reshape(n, n)
+
+    def rank(self, env) -> int:
+        r = C.c_int32(0)
+        _ffi.check(self._lib.ipp_read_rank(self._h, int(env), C.byref(r), self.stream))
+        return int(r.value)
+
+    def write_mean(self, env, mean):
+        t = self._dev(mean, _torch().float32, (self.n_cells,))
+        _ffi.check(self._lib.ipp_write_mean(self._h, int(env), self._ptr(t), self.stream))
+        self._keep = t
+
+    def write_gt(self, env, gt):
+        t = self._dev(gt, _torch().float32, (self.n_cells,))
+        _ffi.check(self._lib.ipp_write_gt(self._h, int(env), self._ptr(t), self.stream))
+        self._keep = t
+
+    def write_cov(self, env, P):
+        t = self._dev(P, _torch().float32, (self.n_cells, self.n_cells))
+        _ffi.check(self._lib.ipp_write_cov_dense(self._h, int(env), self._ptr(t), self.stream))
+        self._keep = t
+
+    def metrics(self, env_ids=None, n: Optional[int] = None):
+        torch = _torch()
+        ids = self._dev(env_ids, torch.int32)
+        n = int(ids.numel()) if ids is not None else int(n if n is not None else self.capacity)
+        out = torch.empty((n, 8), dtype=torch.float32, device=self.device)
+        _ffi.check(self._lib.ipp_metrics(self._h, self._ptr(ids), n, self._ptr(out), self.stream))
+        self._keep = ids
+        return out
+
+    def normal(self, count: int, seed: int, subsequence: int = 0, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty(int(count), dtype=torch.float32, device=self.device)
+        _ffi.check(self._lib.ipp_fill_normal(self._h, self._ptr(out), int(count), int(seed), int(subsequence), self.stream))
+        return out
+
+    def debug_item(self, idx: int) -> Dict:
+        it = _ffi.IppStepItem()
+        _ffi.check(self._lib.ipp_debug_step_item(self._h, int(idx), C.byref(it), self.stream))
+        m = it.m
+        return dict(
+            env=it.env, dst=it.dst, rank_before=it.rank_before, status=it.status,
+            fov=(it.xl, it.xr, it.yu, it.yd), rf=it.rf, m=m, f=it.f, cost=it.cost, noise_var=it.noise_var,
+            S=np.array(it.S[: m * m]).reshape(m, m), Linv=np.array(it.Linv[: m * m]).reshape(m, m),
+            z=np.array(it.z[:m]), y=np.array(it.y[:m]),
+        )
+
+    def profile(self, enable: bool):
+        _ffi.check(self._lib.ipp_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, kind: int, reset: bool = True):
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        _ffi.check(self._lib.ipp_profile_read(self._h, int(kind), C.byref(ms), C.byref(cnt), 1 if reset else 0))
+        return float(ms.value), int(cnt.value)
+
+    # ------------------------------------------------------------------ byte accounting
+    def algorithmic_bytes_per_step(self, rank_before: float, m: float) -> float:
+        """fp32 bytes one committed step must move: factor 4N(r+m)+16N, dense 8N^2+16N."""
+        n = self.n_cells
+        if self.state == "factor":
+            return 4.0 * n * (rank_before + m) + 16.0 * n
+        return 8.0 * n * n + 16.0 * n
