@@ -175,6 +175,7 @@ int ipp_read_diag(void* engine, int32_t env_id, float* out /*[N]*/, void* stream
 int ipp_read_gt(void* engine, int32_t env_id, float* out /*[N]*/, void* stream);
 int ipp_read_cov_dense(void* engine, int32_t env_id, float* out /*[N][N]*/, void* stream);
 int ipp_read_rank(void* engine, int32_t env_id, int32_t* rank /*[host] out*/, void* stream); /* synchronises */
+int ipp_read_ranks(void* engine, int32_t* out /*[dev] int32[capacity]*/, void* stream);      /* all slots, async */
 
 /* Inject state (reference callers assign grid_map.mean / grid_map.cov_matrix directly:
  * planning/mcts_mission.py:395,413; adaptive_info["mean"], planning/common/optimization.py:22-25).

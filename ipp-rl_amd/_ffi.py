@@ -72,6 +72,7 @@ PROTOTYPES = {
     "ipp_read_gt": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_read_cov_dense": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_read_rank": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P]),
+    "ipp_read_ranks": (C.c_int, [_P, _P, _P]),
     "ipp_write_mean": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_write_gt": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_write_cov_dense": (C.c_int, [_P, C.c_int32, _P, _P]),

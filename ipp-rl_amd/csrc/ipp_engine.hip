@@ -472,6 +472,14 @@ int ipp_read_rank(void* engine, int32_t env_id, int32_t* rank, void* stream) {
     return 0;
 }
 
+int ipp_read_ranks(void* engine, int32_t* out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(out, e->v.rank, (size_t)e->v.cap * 4, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 static int write_row(Engine* e, float* slab, int env, const float* in, void* stream) {
     if (!e || !in) return fail(-1, "null argument");
     if (int rc = check_env(e, env)) return rc;

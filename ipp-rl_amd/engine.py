@@ -218,6 +218,14 @@ class IPPEngine:
         _ffi.check(self._lib.ipp_read_rank(self._h, int(env), C.byref(r), self.stream))
         return int(r.value)
 
+    def ranks(self, out=None):
+        """Current factor rank of every slot as a device int32 tensor (no host sync)."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+        _ffi.check(self._lib.ipp_read_ranks(self._h, self._ptr(out), self.stream))
+        return out
+
     def write_mean(self, env, mean):
         t = self._dev(mean, _torch().float32, (self.n_cells,))
         _ffi.check(self._lib.ipp_write_mean(self._h, int(env), self._ptr(t), self.stream))

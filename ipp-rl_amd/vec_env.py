@@ -1,0 +1,172 @@
+"""
+VecIPPEnv -- batched driver over the HIP step engine: B independent IPP environments in opaque env
+slots on one GPU.
+
+One env step = the reference's self-play step sequence fused (planning/mcts_zero/episode_generators.py:
+137-146): simulate_prediction_step (reward) + sensor.take_measurement + mapping.update_grid_map.
+Episodes are ``episode_steps`` long (max_episode_steps, config/example.yaml:64); an episode reset draws a
+new Gaussian-random-field ground truth and (optionally) shuffled prior hyper-parameters
+(shuffle_prior_cov, mapping/mappings.py:238-240) and returns the UAV to Mission.init_action
+(planning/missions.py:69).
+
+Randomness: parity runs pass NumPy legacy-stream normals in (``white_noise`` / ``meas_noise`` arguments);
+throughput runs let the engine's Philox generator fill them on the device (stated in reports).
+Seeds are derived from the GLOBAL env id, so results do not depend on how envs are sharded over GPUs.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .engine import EngineConfig, IPPEngine
+
+INIT_ACTION = (2.0, 2.0, 14.0)  # planning/missions.py:69
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous env-id range of `rank`: [rank*total/world, (rank+1)*total/world)."""
+    lo = (total * rank) // world
+    hi = (total * (rank + 1)) // world
+    return lo, hi
+
+
+def cell_centre_actions(cfg: EngineConfig, step: int, env_lo: int, env_hi: int, total_envs: int,
+                        altitudes: Sequence[float]) -> np.ndarray:
+    """
+    Synthetic workload of SURVEY 8(d): uniform over the N * len(altitudes) cell-centre actions, drawn from
+    RandomState(10_000 + step) for ALL `total_envs` envs and sliced, so a shard sees the same actions
+    whatever the GPU count.
+    """
+    rs = np.random.RandomState(10_000 + step)
+    col = rs.randint(0, cfg.x_dim, total_envs)
+    row = rs.randint(0, cfg.y_dim, total_envs)
+    lev = rs.randint(0, len(altitudes), total_envs)
+    alts = np.asarray(altitudes, dtype=np.float64)
+    acts = np.stack([cfg.resolution * col + 0.5 * cfg.resolution, cfg.resolution * row + 0.5 * cfg.resolution,
+                     alts[lev]], axis=1)
+    return acts[env_lo:env_hi]
+
+
+class VecIPPEnv:
+    def __init__(self, cfg: EngineConfig, num_envs: int, state: str = "factor", episode_steps: int = 40,
+                 device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
+                 rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
+                 adaptive: bool = True, use_flight_time: bool = True):
+        import torch
+
+        self.torch = torch
+        self.cfg = cfg
+        self.num_envs = int(num_envs)
+        self.episode_steps = int(episode_steps)
+        self.seed = int(seed)
+        self.env_id_offset = int(env_id_offset)
+        self.shuffle_prior_cov = shuffle_prior_cov
+        self.adaptive, self.use_flight_time = adaptive, use_flight_time
+        rank_cap = int(rank_cap) if rank_cap else 9 * self.episode_steps
+        self.engine = IPPEngine(cfg, capacity=self.num_envs, state=state, rank_cap=rank_cap, device=device,
+                                tile_threads=tile_threads)
+        dev = self.engine.device
+        self.device = dev
+        B = self.num_envs
+        self.prev = torch.tensor(INIT_ACTION, dtype=torch.float64, device=dev).repeat(B, 1)
+        self.init_prev = self.prev.clone()
+        # stagger: env e starts its first episode at phase e % T so that every batched step sees the
+        # stationary mix of ranks 0 .. (T-1)*m (throughput runs); otherwise all envs run in lock step
+        self.phase = (torch.arange(B, device=dev) + self.env_id_offset) % self.episode_steps if stagger else \
+            torch.zeros(B, dtype=torch.int64, device=dev)
+        self.t = 0
+        self.episode = torch.zeros(B, dtype=torch.int64, device=dev)
+        self._reset_ids_by_phase = None
+        if stagger:
+            self._reset_ids_by_phase = [
+                torch.nonzero(self.phase == p).flatten().to(torch.int32) for p in range(self.episode_steps)
+            ]
+        self._white = torch.empty((B, cfg.n_cells), dtype=torch.float32, device=dev)
+        self._noise = torch.empty((B, self.engine.meas_cap), dtype=torch.float32, device=dev)
+        self.reward = torch.empty(B, dtype=torch.float32, device=dev)
+        self.status = torch.empty(B, dtype=torch.int32, device=dev)
+        self._flags = (4 if adaptive else 0) | (8 if use_flight_time else 0)
+
+    # ------------------------------------------------------------------ resets
+    def _prior_scale(self, ids_host: np.ndarray, episode_index: int):
+        if not self.shuffle_prior_cov:
+            return None
+        out = np.empty((len(ids_host), 2))
+        for k, e in enumerate(ids_host):
+            rs = np.random.RandomState((self.seed * 1_000_003 + int(e) + self.env_id_offset) % (2 ** 31) + episode_index)
+            out[k, 0] = rs.uniform(0.8 * self.cfg.signal_variance, 1.2 * self.cfg.signal_variance)
+            out[k, 1] = rs.uniform(0.8 * self.cfg.length_scale, 1.2 * self.cfg.length_scale)
+        return out
+
+    def reset(self, env_ids=None, white_noise=None, gt=None, prior_scale=None):
+        """Reset the given slots (all when None).  white_noise / gt: [n, H, W] NumPy or tensor (parity)."""
+        torch = self.torch
+        if env_ids is None:
+            ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+        else:
+            ids = torch.as_tensor(env_ids, dtype=torch.int32, device=self.device)
+        n = int(ids.numel())
+        if n == 0:
+            return
+        if gt is None and white_noise is None:
+            # device Philox stream: subsequence = (shard offset, reset-call counter)
+            white = self._white[:n]
+            self.engine.normal(n * self.cfg.n_cells, self.seed, self._subseq_for_reset(), out=white)
+            white_noise = white
+        if prior_scale is None and self.shuffle_prior_cov:
+            prior_scale = self._prior_scale(ids.cpu().numpy(), self.t)
+        self.engine.reset(env_ids=ids, prior_scale=prior_scale, gt=gt, white_noise=white_noise)
+        idl = ids.long()
+        self.prev[idl] = self.init_prev[idl]
+        self.episode[idl] += 1
+
+    def _subseq_for_reset(self) -> int:
+        self._reset_calls = getattr(self, "_reset_calls", 0) + 1
+        return (self.env_id_offset << 24) + self._reset_calls
+
+    # ------------------------------------------------------------------ stepping
+    def step(self, actions, meas_noise=None, env_ids=None, auto_reset: bool = True):
+        """
+        actions: [B, 3] float64 (NumPy or device tensor).  Returns (reward, status) device tensors.
+        With stagger=True and auto_reset, the envs whose episode ends after this step are reset on a fixed
+        schedule known to the host (no device->host sync in the loop).
+        """
+        torch = self.torch
+        a = self.engine._dev(actions, torch.float64).reshape(-1, 3)
+        if meas_noise is None:
+            nz = self._noise
+            self._step_calls = getattr(self, "_step_calls", 0) + 1
+            self.engine.normal(nz.numel(), self.seed ^ 0x5DEECE66D, (self.env_id_offset << 24) + self._step_calls, out=nz)
+        else:
+            nz = meas_noise
+        self.engine.step(a, self.prev, env_ids=env_ids, meas_noise=nz, adaptive=self.adaptive,
+                         use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status)
+        if env_ids is None:
+            self.prev.copy_(a)
+        else:
+            self.prev[torch.as_tensor(env_ids, device=self.device).long()] = a
+        self.t += 1
+        if auto_reset and self._reset_ids_by_phase is not None:
+            # env e has completed (t + phase_e) steps of its current episode modulo T
+            p = (self.episode_steps - (self.t % self.episode_steps)) % self.episode_steps
+            ids = self._reset_ids_by_phase[p]
+            if ids.numel():
+                self.reset(ids)
+        return self.reward, self.status
+
+    # ------------------------------------------------------------------ views
+    def mean(self, env):
+        return self.engine.read_mean(env)
+
+    def diag(self, env):
+        return self.engine.read_diag(env)
+
+    def ground_truth(self, env):
+        return self.engine.read_gt(env)
+
+    def covariance(self, env):
+        return self.engine.read_cov(env)
+
+    def metrics(self, env_ids=None):
+        return self.engine.metrics(env_ids=env_ids)
