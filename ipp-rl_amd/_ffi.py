@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libipp_hip.so")
+LIB_PATH = os.environ.get("IPP_HIP_LIB") or os.path.join(_HERE, "lib", "libipp_hip.so")  # override: A/B builds only
 
 IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME = 1, 2, 4, 8

@@ -55,6 +55,7 @@ struct Engine {
     size_t prep_lds;
     size_t gain_lds;
     int q_chunk;
+    int lut_cap;
     bool profile = false;
     ProfSlot prof[3];
     int last_n = 0;
@@ -85,13 +86,15 @@ int plan(const ipp_config& c, Layout& L) {
         if (c.tile_threads % 64 != 0 || c.tile_threads > kMaxTileThreads) return fail(-1, "tile_threads must be a multiple of 64 and <= %d", kMaxTileThreads);
         L.T = c.tile_threads;
     } else {
-        // least padding first; then the largest workgroup <= 320 threads (5 waves: several workgroups
-        // stay resident per CU so one's prologue / epilogue overlaps another's streaming loop)
+        // least padding first; among equals 128 threads (2 waves) measured best on MI355X (many small
+        // workgroups per CU hide each other's prologue / epilogue), else the largest <= 320
         int best_t = 64;
         long best_pad = -1;
         for (int t = 64; t <= 320; t += 64) {
             const long tiles = (n4 + t - 1) / t, padded = tiles * t;
-            if (best_pad < 0 || padded < best_pad || (padded == best_pad && t > best_t)) { best_pad = padded; best_t = t; }
+            const bool better = best_pad < 0 || padded < best_pad ||
+                                (padded == best_pad && (t == 128 || (best_t != 128 && t > best_t)));
+            if (better) { best_pad = padded; best_t = t; }
         }
         L.T = best_t;
     }
@@ -206,9 +209,9 @@ void prof_drain(ProfSlot& p) {
     p.pending.clear();
 }
 
-size_t gain_lds_bytes(const View& v, int q_chunk) {
+size_t gain_lds_bytes(const View& v, int q_chunk, int lut_cap) {
     const size_t MC = v.meas_cap, QS = v.q_stride;
-    size_t b = (size_t)(q_chunk + 2 * kPipe) * QS * 4 + ((MC * MC + 3) & ~(size_t)3) * 4 + ((MC + 3) & ~(size_t)3) * 4 + 16 * 8;
+    size_t b = std::max((size_t)(q_chunk + 2 * kPipe) * QS, (size_t)((lut_cap + 3) & ~3)) * 4 + ((MC * MC + 3) & ~(size_t)3) * 4 + ((MC + 3) & ~(size_t)3) * 4 + 16 * 8;
     if (v.mode == IPP_DENSE) b += (size_t)q_chunk * 4;
     return (b + 15) & ~(size_t)15;
 }
@@ -230,9 +233,9 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
         ProfScope ps(e, 0, s);
         const int grid = grid_for(n, v.n_tiles);
         if (v.mode == IPP_FACTOR)
-            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, reward);
+            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
         else
-            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_DENSE>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, reward);
+            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_DENSE>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
     }
     if (v.n_tiles > 1) hipLaunchKernelGGL(k_reward_finalize, dim3((n + 255) / 256), dim3(256), 0, s, v, n, reward);
     if (v.mode == IPP_DENSE && !(flags & IPP_PREDICT_ONLY)) {
@@ -305,7 +308,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->n_bands = (L.N + kBandRows - 1) / kBandRows;
     e->prep_lds = prep_lds_bytes(L, *cfg);
     e->q_chunk = std::min(1024, (L.q_rows + 2 * kPipe - 1) / (2 * kPipe) * (2 * kPipe));
-    e->gain_lds = gain_lds_bytes(v, e->q_chunk);
+    // prior table of the factor base term lives in LDS when the grid is small enough (<= 48 KiB)
+    e->lut_cap = (v.mode == IPP_FACTOR && L.N <= 12288) ? L.N : 0;
+    e->gain_lds = gain_lds_bytes(v, e->q_chunk, e->lut_cap);
     if (e->prep_lds > 160 * 1024) {
         delete e;
         return fail(-1, "prologue needs %zu B of LDS (> 160 KiB): lower rank_cap or max_measurements", e->prep_lds);
@@ -371,7 +376,13 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
     hipLaunchKernelGGL(k_reset_small, dim3((v.Npad + 255) / 256, n), dim3(256), 0, s, v, env_ids, n, prior_scale, gt);
     if (!gt && white_noise) {
         if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
-        hipLaunchKernelGGL(k_grf_conv, dim3((v.N + 255) / 256, n), dim3(256), 0, s, v, n, white_noise);
+        if (v.W <= 64) {
+            const int tpr = (v.W + 4) / 5;
+            hipLaunchKernelGGL((k_grf_conv<5>), dim3((v.H * tpr + 255) / 256, n), dim3(256), 0, s, v, n, white_noise, tpr);
+        } else {
+            const int tpr = (v.W + 7) / 8;
+            hipLaunchKernelGGL((k_grf_conv<8>), dim3((v.H * tpr + 255) / 256, n), dim3(256), 0, s, v, n, white_noise, tpr);
+        }
         hipLaunchKernelGGL(k_grf_norm, dim3(n), dim3(256), 0, s, v, env_ids, n);
     }
     if (v.mode == IPP_DENSE) {

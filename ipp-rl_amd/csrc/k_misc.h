@@ -55,25 +55,54 @@ __global__ __launch_bounds__(256) void k_reset_dense(View v, const int* __restri
 
 // GRF as a circular convolution: field = white (*) h, h = Re ifft2(amp) (simulations/ground_truths.py:14-31;
 // amp is real and even so Re ifft2(fft2(white) * amp) is exactly this convolution).  fp64 accumulate.
-__global__ __launch_bounds__(256) void k_grf_conv(View v, int n_items, const float* __restrict__ white) {
+// Register-tiled: a thread owns OT consecutive outputs of one row and keeps the OT kernel taps they share
+// in a rotating register window, so each step costs one 8-byte tap load (L1-resident, 20 KB table at 50x50)
+// and one broadcast white value for OT fp64 FMAs.
+template <int OT>
+__global__ __launch_bounds__(256) void k_grf_conv(View v, int n_items, const float* __restrict__ white, int tpr) {
     const int item = blockIdx.y;
-    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= n_items || cell >= v.N) return;
-    const int y = cell / v.W, x = cell - y * v.W;
-    const float* wn = white + (size_t)item * v.N;
-    double acc = 0.0;
-    for (int yp = 0; yp < v.H; ++yp) {
+    const int tix = blockIdx.x * blockDim.x + threadIdx.x;  // (row, x-group)
+    if (item >= n_items) return;
+    const int W = v.W, H = v.H;
+    const bool active = tix < H * tpr;
+    const int y = active ? tix / tpr : 0;
+    const int x0 = active ? (tix - y * tpr) * OT : 0;
+    const float* __restrict__ wn = white + (size_t)item * v.N;
+    const double* __restrict__ hk = v.grf_h;
+    double acc[OT], win[OT];
+#pragma unroll
+    for (int j = 0; j < OT; ++j) acc[j] = 0.0;
+    const int wsteps = (W + OT - 1) / OT * OT;
+    for (int yp = 0; yp < H; ++yp) {
         int hy = y - yp;
-        if (hy < 0) hy += v.H;
-        const double* hrow = v.grf_h + (size_t)hy * v.W;
-        const float* wrow = wn + (size_t)yp * v.W;
-        for (int xp = 0; xp < v.W; ++xp) {
-            int hx = x - xp;
-            if (hx < 0) hx += v.W;
-            acc = fma((double)wrow[xp], hrow[hx], acc);
+        if (hy < 0) hy += H;
+        const double* __restrict__ hrow = hk + (size_t)hy * W;
+        const float* __restrict__ wrow = wn + (size_t)yp * W;
+        // window holds h[(x0 + j - xp) mod W] at win[(j - xp) mod OT]; preload j = 1..OT-1 for xp = 0
+#pragma unroll
+        for (int j = 1; j < OT; ++j) {
+            int idx = x0 + j;
+            idx -= (idx >= W) ? W : 0;
+            idx -= (idx >= W) ? W : 0;
+            win[j] = hrow[idx];
+        }
+        int hi = x0 - ((x0 >= W) ? W : 0);  // (x0 - xp) mod W, decremented each step
+        for (int xb = 0; xb < wsteps; xb += OT) {
+#pragma unroll
+            for (int u = 0; u < OT; ++u) {
+                const int xp = xb + u;
+                win[(OT - u) % OT] = hrow[hi];       // new tap h[(x0 - xp) mod W] replaces the one that left
+                hi = (hi == 0) ? W - 1 : hi - 1;
+                const double wv = (xp < W) ? (double)wrow[xp] : 0.0;
+#pragma unroll
+                for (int j = 0; j < OT; ++j) acc[j] = fma(wv, win[(j + OT - u) % OT], acc[j]);
+            }
         }
     }
-    v.grf_raw[(size_t)item * v.Npad + cell] = (float)acc;
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < OT; ++j)
+        if (x0 + j < W) v.grf_raw[(size_t)item * v.Npad + y * W + x0 + j] = (float)acc[j];
 }
 
 // min-max normalisation to [0, 1] (simulations/ground_truths.py:31).
