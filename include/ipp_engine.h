@@ -38,6 +38,8 @@ extern "C" {
 #define IPP_PREDICT_ONLY    2u /* reward only, nothing is written  (mappings.py:114 predict_only=True)    */
 #define IPP_ADAPTIVE        4u /* masked reward                    (planning/common/rewards.py:8-12)      */
 #define IPP_USE_FLIGHT_TIME 8u /* cost = flight time, else distance (planning/common/actions.py:8-12)     */
+#define IPP_GIVEN_OBSERVATION 16u /* meas_noise holds the observation z itself (update_grid_map(pos, z),  */
+                                  /* mapping/mappings.py:114-121): no crop / noise / clip is applied       */
 
 /* per-item status written by ipp_step */
 #define IPP_STATUS_OK            0
@@ -158,6 +160,19 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
 int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
              const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
              void* stream);
+
+/*
+ * Observation only: z = clip(area_downsample(gt[F]) + noise_var * eps, 0, 1) for `n` items, no state access
+ * beyond the ground truth.  Replaces Sensor.take_measurement -> ScalarFieldSimulation.take_measurement
+ * (sensors/cameras.py:108-116, simulations/simulations.py:26-34, simulations/sensor_manipulations.py:7-57).
+ *   z_out [dev] float[n][max_measurements] (C order of the downsampled observation), m_out [dev] int32[n],
+ *   shape_out [dev] int32[n][2] = (rows, cols) of the observation as the reference returns it (may be NULL)
+ */
+int ipp_observe(void* engine, const int32_t* env_ids, int32_t n, const double* action, const float* meas_noise,
+                float* z_out, int32_t* m_out, int32_t* shape_out, void* stream);
+
+/* UAV limits of the flight-time cost (uav_specifications argument, planning/common/actions.py:8-41). */
+int ipp_set_uav(void* engine, double max_v, double max_a);
 
 /* Change the adaptive-mask parameters used by subsequent steps.  The reference passes them per call in
  * adaptive_info = {"mean", "value_threshold", "interval_factor"} (planning/common/optimization.py:22-25). */

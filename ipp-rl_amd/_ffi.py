@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPP_HIP_LIB") or os.path.join(_HERE, "lib", "libipp_hip.so")  # override: A/B builds only
 
 IPP_DENSE, IPP_FACTOR = 0, 1
-IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME = 1, 2, 4, 8
+IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION = 1, 2, 4, 8, 16
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
 ABI_VERSION = 1
@@ -65,6 +65,8 @@ PROTOTYPES = {
     "ipp_engine_info": (C.c_int, [_P, C.POINTER(IppInfo)]),
     "ipp_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
+    "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "ipp_set_uav": (C.c_int, [_P, C.c_double, C.c_double]),
     "ipp_set_adaptive": (C.c_int, [_P, C.c_double, C.c_double]),
     "ipp_fork": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ipp_read_mean": (C.c_int, [_P, C.c_int32, _P, _P]),

@@ -1,0 +1,57 @@
+"""
+Single-environment compatibility runtime: the drop-in Mapping / Sensor / Simulation classes keep the
+reference's NumPy-in / NumPy-out surface (fp64 arrays the planners index, hash and assign), and route every
+map operation through a small dense-state HIP engine (2 slots) looked up here.  Nothing in this module
+computes on the CPU; without the HIP library or a GPU the first call raises.
+
+Engines are cached per configuration and are never part of an object's pickled state (the reference pickles
+Mapping objects into multiprocessing workers and experiment.pkl: SURVEY 8(b)); a forked / spawned worker opens
+its own engine lazily.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .engine import EngineConfig, IPPEngine
+
+_ENGINES: Dict[Tuple, IPPEngine] = {}
+_PID = os.getpid()
+
+
+def config_key(cfg: EngineConfig) -> Tuple:
+    return (cfg.x_dim, cfg.y_dim, cfg.resolution, cfg.angle_x, cfg.angle_y, cfg.rf_altitude, cfg.coeff_a, cfg.coeff_b,
+            cfg.signal_variance, cfg.length_scale, cfg.cluster_radius)
+
+
+def compat_engine(cfg: EngineConfig) -> IPPEngine:
+    """Dense-state engine with 2 slots for `cfg` (slot 0: working map, slot 1: scratch)."""
+    global _PID
+    if os.getpid() != _PID:  # forked worker: HIP handles do not survive a fork
+        _ENGINES.clear()
+        _PID = os.getpid()
+    key = config_key(cfg)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        m_cap = 9 if cfg.resolution >= 2 else 25
+        eng = IPPEngine(cfg, capacity=2, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap)
+        _ENGINES[key] = eng
+    return eng
+
+
+def engine_config_from(grid_map, sensor, signal_variance: float, length_scale: float) -> EngineConfig:
+    sim = getattr(sensor, "sensor_simulation", None)
+    cluster = getattr(sim, "cluster_radius", None)
+    return EngineConfig(
+        x_dim=int(grid_map.x_dim), y_dim=int(grid_map.y_dim), resolution=float(grid_map.resolution),
+        angle_x=float(sensor.angle_x), angle_y=float(sensor.angle_y),
+        coeff_a=float(sensor.sensor_model.coeff_a), coeff_b=float(sensor.sensor_model.coeff_b),
+        signal_variance=float(signal_variance), length_scale=float(length_scale),
+        cluster_radius=float(cluster) if cluster is not None else 5.0,
+    )
+
+
+def to_host64(t) -> np.ndarray:
+    return t.detach().cpu().numpy().astype(np.float64)

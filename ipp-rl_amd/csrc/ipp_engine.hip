@@ -224,10 +224,10 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
         ProfScope ps(e, 2, s);
         if (v.mode == IPP_FACTOR)
             hipLaunchKernelGGL((k_prepare<MC, IPP_FACTOR>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
-                               action, prev, noise, flags, status);
+                               action, prev, noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
         else
             hipLaunchKernelGGL((k_prepare<MC, IPP_DENSE>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
-                               action, prev, noise, flags, status);
+                               action, prev, noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
     }
     {
         ProfScope ps(e, 0, s);
@@ -403,7 +403,7 @@ int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32
     if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
     if (n == 0) return 0;
     if (!env_ids && n > e->v.cap) return fail(-1, "n exceeds capacity");
-    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME)) return fail(-1, "unknown flag bits 0x%x", flags);
+    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_GIVEN_OBSERVATION)) return fail(-1, "unknown flag bits 0x%x", flags);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
     e->last_n = n;
@@ -418,6 +418,40 @@ int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32
     if (e->v.meas_cap == 9)
         return launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
     return launch_step<25, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
+}
+
+int ipp_observe(void* engine, const int32_t* env_ids, int32_t n, const double* action, const float* meas_noise,
+                float* z_out, int32_t* m_out, int32_t* shape_out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !action || !z_out || !m_out) return fail(-1, "null argument");
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const View& v = e->v;
+    // the prologue kernel in observation-only mode (prev_action is unused there: pass action)
+    if (v.meas_cap == 9) {
+        if (v.mode == IPP_FACTOR)
+            hipLaunchKernelGGL((k_prepare<9, IPP_FACTOR>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, (const int*)nullptr, n, action, action, meas_noise, 0u, (int*)nullptr, z_out, m_out, shape_out);
+        else
+            hipLaunchKernelGGL((k_prepare<9, IPP_DENSE>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, (const int*)nullptr, n, action, action, meas_noise, 0u, (int*)nullptr, z_out, m_out, shape_out);
+    } else {
+        if (v.mode == IPP_FACTOR)
+            hipLaunchKernelGGL((k_prepare<25, IPP_FACTOR>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, (const int*)nullptr, n, action, action, meas_noise, 0u, (int*)nullptr, z_out, m_out, shape_out);
+        else
+            hipLaunchKernelGGL((k_prepare<25, IPP_DENSE>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, (const int*)nullptr, n, action, action, meas_noise, 0u, (int*)nullptr, z_out, m_out, shape_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_set_uav(void* engine, double max_v, double max_a) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (!(max_v > 0) || !(max_a > 0)) return fail(-1, "max_v and max_a must be positive");
+    e->v.vmax = max_v;
+    e->v.amax = max_a;
+    return 0;
 }
 
 int ipp_set_adaptive(void* engine, double value_threshold, double interval_factor) {

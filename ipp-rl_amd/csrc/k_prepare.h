@@ -34,7 +34,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
                                                           const double* __restrict__ action,
                                                           const double* __restrict__ prev_action,
                                                           const float* __restrict__ meas_noise, unsigned flags,
-                                                          int* __restrict__ status_out) {
+                                                          int* __restrict__ status_out, float* __restrict__ obs_out,
+                                                          int* __restrict__ obs_m, int* __restrict__ obs_shape) {
     constexpr int FC = 4 * MC;
     constexpr int LD = MC + 1;  // padded leading dimension of the small fp64 matrices
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
         if (tid == 0) {
             v.hdr[item] = h;
             if (status_out) status_out[item] = h.status;
+            if (obs_m) obs_m[item] = 0;
         }
         for (int i = tid; i < MC * MC; i += kPrepThreads) linv_out[i] = 0.f;
         for (int i = tid; i < MC; i += kPrepThreads) y_out[i] = 0.f;
@@ -172,7 +174,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
                 (void)orows;
             }
             const double eps = meas_noise ? (double)meas_noise[(size_t)item * MC + tid] : 0.0;
-            val = fmin(fmax(val + h.nv_d * eps, 0.0), 1.0);  // sensor_manipulations.py:56-57 (variance used as std)
+            if (flags & IPP_GIVEN_OBSERVATION)
+                val = eps;  // caller supplies z (update_grid_map(pos, z), mappings.py:114-121)
+            else
+                val = fmin(fmax(val + h.nv_d * eps, 0.0), 1.0);  // sensor_manipulations.py:56-57 (variance used as std)
             zz[tid] = val;
             const Block b = block_of(tid, h.nx, h.rf, h.w, h.h);
             double hx = 0.0;
@@ -185,6 +190,21 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
     } else if (tid < MC) {
         zz[tid] = 0.0;
         vv[tid] = 0.0;
+    }
+
+    if (obs_out) {  // ipp_observe: observation only
+        __syncthreads();
+        if (tid < MC) obs_out[(size_t)item * MC + tid] = (tid < m) ? (float)zz[tid] : 0.f;
+        if (tid == 0) {
+            obs_m[item] = m;
+            if (obs_shape) {
+                // reference shapes: rf=1 -> (h, w); rf=2 -> cv2 dsize transposition -> (ceil(w/rf), ceil(h/rf))
+                obs_shape[2 * item + 0] = (h.rf == 1) ? h.h : (h.w + h.rf - 1) / h.rf;
+                obs_shape[2 * item + 1] = (h.rf == 1) ? h.w : (h.h + h.rf - 1) / h.rf;
+            }
+            if (status_out) status_out[item] = h.status;
+        }
+        return;
     }
 
     // ------------------------------------------------------------------ gather the state rows of the footprint

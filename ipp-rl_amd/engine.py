@@ -157,7 +157,8 @@ class IPPEngine:
         self._keep = (ids, ps, g, w)
 
     def step(self, actions, prev_actions, env_ids=None, dst_ids=None, meas_noise=None, *, cov_only=False,
-             predict_only=False, adaptive=True, use_flight_time=True, reward_out=None, status_out=None):
+             predict_only=False, adaptive=True, use_flight_time=True, given_observation=False, reward_out=None,
+             status_out=None):
         torch = _torch()
         a = self._dev(actions, torch.float64).reshape(-1, 3)
         p = self._dev(prev_actions, torch.float64).reshape(-1, 3)
@@ -174,7 +175,8 @@ class IPPEngine:
         reward = reward_out if reward_out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
         status = status_out if status_out is not None else torch.empty(n, dtype=torch.int32, device=self.device)
         flags = (_ffi.IPP_COV_ONLY if cov_only else 0) | (_ffi.IPP_PREDICT_ONLY if predict_only else 0) | \
-                (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0)
+                (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0) | \
+                (_ffi.IPP_GIVEN_OBSERVATION if given_observation else 0)
         _ffi.check(self._lib.ipp_step(self._h, self._ptr(ids), self._ptr(dst), n, self._ptr(a), self._ptr(p), self._ptr(nz),
                                       flags, self._ptr(reward), self._ptr(status), self.stream))
         self._keep = (a, p, ids, dst, nz)
@@ -184,6 +186,30 @@ class IPPEngine:
         """Zero-overhead variant for the benchmark loop: all arguments are preallocated device tensors."""
         _ffi.check(self._lib.ipp_step(self._h, self._ptr(env_ids), C.c_void_p(0), n, self._ptr(actions), self._ptr(prev_actions),
                                       self._ptr(meas_noise), flags, self._ptr(reward), self._ptr(status), self.stream))
+
+    def observe(self, actions, env_ids=None, meas_noise=None):
+        """Observation only (Sensor.take_measurement): returns (z [n, meas_cap], m [n], shape [n, 2]) device tensors."""
+        torch = _torch()
+        a = self._dev(actions, torch.float64).reshape(-1, 3)
+        n = a.shape[0]
+        ids = self._dev(env_ids, torch.int32)
+        nz = self._dev(meas_noise, torch.float32)
+        if nz is not None:
+            nz = nz.reshape(n, -1)
+            if nz.shape[1] != self.meas_cap:
+                pad = torch.zeros((n, self.meas_cap), dtype=torch.float32, device=self.device)
+                pad[:, : min(nz.shape[1], self.meas_cap)] = nz[:, : self.meas_cap]
+                nz = pad
+        z = torch.empty((n, self.meas_cap), dtype=torch.float32, device=self.device)
+        m = torch.empty(n, dtype=torch.int32, device=self.device)
+        shape = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        _ffi.check(self._lib.ipp_observe(self._h, self._ptr(ids), n, self._ptr(a), self._ptr(nz), self._ptr(z), self._ptr(m),
+                                         self._ptr(shape), self.stream))
+        self._keep = (a, ids, nz)
+        return z, m, shape
+
+    def set_uav(self, max_v: float, max_a: float):
+        _ffi.check(self._lib.ipp_set_uav(self._h, float(max_v), float(max_a)))
 
     def set_adaptive(self, value_threshold: float, interval_factor: float):
         _ffi.check(self._lib.ipp_set_adaptive(self._h, float(value_threshold), float(interval_factor)))

@@ -1,0 +1,187 @@
+"""
+CPU-only checks: the C-ABI library loads and exports every symbol include/ipp_engine.h declares (no compute
+without a GPU), the ctypes binding mirrors the header, the product path fails loudly without a GPU, and the
+host-side mirrors of the reference's scalar helpers agree with golden vectors recorded from the reference.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.params import example_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "ipp_engine.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ipp_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ipp_rl_amd import _ffi
+
+    assert os.path.exists(_ffi.LIB_PATH), "build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ipp_engine.h but not exported"
+    assert sorted(_ffi.PROTOTYPES) == names, "ctypes prototypes and header declarations differ"
+    assert _ffi.load().ipp_abi_version() == _ffi.ABI_VERSION
+    txt = open(os.path.join(ROOT, "include", "ipp_engine.h")).read()
+    for macro, val in (("IPP_COV_ONLY", _ffi.IPP_COV_ONLY), ("IPP_PREDICT_ONLY", _ffi.IPP_PREDICT_ONLY),
+                       ("IPP_ADAPTIVE", _ffi.IPP_ADAPTIVE), ("IPP_USE_FLIGHT_TIME", _ffi.IPP_USE_FLIGHT_TIME),
+                       ("IPP_GIVEN_OBSERVATION", _ffi.IPP_GIVEN_OBSERVATION), ("IPP_MAX_MEAS", _ffi.IPP_MAX_MEAS)):
+        m = re.search(rf"#define\s+{macro}\s+(\d+)", txt)
+        assert m and int(m.group(1)) == val
+
+
+def test_struct_layouts_match_header_order():
+    from ipp_rl_amd import _ffi
+
+    txt = open(os.path.join(ROOT, "include", "ipp_engine.h")).read()
+    body = re.search(r"typedef struct ipp_config \{(.*?)\} ipp_config;", txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(?:int32_t|double)\s+([a-z_]+);", body)
+    assert fields == [f[0] for f in _ffi.IppConfig._fields_]
+    assert ctypes.sizeof(_ffi.IppConfig) == 8 + 13 * 8 + 6 * 4
+
+
+def test_arena_sizing_and_validation_without_gpu():
+    """Pure host entry points work without a device; bad configs are rejected with a message."""
+    from ipp_rl_amd import _ffi
+
+    lib = _ffi.load()
+    c = _ffi.IppConfig(x_dim=50, y_dim=50, resolution=4.0, tan_half_fov_x=0.57735, tan_half_fov_y=0.57735,
+                       rf_altitude=10.0, coeff_a=0.05, coeff_b=0.2, signal_variance=1.82, length_scale=3.67, max_v=2,
+                       max_a=2, value_threshold=0.4, interval_factor=0, cluster_radius=5, state_repr=_ffi.IPP_FACTOR,
+                       capacity=4096, rank_cap=360, max_batch=4096, max_measurements=9, tile_threads=0)
+    nbytes = ctypes.c_uint64(0)
+    assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(nbytes)) == 0
+    cov = 4096 * 360 * 2560 * 4
+    assert cov < nbytes.value < cov * 1.05  # state is dominated by the factor slab U[B][r_cap][Npad]
+    c.state_repr = _ffi.IPP_DENSE
+    assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(nbytes)) == 0
+    assert nbytes.value > 4096 * 2500 * 2560 * 4
+    c.rank_cap, c.state_repr = 0, _ffi.IPP_FACTOR
+    assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(nbytes)) < 0
+    assert b"rank_cap" in lib.ipp_last_error()
+    c.rank_cap, c.tile_threads = 360, 100
+    assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(nbytes)) < 0
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+
+    from ipp_rl_amd import EngineConfig, IPPEngine, IppError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(IppError):
+        IPPEngine(EngineConfig(x_dim=10, y_dim=10), capacity=2)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from ipp_rl_amd import _ffi
+
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_ffi.IppError, match="no CPU fallback"):
+        _ffi.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ipp-rl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+                assert "libipp_oracle" not in src
+
+
+# ------------------------------------------------------------------ host mirrors vs golden
+def make_sensor(dim_x, dim_y, res):
+    from ipp_rl_amd.mapping.grid_maps import GridMap
+    from ipp_rl_amd.sensors.cameras import RGBCamera
+    from ipp_rl_amd.sensors.models.sensor_models import AltitudeSensorModel
+
+    params = example_params(dim_x, dim_y, res)
+    gm = GridMap(params)
+    return gm, RGBCamera(params["sensor"]["field_of_view"], AltitudeSensorModel(0.05, 0.2), gm)
+
+
+def test_camera_footprints_vs_golden(golden):
+    g = golden("footprints")
+    for res, alt, rx, ry, radx, rady, rf, nv in g["table"]:
+        gm, cam = make_sensor(400, 400, res)
+        pos = np.array([200.0 * res + 0.5 * res, 200.0 * res + 0.5 * res, alt])
+        assert cam.field_of_view_range(alt) == (rx, ry)
+        xl, xr, yu, yd = cam.project_field_of_view(pos)
+        assert ((xr - xl) // 2, (yd - yu) // 2) == (radx, rady)
+        assert cam.get_resolution_factor(pos) == rf and cam.sensor_model.get_noise_variance(pos) == nv
+    gm, cam = make_sensor(50, 50, 4)
+    for p, fov in zip(g["positions"], g["fovs"]):
+        assert cam.project_field_of_view(p) == tuple(fov)
+
+
+def test_sensor_model_matrices_vs_golden(golden):
+    g = golden("measurement_model")
+    gm, cam = make_sensor(int(g["x_dim"]), int(g["y_dim"]), 4)
+    sm = cam.sensor_model
+    for fov, rf, m, H, r00 in zip(g["fovs"], g["rfs"], g["ms"], g["H"], g["R00"]):
+        Hm = sm.measurement_model_matrix(gm, tuple(int(v) for v in fov), int(m), int(rf))
+        assert np.array_equal(Hm, H[: int(m)])
+        R = sm.measurement_variance_matrix(np.array([0, 0, 14.0 if rf == 2 else 8.0]), int(m), int(rf))
+        assert abs(R[0, 0] - r00) < 1e-16 and R.shape == (m, m)
+
+
+def test_action_costs_and_rewards_vs_golden(golden):
+    from ipp_rl_amd.planning.common import actions, rewards
+
+    g = golden("costs")
+    uav, uav2 = {"max_v": 2, "max_a": 2}, {"max_v": 5.0, "max_a": 1.5}
+    for i, (a, b) in enumerate(zip(g["a"], g["b"])):
+        assert abs(actions.action_costs(a, b, None) - g["dist"][i]) < 1e-12
+        assert abs(actions.action_costs(a, b, uav) - g["t_v2a2"][i]) < 1e-12
+        assert abs(actions.compute_flight_time(a, b, uav2) - g["t_v5a15"][i]) < 1e-12
+    assert np.max(np.abs(actions.compute_flight_times(g["a"], g["b"][0], uav) - g["t_vec"])) < 1e-12
+    gp = golden("predict_10")
+    P0, P1 = gp["P0"], gp["P_seq"][0]
+    a0, prev = gp["actions"][0], np.array([2.0, 2.0, 14.0])
+    msk = rewards.compute_adaptive_msk(gp["mean_used"][0], P0, 0.4, 0)
+    assert np.array_equal(msk, gp["mask"][0])
+    assert abs(rewards.compute_reward(P0, P1, prev, a0, uav, msk) - gp["reward"][0]) < 1e-12
+    gg = golden("greedy")
+    gm, _ = make_sensor(10, 10, 4)
+    cands = actions.get_actions(prev, 200, gm, 8, 14, 6, uav)
+    assert np.array_equal(np.array(cands), gg["candidates_10"])
+    en = actions.enumerate_actions(gm, 8, 14, 6)
+    assert len(en) == 200 and np.array_equal(en[0], [2.0, 2.0, 8.0]) and np.array_equal(en[100 + 10], [6.0, 2.0, 14.0])
+    assert actions.out_of_bounds([41, 2, 8], gm, 8, 14) and not actions.out_of_bounds([40, 2, 8], gm, 8, 14)
+
+
+def test_config_errors_follow_the_reference():
+    from ipp_rl_amd.mapping.grid_maps import GridMap
+
+    with pytest.raises(ValueError):
+        GridMap({"environment": {"x_dim": 3}}).y_dim
+    with pytest.raises(ValueError):
+        GridMap({}).x_dim
+
+
+def test_engine_config_from_params_and_workload_helpers():
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import cell_centre_actions, shard_range
+
+    cfg = EngineConfig.from_params(example_params(50))
+    assert (cfg.x_dim, cfg.resolution, cfg.coeff_b, cfg.signal_variance, cfg.max_v) == (50, 4.0, 0.2, 1.82, 2.0)
+    full = cell_centre_actions(cfg, 3, 0, 64, 64, [5.0, 6.0, 7.0])
+    parts = [cell_centre_actions(cfg, 3, *shard_range(64, r, 4), 64, [5.0, 6.0, 7.0]) for r in range(4)]
+    assert np.array_equal(np.concatenate(parts), full)  # sharding does not change any env's inputs
+    assert np.all((full[:, 0] - 2.0) % 4.0 == 0) and set(np.unique(full[:, 2])) <= {5.0, 6.0, 7.0}
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
