@@ -157,16 +157,10 @@ def main():
             run_steps(1)
             rank_sum += eng.ranks(ranks_buf).double().sum()  # rows streamed (nothing appended)
         else:
-            t_idx_before = t_idx
-            # rows streamed + columns appended this step = sum of ranks right after the step kernel; resets
-            # come after it inside env.step, so read the ranks through a no-reset step and reset by hand
-            env.step(actions[t_idx], auto_reset=False); t_idx += 1
-            rank_sum += eng.ranks(ranks_buf).double().sum()
-            p = (T - (env.t % T)) % T
-            ids = env._reset_ids_by_phase[p]
-            if ids.numel():
-                env.reset(ids)
-            del t_idx_before
+            # rows streamed + columns appended by this step = ranks right after the step kernel and before
+            # the scheduled resets: env.step() snapshots them through this hook
+            env.step(actions[t_idx], after_step_hook=lambda: rank_sum.add_(eng.ranks(ranks_buf).double().sum()))
+            t_idx += 1
     torch.cuda.synchronize()
     gain_ms, gain_n = eng.profile_read(0)
     down_ms, down_n = eng.profile_read(1)

@@ -135,6 +135,15 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
               const float* white_noise, void* stream);
 
 /*
+ * Ground-truth generation only: white noise [n][H][W] -> min-max normalised Gaussian random field into the
+ * caller buffer gt_out [n][H][W] (no env slot is touched).  Lets the host prepare the next episodes' ground
+ * truths on a side stream while ipp_step runs, then install them with ipp_reset(gt = ...).
+ * Replaces gaussian_random_field (simulations/ground_truths.py:14-33).  Uses its own scratch, so it may
+ * overlap ipp_step / ipp_reset of the same engine issued on another stream.
+ */
+int ipp_generate_grf(void* engine, int32_t n, const float* white_noise /*[dev]*/, float* gt_out /*[dev]*/, void* stream);
+
+/*
  * One fused environment step for `n` items.  Replaces, per item:
  *   simulate_prediction_step            (planning/common/optimization.py:14-30)
  *     compute_adaptive_msk              (planning/common/rewards.py:8-12)

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "ipp_engine_destroy": (C.c_int, [_P]),
     "ipp_engine_info": (C.c_int, [_P, C.POINTER(IppInfo)]),
     "ipp_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
+    "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "ipp_set_uav": (C.c_int, [_P, C.c_double, C.c_double]),

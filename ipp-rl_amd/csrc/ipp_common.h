@@ -8,7 +8,10 @@
 namespace ipp {
 
 constexpr int kWave = 64;          // CDNA wavefront
-constexpr int kPrepThreads = 256;  // prologue workgroup
+#ifndef IPP_PREP_THREADS
+#define IPP_PREP_THREADS 128
+#endif
+constexpr int kPrepThreads = IPP_PREP_THREADS;  // prologue workgroup
 constexpr int kMaxTileThreads = 640;
 constexpr int kQChunk = 128;       // rows of Q staged in LDS per pass of the streaming loop
 constexpr int kBandRows = 20;      // rows of P per dense-downdate workgroup
@@ -27,9 +30,10 @@ struct ItemHdr {
 
 // Everything the kernels need, passed by value.
 struct View {
-    int W, H, N, Npad, T, n_tiles, vec, pad_;
+    int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL
     int mode, cap, rank_cap, max_batch;
     int meas_cap, fp_cap, q_stride, q_rows;
+    uint64_t q_item;  // floats of Q scratch per item: (q_rows + 2*kPipe pad rows) * q_stride
     double res, tanx, tany, rf_alt, coeff_a, coeff_b, sv0, ls0, vmax, amax, thr, kf;
     // state slabs
     float* mean;     // [cap][Npad]
@@ -48,7 +52,8 @@ struct View {
     double* partial; // [max_batch][n_tiles]
     double* dbg;     // [max_batch][2*MC*MC + 2*MC]   S, Linv, z, y in fp64 (tests)
     double* grf_h;   // [H][W] circular-convolution kernel of the GRF
-    float* grf_raw;  // [max_batch][Npad] un-normalised field
+    float* grf_raw;  // [max_batch][Npad] un-normalised field (ipp_reset)
+    float* grf_raw2; // [max_batch][Npad] un-normalised field (ipp_generate_grf, may run on a side stream)
 };
 
 __device__ __forceinline__ double wave_sum(double x) {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,6 +39,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr uint64_t kAlign = 256;
+constexpr int kMaxChunks = 8;
 inline uint64_t up(uint64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct ProfSlot {
@@ -57,6 +59,10 @@ struct Engine {
     int q_chunk;
     int lut_cap;
     bool profile = false;
+    int step_chunks = 0;  // 0 = auto
+    hipStream_t side = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_prep[8] = {};
     ProfSlot prof[3];
     int last_n = 0;
 };
@@ -64,8 +70,13 @@ struct Engine {
 struct Layout {
     int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
-        off_partial, off_dbg, off_grfh, off_grfraw, total, cov_slot_floats;
+        off_partial, off_dbg, off_grfh, off_grfraw, off_grfraw2, total, cov_slot_floats;
 };
+
+uint64_t q_item_floats(const Layout& L) {
+    const uint64_t lq = ((uint64_t)L.MC * L.MC + L.MC + 3) & ~(uint64_t)3;
+    return lq + (uint64_t)(L.q_rows + 8) * L.QS;
+}
 
 int plan(const ipp_config& c, Layout& L) {
     if (c.x_dim <= 0 || c.y_dim <= 0) return fail(-1, "x_dim/y_dim must be positive");
@@ -113,19 +124,21 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
     L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
     L.off_yv = o; o += up(mb * L.MC * 4);
-    L.off_q = o; o += up(mb * (uint64_t)L.q_rows * L.QS * 4);
+    L.off_q = o; o += up(mb * q_item_floats(L) * 4 + 4096);  // [L^-1|y] head + Q rows + pad rows, + DMA over-read slack
     L.off_wc = o; o += (c.state_repr == IPP_DENSE) ? up(mb * L.MC * np * 4) : 0;
     L.off_partial = o; o += up(mb * L.n_tiles * 8);
     L.off_dbg = o; o += up(mb * (2 * L.MC * L.MC + 2 * L.MC) * 8);
     L.off_grfh = o; o += up((uint64_t)L.N * 8);
     L.off_grfraw = o; o += up(mb * np * 4);
+    L.off_grfraw2 = o; o += up(mb * np * 4);
     L.total = o;
     return 0;
 }
 
 size_t prep_lds_bytes(const Layout& L, const ipp_config& c) {
     const size_t MC = L.MC, FC = L.FC, LD = MC + 1;
-    size_t b = (3 * MC * LD + 3 * MC + FC) * sizeof(double) + sizeof(ItemHdr) + 16;
+    size_t b = (3 * MC * LD + 3 * MC + 2 * FC) * sizeof(double) + sizeof(ItemHdr) + 16 +
+               (FC + 8 * MC + ((MC + 3) & ~(size_t)3)) * sizeof(int) + MC * sizeof(double);
     if (c.state_repr == IPP_FACTOR)
         b += MC * (size_t)((c.rank_cap + 3) & ~3) * sizeof(float);
     else
@@ -216,10 +229,12 @@ size_t gain_lds_bytes(const View& v, int q_chunk, int lut_cap) {
     return (b + 15) & ~(size_t)15;
 }
 
+// One chunk of items: prologue -> streaming gain (-> reward finalize) (-> dense downdate) on stream `s`.
+// `v` carries scratch pointers already offset to the chunk's first item.
 template <int MC, int VEC>
-int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
-                const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s) {
-    const View& v = e->v;
+void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
+                  const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
+                  hipEvent_t prep_done) {
     {
         ProfScope ps(e, 2, s);
         if (v.mode == IPP_FACTOR)
@@ -229,6 +244,7 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
             hipLaunchKernelGGL((k_prepare<MC, IPP_DENSE>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
                                action, prev, noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
     }
+    if (prep_done) (void)hipEventRecord(prep_done, s);
     {
         ProfScope ps(e, 0, s);
         const int grid = grid_for(n, v.n_tiles);
@@ -243,6 +259,70 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
         const int grid = grid_for(n, e->n_bands * v.n_tiles);
         hipLaunchKernelGGL((k_downdate<MC, VEC>), dim3(grid), dim3(v.T), 0, s, v, n, e->n_bands);
     }
+}
+
+// The prologue is latency-bound (dependent loads, a 9x9 fp64 factorisation per item) and the gain kernel is
+// HBM-bound, so a large batch is cut into chunks that alternate between the caller's stream and an engine-owned
+// side stream: chunk c's prologue waits for chunk c-1's prologue and therefore runs under chunk c-1's gain
+// kernel.  Chunks touch disjoint items and (for committed steps) disjoint env slots.
+template <int MC, int VEC>
+int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
+                const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s) {
+    int chunks = e->step_chunks;
+    if (chunks <= 0) chunks = 1;  // measured on MI355X: no gain from 2 chunks, slower from 4; opt in with IPP_STEP_CHUNKS
+    if (e->profile) chunks = 1;  // kernels are timed alone (bench.py roofline leg)
+    chunks = std::min(chunks, kMaxChunks);
+    if (chunks <= 1 || !e->side) {
+        launch_chunk<MC, VEC>(e, e->v, env_ids, dst_ids, n, action, prev, noise, flags, reward, status, s, nullptr);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    HIP_TRY(hipEventRecord(e->ev_begin, s));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_begin, 0));
+    const int per = ((n + chunks - 1) / chunks + 7) / 8 * 8;
+    int used = 0;
+    for (int c = 0, off = 0; off < n; ++c, off += per) {
+        const int nc = std::min(per, n - off);
+        hipStream_t st = (c % 2 == 0) ? s : e->side;
+        View v = e->v;
+        v.env_base = off;
+        v.hdr += off;
+        v.linv += (size_t)off * v.meas_cap * v.meas_cap;
+        v.yv += (size_t)off * v.meas_cap;
+        v.q += (size_t)off * v.q_item;
+        if (v.wc) v.wc += (size_t)off * v.meas_cap * v.Npad;
+        v.partial += (size_t)off * v.n_tiles;
+        v.dbg += (size_t)off * (2 * v.meas_cap * v.meas_cap + 2 * v.meas_cap);
+        if (c > 0) HIP_TRY(hipStreamWaitEvent(st, e->ev_prep[c - 1], 0));
+        launch_chunk<MC, VEC>(e, v, env_ids ? env_ids + off : nullptr, dst_ids ? dst_ids + off : nullptr, nc,
+                              action + 3 * (size_t)off, prev + 3 * (size_t)off, noise ? noise + (size_t)off * MC : nullptr,
+                              flags, reward + off, status ? status + off : nullptr, st, e->ev_prep[c]);
+        used = c + 1;
+    }
+    (void)used;
+    HIP_TRY(hipEventRecord(e->ev_end, e->side));
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_end, 0));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// white [n][N] -> normalised field, either into the env slots (gt_out == nullptr) or into gt_out [n][N]
+int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
+    const View& v = e->v;
+    if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
+    const size_t lds = (size_t)v.N * (sizeof(double) + sizeof(float));
+    const bool use_lds = lds <= 120 * 1024;
+    const int ot = (v.W <= 64) ? 5 : 8;
+    const int tpr = (v.W + ot - 1) / ot;
+    const int groups = v.H * tpr;
+    if (use_lds) {  // one workgroup per env, tables in LDS
+        if (ot == 5) hipLaunchKernelGGL((k_grf_conv<5, true>), dim3(1, n), dim3(256), lds, s, v, n, white, tpr, raw);
+        else         hipLaunchKernelGGL((k_grf_conv<8, true>), dim3(1, n), dim3(256), lds, s, v, n, white, tpr, raw);
+    } else {
+        if (ot == 5) hipLaunchKernelGGL((k_grf_conv<5, false>), dim3((groups + 255) / 256, n), dim3(256), 0, s, v, n, white, tpr, raw);
+        else         hipLaunchKernelGGL((k_grf_conv<8, false>), dim3((groups + 255) / 256, n), dim3(256), 0, s, v, n, white, tpr, raw);
+    }
+    hipLaunchKernelGGL(k_grf_norm, dim3(n), dim3(256), 0, s, v, env_ids, n, raw, gt_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -282,9 +362,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->device = device;
     e->used_bytes = L.total;
     View& v = e->v;
-    v.W = cfg->x_dim; v.H = cfg->y_dim; v.N = L.N; v.Npad = L.Npad; v.T = L.T; v.n_tiles = L.n_tiles; v.vec = L.VEC; v.pad_ = 0;
+    v.W = cfg->x_dim; v.H = cfg->y_dim; v.N = L.N; v.Npad = L.Npad; v.T = L.T; v.n_tiles = L.n_tiles; v.vec = L.VEC; v.env_base = 0;
     v.mode = cfg->state_repr; v.cap = cfg->capacity; v.rank_cap = cfg->rank_cap; v.max_batch = cfg->max_batch;
-    v.meas_cap = L.MC; v.fp_cap = L.FC; v.q_stride = L.QS; v.q_rows = L.q_rows;
+    v.meas_cap = L.MC; v.fp_cap = L.FC; v.q_stride = L.QS; v.q_rows = L.q_rows; v.q_item = q_item_floats(L);
     v.res = cfg->resolution; v.tanx = cfg->tan_half_fov_x; v.tany = cfg->tan_half_fov_y; v.rf_alt = cfg->rf_altitude;
     v.coeff_a = cfg->coeff_a; v.coeff_b = cfg->coeff_b; v.sv0 = cfg->signal_variance; v.ls0 = cfg->length_scale;
     v.vmax = cfg->max_v; v.amax = cfg->max_a; v.thr = cfg->value_threshold; v.kf = cfg->interval_factor;
@@ -305,6 +385,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.dbg = reinterpret_cast<double*>(base + L.off_dbg);
     v.grf_h = reinterpret_cast<double*>(base + L.off_grfh);
     v.grf_raw = reinterpret_cast<float*>(base + L.off_grfraw);
+    v.grf_raw2 = reinterpret_cast<float*>(base + L.off_grfraw2);
     e->n_bands = (L.N + kBandRows - 1) / kBandRows;
     e->prep_lds = prep_lds_bytes(L, *cfg);
     e->q_chunk = std::min(1024, (L.q_rows + 2 * kPipe - 1) / (2 * kPipe) * (2 * kPipe));
@@ -321,6 +402,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<9, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     const int glds = (int)e->gain_lds;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -335,6 +418,15 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         grf_kernel_host(cfg->y_dim, cfg->x_dim, cfg->cluster_radius, h);
         HIP_TRY(hipMemcpy(v.grf_h, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (const char* ch = getenv("IPP_STEP_CHUNKS")) e->step_chunks = atoi(ch);
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess) {
+        (void)hipEventCreateWithFlags(&e->ev_begin, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&e->ev_end, hipEventDisableTiming);
+        for (auto& ev : e->ev_prep) (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    } else {
+        e->side = nullptr;
+        (void)hipGetLastError();
+    }
     *engine = e;
     return 0;
 }
@@ -343,6 +435,13 @@ int ipp_engine_destroy(void* engine) {
     Engine* e = as_engine(engine);
     if (!e) return 0;
     for (auto& p : e->prof) prof_drain(p);
+    if (e->side) {
+        (void)hipStreamSynchronize(e->side);
+        (void)hipStreamDestroy(e->side);
+        (void)hipEventDestroy(e->ev_begin);
+        (void)hipEventDestroy(e->ev_end);
+        for (auto& ev : e->ev_prep) (void)hipEventDestroy(ev);
+    }
     delete e;
     return 0;
 }
@@ -376,14 +475,7 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
     hipLaunchKernelGGL(k_reset_small, dim3((v.Npad + 255) / 256, n), dim3(256), 0, s, v, env_ids, n, prior_scale, gt);
     if (!gt && white_noise) {
         if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
-        if (v.W <= 64) {
-            const int tpr = (v.W + 4) / 5;
-            hipLaunchKernelGGL((k_grf_conv<5>), dim3((v.H * tpr + 255) / 256, n), dim3(256), 0, s, v, n, white_noise, tpr);
-        } else {
-            const int tpr = (v.W + 7) / 8;
-            hipLaunchKernelGGL((k_grf_conv<8>), dim3((v.H * tpr + 255) / 256, n), dim3(256), 0, s, v, n, white_noise, tpr);
-        }
-        hipLaunchKernelGGL(k_grf_norm, dim3(n), dim3(256), 0, s, v, env_ids, n);
+        if (int rc = launch_grf(e, n, white_noise, v.grf_raw, env_ids, nullptr, s)) return rc;
     }
     if (v.mode == IPP_DENSE) {
         const int n_ctiles = (v.Npad + 1023) / 1024;
@@ -418,6 +510,15 @@ int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32
     if (e->v.meas_cap == 9)
         return launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
     return launch_step<25, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
+}
+
+int ipp_generate_grf(void* engine, int32_t n, const float* white_noise, float* gt_out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !white_noise || !gt_out) return fail(-1, "null argument");
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    return launch_grf(e, n, white_noise, e->v.grf_raw2, nullptr, gt_out, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ipp_observe(void* engine, const int32_t* env_ids, int32_t n, const double* action, const float* meas_noise,

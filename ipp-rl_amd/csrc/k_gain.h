@@ -132,7 +132,8 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
     }
 
     const int cell0 = tile * VEC * T + VEC * tid;
-    const float* __restrict__ qg = v.q + (size_t)item * v.q_rows * v.q_stride;
+    constexpr int LQ = (MC * MC + MC + 3) & ~3;  // the item's scratch block is [L^-1 | y | pad | Q rows | zero rows]
+    const float* __restrict__ qg = v.q + (size_t)item * v.q_item + LQ;
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
     const int rows = h.rows;

@@ -55,63 +55,83 @@ __global__ __launch_bounds__(256) void k_reset_dense(View v, const int* __restri
 
 // GRF as a circular convolution: field = white (*) h, h = Re ifft2(amp) (simulations/ground_truths.py:14-31;
 // amp is real and even so Re ifft2(fft2(white) * amp) is exactly this convolution).  fp64 accumulate.
-// Register-tiled: a thread owns OT consecutive outputs of one row and keeps the OT kernel taps they share
-// in a rotating register window, so each step costs one 8-byte tap load (L1-resident, 20 KB table at 50x50)
-// and one broadcast white value for OT fp64 FMAs.
-template <int OT>
-__global__ __launch_bounds__(256) void k_grf_conv(View v, int n_items, const float* __restrict__ white, int tpr) {
+// One workgroup per env: the tap table h (fp64) and the white noise (fp32) are staged in LDS once; a thread
+// owns OT consecutive outputs of one row and keeps the OT taps they share in a rotating register window, so
+// each step costs one 8-byte LDS tap read and one broadcast white value for OT fp64 FMAs; the taps of the
+// next OT steps are read while the current ones are consumed.  Grids whose tables exceed LDS read them
+// through L1/L2 instead (LDS_TABLES = false).
+template <int OT, bool LDS_TABLES>
+__global__ __launch_bounds__(256) void k_grf_conv(View v, int n_items, const float* __restrict__ white, int tpr,
+                                                  float* __restrict__ raw_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_grf[];
     const int item = blockIdx.y;
-    const int tix = blockIdx.x * blockDim.x + threadIdx.x;  // (row, x-group)
     if (item >= n_items) return;
-    const int W = v.W, H = v.H;
-    const bool active = tix < H * tpr;
-    const int y = active ? tix / tpr : 0;
-    const int x0 = active ? (tix - y * tpr) * OT : 0;
-    const float* __restrict__ wn = white + (size_t)item * v.N;
-    const double* __restrict__ hk = v.grf_h;
-    double acc[OT], win[OT];
+    const int W = v.W, H = v.H, N = v.N;
+    const float* __restrict__ wn = white + (size_t)item * N;
+    const double* hk = v.grf_h;
+    const float* wk = wn;
+    if (LDS_TABLES) {
+        double* hs = reinterpret_cast<double*>(smem_grf);
+        float* ws = reinterpret_cast<float*>(hs + N);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) { hs[i] = v.grf_h[i]; ws[i] = wn[i]; }
+        __syncthreads();
+        hk = hs;
+        wk = ws;
+    }
+    const int n_groups = H * tpr;
+    for (int tix = blockIdx.x * blockDim.x + threadIdx.x; tix < n_groups; tix += gridDim.x * blockDim.x) {
+        const int y = tix / tpr;
+        const int x0 = (tix - y * tpr) * OT;
+        double acc[OT], win[OT], nxt[OT];
 #pragma unroll
-    for (int j = 0; j < OT; ++j) acc[j] = 0.0;
-    const int wsteps = (W + OT - 1) / OT * OT;
-    for (int yp = 0; yp < H; ++yp) {
-        int hy = y - yp;
-        if (hy < 0) hy += H;
-        const double* __restrict__ hrow = hk + (size_t)hy * W;
-        const float* __restrict__ wrow = wn + (size_t)yp * W;
-        // window holds h[(x0 + j - xp) mod W] at win[(j - xp) mod OT]; preload j = 1..OT-1 for xp = 0
+        for (int j = 0; j < OT; ++j) acc[j] = 0.0;
+        const int wsteps = (W + OT - 1) / OT * OT;
+        for (int yp = 0; yp < H; ++yp) {
+            int hy = y - yp;
+            if (hy < 0) hy += H;
+            const double* hrow = hk + (size_t)hy * W;
+            const float* wrow = wk + (size_t)yp * W;
+            // window holds h[(x0 + j - xp) mod W] at win[(j - xp) mod OT]; preload j = 1..OT-1 for xp = 0
 #pragma unroll
-        for (int j = 1; j < OT; ++j) {
-            int idx = x0 + j;
-            idx -= (idx >= W) ? W : 0;
-            idx -= (idx >= W) ? W : 0;
-            win[j] = hrow[idx];
-        }
-        int hi = x0 - ((x0 >= W) ? W : 0);  // (x0 - xp) mod W, decremented each step
-        for (int xb = 0; xb < wsteps; xb += OT) {
+            for (int j = 1; j < OT; ++j) {
+                int idx = x0 + j;
+                idx -= (idx >= W) ? W : 0;
+                win[j] = hrow[idx];
+            }
+            int hi = x0;  // (x0 - xp) mod W, decremented each step
 #pragma unroll
-            for (int u = 0; u < OT; ++u) {
-                const int xp = xb + u;
-                win[(OT - u) % OT] = hrow[hi];       // new tap h[(x0 - xp) mod W] replaces the one that left
-                hi = (hi == 0) ? W - 1 : hi - 1;
-                const double wv = (xp < W) ? (double)wrow[xp] : 0.0;
+            for (int u = 0; u < OT; ++u) { nxt[u] = hrow[hi]; hi = (hi == 0) ? W - 1 : hi - 1; }
+            for (int xb = 0; xb < wsteps; xb += OT) {
+                double cur[OT];
+                float wv[OT];
 #pragma unroll
-                for (int j = 0; j < OT; ++j) acc[j] = fma(wv, win[(j + OT - u) % OT], acc[j]);
+                for (int u = 0; u < OT; ++u) { cur[u] = nxt[u]; wv[u] = (xb + u < W) ? wrow[xb + u] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < OT; ++u) { nxt[u] = hrow[hi]; hi = (hi == 0) ? W - 1 : hi - 1; }  // taps of the next block
+#pragma unroll
+                for (int u = 0; u < OT; ++u) {
+                    win[(OT - u) % OT] = cur[u];  // new tap h[(x0 - xp) mod W] replaces the one that left
+                    const double w = (double)wv[u];
+#pragma unroll
+                    for (int j = 0; j < OT; ++j) acc[j] = fma(w, win[(j + OT - u) % OT], acc[j]);
+                }
             }
         }
-    }
-    if (!active) return;
 #pragma unroll
-    for (int j = 0; j < OT; ++j)
-        if (x0 + j < W) v.grf_raw[(size_t)item * v.Npad + y * W + x0 + j] = (float)acc[j];
+        for (int j = 0; j < OT; ++j)
+            if (x0 + j < W) raw_out[(size_t)item * v.Npad + y * W + x0 + j] = (float)acc[j];
+    }
 }
 
 // min-max normalisation to [0, 1] (simulations/ground_truths.py:31).
-__global__ __launch_bounds__(256) void k_grf_norm(View v, const int* __restrict__ env_ids, int n_items) {
+// gt_out == nullptr: write into the env slots (ipp_reset); else into the caller buffer [n][N] (ipp_generate_grf).
+__global__ __launch_bounds__(256) void k_grf_norm(View v, const int* __restrict__ env_ids, int n_items,
+                                                  const float* __restrict__ raw_all, float* __restrict__ gt_out) {
     __shared__ float smin[4], smax[4];
     const int item = blockIdx.x;
-    const int env = env_ids ? env_ids[item] : item;
+    const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
     if (env < 0 || env >= v.cap) return;
-    const float* raw = v.grf_raw + (size_t)item * v.Npad;
+    const float* raw = raw_all + (size_t)item * v.Npad;
     float lo = INFINITY, hi = -INFINITY;
     for (int i = threadIdx.x; i < v.N; i += blockDim.x) { lo = fminf(lo, raw[i]); hi = fmaxf(hi, raw[i]); }
     lo = wave_min(lo);
@@ -121,6 +141,11 @@ __global__ __launch_bounds__(256) void k_grf_norm(View v, const int* __restrict_
     lo = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
     hi = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
     const double dlo = lo, span = (double)hi - (double)lo;
+    if (gt_out) {
+        float* gt = gt_out + (size_t)item * v.N;
+        for (int i = threadIdx.x; i < v.N; i += blockDim.x) gt[i] = (float)(((double)raw[i] - dlo) / span);
+        return;
+    }
     float* gt = v.gt + (size_t)env * v.Npad;
     for (int i = threadIdx.x; i < v.Npad; i += blockDim.x) gt[i] = (i < v.N) ? (float)(((double)raw[i] - dlo) / span) : 0.f;
 }

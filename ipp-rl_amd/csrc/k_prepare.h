@@ -10,26 +10,31 @@
 #pragma once
 #include "ipp_common.h"
 
+#ifndef IPP_PREP_MINWAVES
+#define IPP_PREP_MINWAVES 4
+#endif
+
 namespace ipp {
 
-// One axis of OpenCV's INTER_AREA table (computeResizeAreaTab, opencv 4.5.2 resize.cpp): weights are
-// evaluated in double and stored as float.  Returns the tap count (<= cap).
-__device__ inline int area_taps(int src, int dst, int d, int* idx, double* wt, int cap) {
+// Weight of source index s for destination index d along one axis of OpenCV's INTER_AREA table
+// (computeResizeAreaTab, opencv 4.5.2 resize.cpp): the table's three clauses evaluated directly; weights are
+// computed in double and stored as float there, hence the (float) round trip.  PARITY UNPINNED (cv2 absent).
+__device__ inline double area_weight(int src, int dst, int d, int s) {
     const double scale = (double)src / (double)dst;
     const double a = d * scale, b = a + scale;
     const double cell = fmin(scale, (double)src - a);
     int s1 = (int)ceil(a);
-    int s2 = min((int)floor(b), src - 1);
+    const int s2 = min((int)floor(b), src - 1);
     s1 = min(s1, s2);
-    int n = 0;
-    if (s1 - a > 1e-3 && n < cap) { idx[n] = s1 - 1; wt[n++] = (double)(float)((s1 - a) / cell); }
-    for (int s = s1; s < s2 && n < cap; ++s) { idx[n] = s; wt[n++] = (double)(float)(1.0 / cell); }
-    if (b - s2 > 1e-3 && n < cap) { idx[n] = s2; wt[n++] = (double)(float)(fmin(fmin(b - s2, 1.0), cell) / cell); }
-    return n;
+    double w = 0.0;
+    if (s == s1 - 1 && s1 - a > 1e-3) w += (double)(float)((s1 - a) / cell);
+    if (s >= s1 && s < s2) w += (double)(float)(1.0 / cell);
+    if (s == s2 && b - s2 > 1e-3) w += (double)(float)(fmin(fmin(b - s2, 1.0), cell) / cell);
+    return w;
 }
 
 template <int MC, int MODE>
-__global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __restrict__ env_ids,
+__global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(View v, const int* __restrict__ env_ids,
                                                           const int* __restrict__ dst_ids, int n_items,
                                                           const double* __restrict__ action,
                                                           const double* __restrict__ prev_action,
@@ -47,20 +52,24 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
     double* vv = zz + MC;                                 // [MC] innovation
     double* yy = vv + MC;                                 // [MC]
     double* sub = yy + MC;                                // [FC] ground-truth crop
-    ItemHdr* hs = reinterpret_cast<ItemHdr*>(sub + FC);
+    double* ktab = sub + FC;                              // [FC] prior between footprint cells by (|drow|, |dcol|)
+    ItemHdr* hs = reinterpret_cast<ItemHdr*>(ktab + FC);
     int* okflag = reinterpret_cast<int*>(hs + 1);          // [4]
-    float* big = reinterpret_cast<float*>(okflag + 4);     // factor: HT[MC][ht_ld]   dense: PFF[FC][FC+1]
+    int* cellidx = okflag + 4;                             // [FC] flat cell index of footprint cell fi
+    int* bcell = cellidx + FC;                             // [MC][4] flat cell indices of block i
+    int* bfi = bcell + 4 * MC;                             // [MC][4] footprint-local indices of block i
+    int* bcnt = bfi + 4 * MC;                              // [MC] cells in block i (1, 2 or 4)
+    double* bwt = reinterpret_cast<double*>(bcnt + ((MC + 3) & ~3));  // [MC] weight of block i
+    float* big = reinterpret_cast<float*>(bwt + MC);       // factor: HT[MC][ht_ld]   dense: PFF[FC][FC+1]
 
     const int item = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    constexpr int NW = kPrepThreads / kWave;
     if (item >= n_items) return;
 
     // ------------------------------------------------------------------ header (thread 0, fp64 like NumPy)
     if (tid == 0) {
         ItemHdr h;
-        h.env = env_ids ? env_ids[item] : item;
+        h.env = env_ids ? env_ids[item] : item + v.env_base;
         h.dst = dst_ids ? dst_ids[item] : h.env;
         h.status = IPP_STATUS_OK;
         h.fallback = 0;
@@ -129,7 +138,9 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
     float* linv_out = v.linv + (size_t)item * MC * MC;
     float* y_out = v.yv + (size_t)item * MC;
     double* dbg = v.dbg + (size_t)item * (2 * MC * MC + 2 * MC);
-    float* q_out = v.q + (size_t)item * v.q_rows * v.q_stride;
+    constexpr int LQ = (MC * MC + MC + 3) & ~3;
+    float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]: one DMA block for k_gain
+    float* q_out = blk_out + LQ;
 
     if (m == 0) {  // bad footprint: nothing to stream
         if (tid == 0) {
@@ -137,8 +148,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
             if (status_out) status_out[item] = h.status;
             if (obs_m) obs_m[item] = 0;
         }
-        for (int i = tid; i < MC * MC; i += kPrepThreads) linv_out[i] = 0.f;
-        for (int i = tid; i < MC; i += kPrepThreads) y_out[i] = 0.f;
+        for (int i = tid; i < MC * MC; i += kPrepThreads) { linv_out[i] = 0.f; blk_out[i] = 0.f; }
+        for (int i = tid; i < MC; i += kPrepThreads) { y_out[i] = 0.f; blk_out[MC * MC + i] = 0.f; }
         return;
     }
 
@@ -149,12 +160,28 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
     const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
     const bool cov_only = (flags & IPP_COV_ONLY) != 0;
 
+    // ------------------------------------------------------------------ footprint tables (no divisions later)
+    for (int fi = tid; fi < f; fi += kPrepThreads) {
+        const int ly = fi / h.w, lx = fi - ly * h.w;
+        cellidx[fi] = (h.yu + ly) * v.W + h.xl + lx;
+    }
+    for (int i = tid; i < m; i += kPrepThreads) {
+        const Block b = block_of(i, h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+        bcnt[i] = b.count();
+        bwt[i] = b.weight;
+        for (int a = 0; a < 4; ++a) {
+            const int aa = min(a, b.count() - 1);
+            const int ly = b.y0 + aa / b.bw, lx = b.x0 + aa % b.bw;
+            bfi[4 * i + a] = ly * h.w + lx;
+            bcell[4 * i + a] = (h.yu + ly) * v.W + h.xl + lx;
+        }
+    }
+    if (MODE == IPP_FACTOR && tid < f) ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv, ls);
+    __syncthreads();
+
     // ------------------------------------------------------------------ observation + innovation
     if (!cov_only) {
-        for (int i = tid; i < f; i += kPrepThreads) {
-            const int ly = i / h.w, lx = i - ly * h.w;
-            sub[i] = (double)gt_env[(h.yu + ly) * v.W + h.xl + lx];  // simulations/__init__.py:24-25
-        }
+        for (int i = tid; i < f; i += kPrepThreads) sub[i] = (double)gt_env[cellidx[i]];  // simulations/__init__.py:24-25
         __syncthreads();
         if (tid < m) {
             double val;
@@ -164,14 +191,15 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
                 // cv2.resize(sub, dsize=(ceil(h/rf), ceil(w/rf))) -> width=ceil(h/rf), height=ceil(w/rf)
                 const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
                 const int orow = tid / ocols, ocol = tid - orow * ocols;
-                int ix[12], iy[12];
-                double wx[12], wy[12];
-                const int nxt = area_taps(h.w, ocols, ocol, ix, wx, 12);
-                const int nyt = area_taps(h.h, orows, orow, iy, wy, 12);
                 val = 0.0;
-                for (int a = 0; a < nyt; ++a)
-                    for (int b = 0; b < nxt; ++b) val += sub[iy[a] * h.w + ix[b]] * wx[b] * wy[a];
-                (void)orows;
+                for (int sy = 0; sy < h.h; ++sy) {
+                    const double wy = area_weight(h.h, orows, orow, sy);
+                    if (wy == 0.0) continue;
+                    for (int sx = 0; sx < h.w; ++sx) {
+                        const double wx = area_weight(h.w, ocols, ocol, sx);
+                        if (wx != 0.0) val += sub[sy * h.w + sx] * wx * wy;
+                    }
+                }
             }
             const double eps = meas_noise ? (double)meas_noise[(size_t)item * MC + tid] : 0.0;
             if (flags & IPP_GIVEN_OBSERVATION)
@@ -179,12 +207,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
             else
                 val = fmin(fmax(val + h.nv_d * eps, 0.0), 1.0);  // sensor_manipulations.py:56-57 (variance used as std)
             zz[tid] = val;
-            const Block b = block_of(tid, h.nx, h.rf, h.w, h.h);
             double hx = 0.0;
-            for (int a = 0; a < b.count(); ++a) {
-                const int ly = b.y0 + a / b.bw, lx = b.x0 + a % b.bw;
-                hx += b.weight * (double)mean_env[(h.yu + ly) * v.W + h.xl + lx];
-            }
+            for (int a = 0; a < bcnt[tid]; ++a) hx += bwt[tid] * (double)mean_env[bcell[4 * tid + a]];
             vv[tid] = val - hx;  // mappings.py:195
         }
     } else if (tid < MC) {
@@ -208,60 +232,86 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
     }
 
     // ------------------------------------------------------------------ gather the state rows of the footprint
+    constexpr int MP = (MC <= 16) ? 16 : 32;  // lanes per streaming index: i = tid % MP, no runtime division
     int ht_ld = 0;
     if (MODE == IPP_FACTOR) {
         // HT[i][k] = sum_{cells of block i} w * U[k][cell]   (m x r)
         ht_ld = (r + 3) & ~3;
-        for (int idx = tid; idx < r * m; idx += kPrepThreads) {
-            const int k = idx / m, i = idx - k * m;
-            const Block b = block_of(i, h.nx, h.rf, h.w, h.h);
-            const float* row = cov_env + (size_t)k * v.Npad;
-            float s = 0.f;
-            for (int a = 0; a < b.count(); ++a) {
-                const int ly = b.y0 + a / b.bw, lx = b.x0 + a % b.bw;
-                s += row[(h.yu + ly) * v.W + h.xl + lx];
+        const int i = tid & (MP - 1);
+        if (i < m) {
+            const int cnt = bcnt[i];
+            const int c0 = bcell[4 * i], c1 = bcell[4 * i + 1], c2 = bcell[4 * i + 2], c3 = bcell[4 * i + 3];
+            const float w = (float)bwt[i];
+            // 8 rows per pass: all (<= 32) 4-byte loads of a pass are issued before the first LDS store, so a
+            // thread pays one memory round trip per 8 rows instead of one per row
+            constexpr int KS = kPrepThreads / MP, UN = 8;
+            for (int k0 = tid / MP; k0 < r; k0 += UN * KS) {
+                float sacc[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int k = min(k0 + u * KS, r - 1);
+                    const float* row = cov_env + (size_t)k * v.Npad;
+                    float t = row[c0];
+                    if (cnt > 1) t += row[c1];
+                    if (cnt > 2) t += row[c2] + row[c3];
+                    sacc[u] = t;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+                    if (k0 + u * KS < r) big[i * ht_ld + k0 + u * KS] = sacc[u] * w;
             }
-            big[i * ht_ld + k] = s * (float)b.weight;
         }
     } else {
         // PFF[a][b] = P[F_a][F_b]   (f x f)
-        for (int idx = tid; idx < f * f; idx += kPrepThreads) {
-            const int a = idx / f, b = idx - a * f;
-            const int ca = (h.yu + a / h.w) * v.W + h.xl + a % h.w;
-            const int cb = (h.yu + b / h.w) * v.W + h.xl + b % h.w;
-            big[a * (FC + 1) + b] = cov_env[(size_t)ca * v.Npad + cb];
-        }
+        for (int a = tid / 32; a < f; a += kPrepThreads / 32)
+            for (int b = tid & 31; b < f; b += 32) big[a * (FC + 1) + b] = cov_env[(size_t)cellidx[a] * v.Npad + cellidx[b]];
     }
     __syncthreads();
 
     // ------------------------------------------------------------------ S = H P_FF H^T + R  (mappings.py:182-183)
-    const int npairs = m * (m + 1) / 2;
-    for (int p = wave; p < npairs; p += NW) {
-        int j = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-        while (j * (j + 1) / 2 > p) --j;
-        while ((j + 1) * (j + 2) / 2 <= p) ++j;
-        const int i = p - j * (j + 1) / 2;  // i <= j
-        const Block bi = block_of(i, h.nx, h.rf, h.w, h.h), bj = block_of(j, h.nx, h.rf, h.w, h.h);
-        double acc = 0.0;
-        if (lane < bi.count() * bj.count()) {
-            const int a = lane / bj.count(), b = lane - a * bj.count();
-            const int lya = bi.y0 + a / bi.bw, lxa = bi.x0 + a % bi.bw;
-            const int lyb = bj.y0 + b / bj.bw, lxb = bj.x0 + b % bj.bw;
-            if (MODE == IPP_FACTOR)
-                acc = bi.weight * bj.weight * matern_d(lya - lyb, lxa - lxb, v.res, sv, ls);
-            else
-                acc = bi.weight * bj.weight * (double)big[(lya * h.w + lxa) * (FC + 1) + lyb * h.w + lxb];
-        }
-        if (MODE == IPP_FACTOR) {
-            const float* hi = big + i * ht_ld;
-            const float* hj = big + j * ht_ld;
-            for (int k = lane; k < r; k += kWave) acc -= (double)hi[k] * (double)hj[k];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            if (i == j) acc += R;
-            S[i * LD + j] = acc;
-            S[j * LD + i] = acc;
+    // one 8-lane group per (i <= j) pair: prior / P_FF part over the <= rf^4 cell combinations, factor part
+    // -sum_k HT[i][k] HT[j][k] split over the 8 lanes, fp64 accumulation, 3 shuffle steps to reduce.
+    {
+        constexpr int GL = 8;
+        const int grp = tid / GL, sl = tid & (GL - 1), n_grp = kPrepThreads / GL;
+        const int npairs = m * (m + 1) / 2;
+        for (int p0 = 0; p0 < npairs; p0 += n_grp) {
+            const int p = p0 + grp;
+            const bool on = p < npairs;
+            int i = 0, j = 0;
+            if (on) {
+                j = (int)((sqrtf(8.0f * p + 1.0f) - 1.0f) * 0.5f);
+                while (j * (j + 1) / 2 > p) --j;
+                while ((j + 1) * (j + 2) / 2 <= p) ++j;
+                i = p - j * (j + 1) / 2;  // i <= j
+            }
+            double acc = 0.0;
+            if (on) {
+                const int ci = bcnt[i], cj = bcnt[j];        // 1, 2 or 4
+                const int sh = (cj == 4) ? 2 : (cj == 2 ? 1 : 0);
+                const double wij = bwt[i] * bwt[j];
+                for (int c = sl; c < ci * cj; c += GL) {
+                    const int fa = bfi[4 * i + (c >> sh)], fb = bfi[4 * j + (c & (cj - 1))];
+                    if (MODE == IPP_FACTOR) {
+                        const int lya = fa / h.w, lxa = fa - lya * h.w, lyb = fb / h.w, lxb = fb - lyb * h.w;
+                        acc += wij * ktab[abs(lya - lyb) * h.w + abs(lxa - lxb)];
+                    } else {
+                        acc += wij * (double)big[fa * (FC + 1) + fb];
+                    }
+                }
+                if (MODE == IPP_FACTOR) {
+                    const float* hi = big + i * ht_ld;
+                    const float* hj = big + j * ht_ld;
+                    for (int k = sl; k < r; k += GL) acc -= (double)hi[k] * (double)hj[k];
+                }
+            }
+#pragma unroll
+            for (int off = GL / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, GL);
+            if (on && sl == 0) {
+                if (i == j) acc += R;
+                S[i * LD + j] = acc;
+                S[j * LD + i] = acc;
+            }
         }
     }
     __syncthreads();
@@ -350,36 +400,46 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(View v, const int* __r
         const int i = idx / MC, j = idx - i * MC;
         const double val = (!dead && i < m && j < m) ? Li[i * LD + j] : 0.0;
         linv_out[idx] = (float)val;
+        blk_out[idx] = (float)val;
         dbg[MC * MC + idx] = val;
         dbg[idx] = (i < m && j < m) ? S[i * LD + j] : 0.0;
     }
     for (int i = tid; i < MC; i += kPrepThreads) {
         const double yval = (!dead && !cov_only && i < m) ? yy[i] : 0.0;
         y_out[i] = (float)yval;
+        blk_out[MC * MC + i] = (float)yval;
         dbg[2 * MC * MC + i] = (i < m) ? zz[i] : 0.0;
         dbg[2 * MC * MC + MC + i] = yval;
     }
-    const int QS = v.q_stride;
+    constexpr int QS = (MC + 3) & ~3;
+    constexpr int QP = (QS <= 16) ? 16 : 32;
     if (MODE == IPP_FACTOR) {
-        // Q[k][j] = sum_{i<=j} HT[i][k] L_inv[i][j]:  U Q = U U[F,:]^T H_F^T L^-1
-        for (int idx = tid; idx < r * QS; idx += kPrepThreads) {
-            const int k = idx / QS, j = idx - k * QS;
-            double s = 0.0;
-            if (!dead && j < m)
-                for (int i = 0; i <= j; ++i) s += (double)big[i * ht_ld + k] * Li[i * LD + j];
-            q_out[idx] = (float)(-s);  // stored negated: the stream accumulates acc += row * Q
+        // Q[k][j] = -sum_{i<=j} HT[i][k] L_inv[i][j]:  Wc = P0[:,F] G - U (U[F,:]^T G), sign folded into Q
+        const int j = tid & (QP - 1);
+        if (j < QS) {
+            for (int k = tid / QP; k < r; k += kPrepThreads / QP) {
+                double sacc = 0.0;
+                if (!dead && j < m)
+                    for (int i = 0; i <= j; ++i) sacc += (double)big[i * ht_ld + k] * Li[i * LD + j];
+                q_out[k * QS + j] = (float)(-sacc);
+            }
         }
     } else {
         // Q[fi][j] = w_f L_inv[blk(f)][j]  (normal)   or  w_f [blk(f) == j]  (fallback: stream PH^T)
-        for (int idx = tid; idx < f * QS; idx += kPrepThreads) {
-            const int fi = idx / QS, j = idx - fi * QS;
-            const int ly = fi / h.w, lx = fi - ly * h.w;
-            const int bi = (ly / h.rf) * h.nx + lx / h.rf;
-            const Block b = block_of(bi, h.nx, h.rf, h.w, h.h);
-            double s = 0.0;
-            if (j < m) s = fallback ? ((bi == j) ? b.weight : 0.0) : b.weight * Li[bi * LD + j];
-            q_out[idx] = (float)s;
+        const int j = tid & (QP - 1);
+        if (j < QS) {
+            for (int fi = tid / QP; fi < f; fi += kPrepThreads / QP) {
+                const int ly = fi / h.w, lx = fi - ly * h.w;
+                const int bi = (ly / h.rf) * h.nx + lx / h.rf;
+                double sacc = 0.0;
+                if (j < m) sacc = fallback ? ((bi == j) ? bwt[bi] : 0.0) : bwt[bi] * Li[bi * LD + j];
+                q_out[fi * QS + j] = (float)sacc;
+            }
         }
+    }
+    {   // the gain kernel's LDS-DMA copies whole rows past the end: keep the 8 rows after Q zero
+        const int qrows = (MODE == IPP_FACTOR) ? r : f;
+        for (int idx = tid; idx < 8 * QS; idx += kPrepThreads) q_out[(size_t)qrows * QS + idx] = 0.f;
     }
     if (tid == 0) {
         ItemHdr ho = h;

@@ -156,6 +156,18 @@ class IPPEngine:
         _ffi.check(self._lib.ipp_reset(self._h, self._ptr(ids), n, self._ptr(ps), self._ptr(g), self._ptr(w), self.stream))
         self._keep = (ids, ps, g, w)
 
+    def generate_grf(self, white_noise, out=None, stream=None):
+        """white noise [n, N] -> normalised GRF [n, N] in a caller tensor (no env slot touched)."""
+        torch = _torch()
+        w = self._dev(white_noise, torch.float32).reshape(-1, self.n_cells)
+        n = w.shape[0]
+        if out is None:
+            out = torch.empty((n, self.n_cells), dtype=torch.float32, device=self.device)
+        st = self.stream if stream is None else C.c_void_p(stream.cuda_stream)
+        _ffi.check(self._lib.ipp_generate_grf(self._h, n, self._ptr(w), self._ptr(out), st))
+        self._keep_grf = w
+        return out
+
     def step(self, actions, prev_actions, env_ids=None, dst_ids=None, meas_noise=None, *, cov_only=False,
              predict_only=False, adaptive=True, use_flight_time=True, given_observation=False, reward_out=None,
              status_out=None):

@@ -83,6 +83,17 @@ class VecIPPEnv:
                 torch.nonzero(self.phase == p).flatten().to(torch.int32) for p in range(self.episode_steps)
             ]
         self._white = torch.empty((B, cfg.n_cells), dtype=torch.float32, device=dev)
+        # staggered runs prepare the next reset's ground truths on a side stream while the step kernels run
+        # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip)
+        self._side = torch.cuda.Stream(device=dev) if stagger else None
+        if stagger:
+            n_max = max(int(i.numel()) for i in self._reset_ids_by_phase)
+            self._staged = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._staged_white = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._staged_ready = [torch.cuda.Event() for _ in range(2)]
+            self._staged_free = [torch.cuda.Event() for _ in range(2)]
+            for ev in self._staged_free:
+                ev.record(torch.cuda.current_stream(dev))
         self._noise = torch.empty((B, self.engine.meas_cap), dtype=torch.float32, device=dev)
         self.reward = torch.empty(B, dtype=torch.float32, device=dev)
         self.status = torch.empty(B, dtype=torch.int32, device=dev)
@@ -126,7 +137,7 @@ class VecIPPEnv:
         return (self.env_id_offset << 24) + self._reset_calls
 
     # ------------------------------------------------------------------ stepping
-    def step(self, actions, meas_noise=None, env_ids=None, auto_reset: bool = True):
+    def step(self, actions, meas_noise=None, env_ids=None, auto_reset: bool = True, after_step_hook=None):
         """
         actions: [B, 3] float64 (NumPy or device tensor).  Returns (reward, status) device tensors.
         With stagger=True and auto_reset, the envs whose episode ends after this step are reset on a fixed
@@ -134,6 +145,24 @@ class VecIPPEnv:
         """
         torch = self.torch
         a = self.engine._dev(actions, torch.float64).reshape(-1, 3)
+        main = torch.cuda.current_stream(self.device)
+        scheduled = None
+        if auto_reset and self._reset_ids_by_phase is not None:
+            # envs whose episode ends with this step: env e has done (t + 1 + phase_e) steps modulo T afterwards
+            p = (self.episode_steps - ((self.t + 1) % self.episode_steps)) % self.episode_steps
+            ids = self._reset_ids_by_phase[p]
+            if ids.numel() and self.shuffle_prior_cov is False:
+                k = self.t % 2
+                n = int(ids.numel())
+                self._side.wait_event(self._staged_free[k])
+                with torch.cuda.stream(self._side):
+                    white = self._staged_white[k][:n]
+                    self.engine.normal(n * self.cfg.n_cells, self.seed, self._subseq_for_reset(), out=white)
+                    self.engine.generate_grf(white, out=self._staged[k][:n])
+                    self._staged_ready[k].record(self._side)
+                scheduled = (ids, k, n)
+            elif ids.numel():
+                scheduled = (ids, None, int(ids.numel()))
         if meas_noise is None:
             nz = self._noise
             self._step_calls = getattr(self, "_step_calls", 0) + 1
@@ -147,12 +176,16 @@ class VecIPPEnv:
         else:
             self.prev[torch.as_tensor(env_ids, device=self.device).long()] = a
         self.t += 1
-        if auto_reset and self._reset_ids_by_phase is not None:
-            # env e has completed (t + phase_e) steps of its current episode modulo T
-            p = (self.episode_steps - (self.t % self.episode_steps)) % self.episode_steps
-            ids = self._reset_ids_by_phase[p]
-            if ids.numel():
+        if after_step_hook is not None:
+            after_step_hook()
+        if scheduled is not None:
+            ids, k, n = scheduled
+            if k is None:
                 self.reset(ids)
+            else:
+                main.wait_event(self._staged_ready[k])
+                self.reset(ids, gt=self._staged[k][:n])
+                self._staged_free[k].record(main)
         return self.reward, self.status
 
     # ------------------------------------------------------------------ views

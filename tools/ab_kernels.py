@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""
+Interleaved A/B timing of engine builds (different libipp_*.so variants) inside ONE process: every variant gets
+its own engine with identical state and inputs (staggered 40-step episodes, cfg2 workload) and the variants take
+turns step by step, so clock / thermal drift hits all of them equally.  Reports the median kernel times from the
+engines' own HIP-event profiling and the median wall time per step.
+
+usage: python tools/ab_kernels.py [--envs 4096] [--rounds 60] name=path/to/lib.so[:tile_threads] ...
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ipp_rl_amd import _ffi, EngineConfig  # noqa: E402
+from ipp_rl_amd.engine import IPPEngine  # noqa: E402
+from ipp_rl_amd.vec_env import cell_centre_actions  # noqa: E402
+
+
+def make_engine(lib_path, cfg, B, tile_threads):
+    _ffi._lib = None
+    _ffi.LIB_PATH = lib_path
+    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, tile_threads=tile_threads)
+    return eng
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=60)
+    ap.add_argument("variants", nargs="+")
+    args = ap.parse_args()
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B, T = args.envs, 40
+    alts = [float(a) for a in range(5, 15)]
+    n_steps = T + args.rounds
+    acts = torch.stack([torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, alts)) for t in range(n_steps)]).cuda()
+    init = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+    phase = torch.arange(B, device="cuda") % T
+    ids_by_phase = [torch.nonzero(phase == p).flatten().to(torch.int32) for p in range(T)]
+    gt = torch.rand((B, cfg.n_cells), device="cuda")
+    noise = torch.randn((n_steps, B, 9), device="cuda")
+    engines = []
+    for spec in args.variants:
+        name, rest = spec.split("=")
+        path, _, tt = rest.partition(":")
+        eng = make_engine(os.path.abspath(path), cfg, B, int(tt or 0))
+        eng.reset(gt=gt)
+        engines.append((name, eng, init.clone()))
+    reward = torch.empty(B, dtype=torch.float32, device="cuda")
+    status = torch.empty(B, dtype=torch.int32, device="cuda")
+    flags = _ffi.IPP_ADAPTIVE | _ffi.IPP_USE_FLIGHT_TIME
+    wall = {n: [] for n, _, _ in engines}
+
+    def one(eng, prev, t, timed_name=None):
+        if timed_name:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        eng.step_raw(B, acts[t], prev, noise[t], flags, reward, status)
+        if timed_name:
+            torch.cuda.synchronize()
+            wall[timed_name].append(time.perf_counter() - t0)
+        prev.copy_(acts[t])
+        p = (T - ((t + 1) % T)) % T
+        ids = ids_by_phase[p]
+        eng.reset(env_ids=ids, gt=gt[: ids.numel()])
+        prev[ids.long()] = init[ids.long()]
+
+    for t in range(T):  # pre-roll to the stationary rank mix
+        for name, eng, prev in engines:
+            one(eng, prev, t)
+    for _, eng, _ in engines:
+        eng.profile(True)
+    for r in range(args.rounds):
+        order = engines if r % 2 == 0 else engines[::-1]
+        for name, eng, prev in order:
+            one(eng, prev, T + r, timed_name=name)
+    torch.cuda.synchronize()
+    base = None
+    for name, eng, _ in engines:
+        g_ms, g_n = eng.profile_read(0)
+        p_ms, _ = eng.profile_read(2)
+        w = 1e3 * float(np.median(wall[name]))
+        ranks = eng.ranks().double().mean().item()
+        base = base or g_ms
+        print(f"{name:14s} T={eng.info.tile_threads:3d} gain {g_ms:.4f} ms ({g_ms / base:5.3f}x)  prepare {p_ms:.4f} ms  "
+              f"step wall median {w:.4f} ms  mean rank {ranks:.1f}")
+
+
+if __name__ == "__main__":
+    main()
