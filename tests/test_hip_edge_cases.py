@@ -1,0 +1,275 @@
+"""
+GPU edge cases and size-independent properties of the HIP step engine (through the C-ABI):
+border / clipped footprints, every altitude level 4..30 m (m up to 25 -> the second compiled instantiation),
+non-square grids, status codes, out-of-place steps, forks, predict-only scoring, full-size (cfg2) invariants and
+sharding equivalence.  Oracle = oracle/ipp_oracle.py (fp64, pinned against the reference's golden vectors).
+"""
+import numpy as np
+import pytest
+
+from oracle import ipp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def make(dim_x, dim_y=None, state="factor", capacity=2, res=4.0, **kw):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    dim_y = dim_y or dim_x
+    cfg = EngineConfig(x_dim=dim_x, y_dim=dim_y, resolution=res, **kw.pop("cfg", {}))
+    eng = IPPEngine(cfg, capacity=capacity, state=state, rank_cap=kw.pop("rank_cap", 512), **kw)
+    ocfg = orc.OracleConfig(x_dim=dim_x, y_dim=dim_y, resolution=res, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b)
+    return eng, ocfg
+
+
+@pytest.mark.parametrize("state", ["dense", "factor"])
+def test_all_altitudes_and_borders_m_up_to_25(state):
+    """alt 4..30 at res 4 (footprints 1x1 .. 9x9, rf 1 and 2, m <= 25) incl. corners / edges / pos == W*res."""
+    dim = 24
+    eng, ocfg = make(dim, state=state, max_measurements=25)
+    assert eng.meas_cap == 25
+    rs = np.random.RandomState(5)
+    gt = rs.uniform(size=(dim, dim))
+    eng.reset(env_ids=[0], gt=gt[None])
+    st = orc.EnvState(mean=0.5 * np.ones((dim, dim)), P=orc.matern_prior(ocfg), gt=gt)
+    W = dim * 4.0
+    spots = [(2.0, 2.0), (W - 2, W - 2), (2.0, W - 2), (W, W), (0.0, 50.0), (50.0, 0.0), (W / 2, W / 2), (33.3, 71.9)]
+    prev = np.array([2.0, 2.0, 14.0])
+    for t, alt in enumerate(range(4, 31)):
+        x, y = spots[t % len(spots)]
+        a = np.array([x, y, float(alt)])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
+        eps = rs.normal(size=25)
+        reward, status = eng.step(a[None], prev[None], env_ids=[0], meas_noise=eps[None])
+        it = eng.debug_item(0)
+        out = orc.env_step(ocfg, st, a, eps[:m])
+        assert int(status[0]) == 0 and it["m"] == m and it["fov"] == orc.project_fov(ocfg, a)
+        assert abs(float(reward[0]) - out["reward"]) < TOL
+        assert np.max(np.abs(it["z"] - out["z"].ravel())) < 1e-6
+        prev = a
+    assert np.max(np.abs(host(eng.read_mean(0)) - st.mean)) < TOL
+    assert np.max(np.abs(host(eng.read_cov(0)) - st.P)) < TOL
+
+
+@pytest.mark.parametrize("state", ["dense", "factor"])
+def test_resolution_one_rf1_5x5(state):
+    """res = 1 m/cell: a 5x5 footprint at rf = 1 gives m = 25 (res in {1, 4})."""
+    dim = 16
+    eng, ocfg = make(dim, state=state, res=1.0, max_measurements=25)
+    rs = np.random.RandomState(9)
+    gt = rs.uniform(size=(dim, dim))
+    eng.reset(env_ids=[0], gt=gt[None])
+    st = orc.EnvState(mean=0.5 * np.ones((dim, dim)), P=orc.matern_prior(ocfg), gt=gt, prev=np.array([0.5, 0.5, 5.0]))
+    prev = st.prev.copy()
+    for alt, (x, y) in [(5.0, (8.5, 8.5)), (5.0, (0.5, 15.5)), (4.0, (3.5, 9.5)), (3.0, (12.5, 2.5))]:
+        a = np.array([x, y, alt])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), 1)
+        eps = rs.normal(size=25)
+        reward, status = eng.step(a[None], prev[None], env_ids=[0], meas_noise=eps[None])
+        out = orc.env_step(ocfg, st, a, eps[:m])
+        assert int(status[0]) == 0 and abs(float(reward[0]) - out["reward"]) < TOL
+        prev = a
+    assert np.max(np.abs(host(eng.read_cov(0)) - st.P)) < TOL and np.max(np.abs(host(eng.read_mean(0)) - st.mean)) < TOL
+
+
+@pytest.mark.parametrize("state", ["dense", "factor"])
+def test_non_square_grid(state):
+    """flat index = x_dim * row + col on a 12 x 10 grid (ground truth supplied: the reference's GRF is square-only)."""
+    eng, ocfg = make(10, 12, state=state)
+    rs = np.random.RandomState(2)
+    gt = rs.uniform(size=(12, 10))
+    eng.reset(env_ids=[0], gt=gt[None])
+    st = orc.EnvState(mean=0.5 * np.ones((12, 10)), P=orc.matern_prior(ocfg), gt=gt)
+    prev = np.array([2.0, 2.0, 14.0])
+    for _ in range(12):
+        a = np.array([4.0 * rs.randint(0, 10) + 2, 4.0 * rs.randint(0, 12) + 2, float(rs.randint(5, 15))])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
+        eps = rs.normal(size=9)
+        reward, _ = eng.step(a[None], prev[None], env_ids=[0], meas_noise=eps[None])
+        out = orc.env_step(ocfg, st, a, eps[:m])
+        assert abs(float(reward[0]) - out["reward"]) < TOL
+        prev = a
+    assert np.max(np.abs(host(eng.read_cov(0)) - st.P)) < TOL
+    assert np.max(np.abs(host(eng.read_mean(0)) - st.mean)) < TOL
+
+
+def test_status_codes():
+    from ipp_rl_amd import _ffi
+
+    # m > compiled cap (9): alt 25 m -> 7x7 rf 2 -> m = 16
+    eng, _ = make(20, state="factor")
+    eng.reset(env_ids=[0])
+    r, s = eng.step(np.array([[42.0, 42.0, 25.0]]), np.array([[2.0, 2.0, 14.0]]), env_ids=[0])
+    assert int(s[0]) == _ffi.STATUS_BAD_FOOTPRINT and float(r[0]) == 0.0 and eng.rank(0) == 0
+    # non-finite position
+    r, s = eng.step(np.array([[np.nan, 42.0, 8.0]]), np.array([[2.0, 2.0, 14.0]]), env_ids=[0])
+    assert int(s[0]) == _ffi.STATUS_BAD_FOOTPRINT
+    # rank cap: 2 steps of m = 9 fit into rank_cap 20, the third does not: reward still valid, state untouched
+    eng, ocfg = make(20, state="factor", rank_cap=20)
+    eng.reset(env_ids=[0])
+    prev = np.array([[2.0, 2.0, 14.0]])
+    for k, a in enumerate([[42.0, 42.0, 8.0], [10.0, 50.0, 9.0], [62.0, 22.0, 8.0]]):
+        a = np.array([a])
+        before = host(eng.read_diag(0))
+        r, s = eng.step(a, prev, env_ids=[0], cov_only=True)
+        if k < 2:
+            assert int(s[0]) == 0
+        else:
+            assert int(s[0]) == _ffi.STATUS_RANK_FULL and eng.rank(0) == 18 and float(r[0]) > 0
+            assert np.array_equal(host(eng.read_diag(0)), before)
+        prev = a
+
+
+def test_not_positive_definite_paths():
+    """Negative sensor noise makes S indefinite: dense takes the reference's inverse fallback (mappings.py:200-215),
+    the factor form refuses the step."""
+    from ipp_rl_amd import _ffi
+
+    neg = {"coeff_a": -3.0}
+    dense, ocfg = make(8, state="dense", cfg=neg)
+    factor, _ = make(8, state="factor", cfg=neg)
+    ocfg.coeff_a = -3.0
+    gt = np.linspace(0, 1, 64).reshape(8, 8)
+    a, prev = np.array([[14.0, 14.0, 8.0]]), np.array([[2.0, 2.0, 14.0]])
+    z = np.full((1, 9), 0.6)
+    for eng in (dense, factor):
+        eng.reset(env_ids=[0], gt=gt[None])
+    r, s = dense.step(a, prev, env_ids=[0], meas_noise=z, adaptive=False, given_observation=True)
+    assert int(s[0]) == _ffi.STATUS_CHOL_FALLBACK
+    P0 = orc.matern_prior(ocfg)
+    x, Pn, terms = orc.update_grid_map(ocfg, P0, 0.5 * np.ones((8, 8)), a[0], z[0])
+    assert terms.used_fallback
+    assert np.max(np.abs(host(dense.read_cov(0)) - Pn)) < 1e-4 * max(1.0, np.abs(Pn).max())
+    assert np.max(np.abs(host(dense.read_mean(0)) - x)) < 1e-4 * max(1.0, np.abs(x).max())
+    r, s = factor.step(a, prev, env_ids=[0], meas_noise=z, adaptive=False, given_observation=True)
+    assert int(s[0]) == _ffi.STATUS_NOT_PD and np.isnan(float(r[0])) and factor.rank(0) == 0
+
+
+@pytest.mark.parametrize("state", ["dense", "factor"])
+def test_out_of_place_fork_and_predict_only(state):
+    dim = 14
+    eng, ocfg = make(dim, state=state, capacity=6)
+    rs = np.random.RandomState(3)
+    eng.reset(white_noise=rs.normal(size=(6, dim, dim)))
+    prev = np.tile([2.0, 2.0, 14.0], (6, 1))
+    acts = np.stack([4.0 * rs.randint(0, dim, 6) + 2, 4.0 * rs.randint(0, dim, 6) + 2, rs.randint(5, 15, 6) * 1.0], 1)
+    eng.step(acts, prev, meas_noise=rs.normal(size=(6, 9)))
+    P0, m0, d0 = host(eng.read_cov(0)), host(eng.read_mean(0)), host(eng.read_diag(0))
+    # predict-only scoring of 40 candidates from slot 0 (env id repeated): nothing may change, bit for bit
+    cands = np.stack([4.0 * rs.randint(0, dim, 40) + 2, 4.0 * rs.randint(0, dim, 40) + 2, rs.randint(5, 15, 40) * 1.0], 1)
+    eng2 = None
+    r_pred, s_pred = eng.step(cands[:6], np.tile(acts[0], (6, 1)), env_ids=np.zeros(6, np.int32), predict_only=True,
+                              cov_only=True)
+    assert np.array_equal(host(eng.read_cov(0)), P0) and np.array_equal(host(eng.read_diag(0)), d0)
+    # out-of-place: slot 0 -> slot 4 with the first candidate; source untouched, destination == in-place result on a fork
+    eng.fork([0], [5])
+    a = cands[:1]
+    r_oop, _ = eng.step(a, acts[:1], env_ids=[0], dst_ids=[4], cov_only=True)
+    r_inp, _ = eng.step(a, acts[:1], env_ids=[5], cov_only=True)
+    assert np.array_equal(host(eng.read_cov(0)), P0) and np.array_equal(host(eng.read_mean(0)), m0)
+    assert abs(float(r_oop[0]) - float(r_pred[0])) < 1e-6 and abs(float(r_oop[0]) - float(r_inp[0])) < 1e-6
+    assert np.max(np.abs(host(eng.read_cov(4)) - host(eng.read_cov(5)))) < 1e-6
+    assert np.array_equal(host(eng.read_gt(4)), host(eng.read_gt(0)))
+    if state == "factor":
+        assert eng.rank(4) == eng.rank(0) + eng.debug_item(0)["m"]
+    del eng2
+
+
+def test_fullsize_invariants_and_sharding_equivalence():
+    """cfg2 size (4096 envs, 50x50, factor state): trace monotone, reward >= 0, cached diag == diag(P0 - U U^T) on
+    sampled envs, and a 2-way shard (2 engines x 2048 envs) reproduces every env's result bit for bit."""
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import cell_centre_actions
+    import torch
+
+    B, dim, steps = 4096, 50, 6
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    alts = [float(a) for a in range(5, 15)]
+    full, _ = make(dim, state="factor", capacity=B, rank_cap=64)
+    halves = [make(dim, state="factor", capacity=B // 2, rank_cap=64)[0] for _ in range(2)]
+    white = full.normal(B * dim * dim, seed=7).reshape(B, -1)
+    full.reset(white_noise=white)
+    for h, eng in enumerate(halves):
+        eng.reset(white_noise=white[h * B // 2:(h + 1) * B // 2])
+    prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+    trace_before = full.read_diag(0).sum() * 0 + torch.stack([full.read_diag(e).sum() for e in (0, 1, 2047, 2048, 4095)])
+    for t in range(steps):
+        acts = torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, alts), device="cuda")
+        eps = full.normal(B * 9, seed=100 + t).reshape(B, 9)
+        r_full, s_full = full.step(acts, prev, meas_noise=eps)
+        r_full = r_full.clone()
+        assert int(s_full.abs().sum()) == 0 and bool((r_full >= 0).all())
+        for h, eng in enumerate(halves):
+            sl = slice(h * B // 2, (h + 1) * B // 2)
+            r_h, _ = eng.step(acts[sl], prev[sl], meas_noise=eps[sl])
+            assert torch.equal(r_h, r_full[sl])  # bit-identical regardless of how envs are sharded
+        prev = acts
+    for e in (0, 1, 2047, 2048, 4095):
+        h, le = divmod(e, B // 2)
+        assert torch.equal(full.read_mean(e), halves[h].read_mean(le))
+        assert torch.equal(full.read_diag(e), halves[h].read_diag(le))
+    trace_after = torch.stack([full.read_diag(e).sum() for e in (0, 1, 2047, 2048, 4095)])
+    assert bool((trace_after < trace_before).all())
+    P = host(full.read_cov(4095))
+    assert np.max(np.abs(np.diag(P) - host(full.read_diag(4095)))) < TOL
+    assert np.max(np.abs(P - P.T)) < 1e-6 and np.linalg.eigvalsh(P).min() > -1e-4
+
+
+def test_vec_env_staged_ground_truth_matches_direct_reset():
+    """VecIPPEnv's side-stream GRF staging (ipp_generate_grf -> ipp_reset(gt)) equals the direct white-noise reset."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    dim, B = 20, 8
+    eng = IPPEngine(EngineConfig(x_dim=dim, y_dim=dim), capacity=B, state="factor", rank_cap=32)
+    white = eng.normal(B * dim * dim, seed=11, subsequence=3).reshape(B, -1)
+    eng.reset(white_noise=white)
+    direct = [eng.read_gt(e).clone() for e in range(B)]
+    staged = eng.generate_grf(white)
+    eng.reset(gt=staged)
+    for e in range(B):
+        assert np.array_equal(host(eng.read_gt(e)), host(direct[e]))
+    gt = host(direct[0])
+    assert gt.min() == 0.0 and abs(gt.max() - 1.0) < 1e-6
+    ref = orc.grf_from_white_noise(host(white[0]).reshape(dim, dim), 5.0)
+    assert np.max(np.abs(gt - ref)) < TOL
+
+
+def test_philox_normals_deterministic_and_standard():
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    eng = IPPEngine(EngineConfig(x_dim=10, y_dim=10), capacity=2, state="factor", rank_cap=16)
+    a = host(eng.normal(1 << 20, seed=5, subsequence=2))
+    b = host(eng.normal(1 << 20, seed=5, subsequence=2))
+    c = host(eng.normal(1 << 20, seed=5, subsequence=3))
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert abs(a.mean()) < 5e-3 and abs(a.std() - 1.0) < 5e-3 and abs(((a - a.mean()) ** 4).mean() - 3.0) < 0.05
+    assert np.array_equal(host(eng.normal(1000, seed=5, subsequence=2)), a[:1000])  # depends on (seed, subseq, i) only
+
+
+def test_metrics_kernel_vs_oracle():
+    dim = 20
+    eng, ocfg = make(dim, state="factor")
+    rs = np.random.RandomState(8)
+    white = rs.normal(size=(1, dim, dim))
+    eng.reset(env_ids=[0], white_noise=white)
+    st = orc.env_reset(ocfg, white[0])
+    prev = np.array([2.0, 2.0, 14.0])
+    for _ in range(10):
+        a = np.array([4.0 * rs.randint(0, dim) + 2, 4.0 * rs.randint(0, dim) + 2, float(rs.randint(5, 15))])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
+        eps = rs.normal(size=9)
+        eng.step(a[None], prev[None], env_ids=[0], meas_noise=eps[None])
+        orc.env_step(ocfg, st, a, eps[:m])
+        prev = a
+    gt, est, diag = st.gt, st.mean, np.diag(st.P)
+    msk = gt.ravel() >= 0.4
+    want = np.array([orc.metric_rmse(gt, est), orc.metric_rmse(gt, est, msk), orc.metric_wrmse(gt, est),
+                     orc.metric_mll(gt, est, diag), orc.metric_wmll(gt, est, diag), orc.metric_uncertainty(diag),
+                     orc.metric_uncertainty(diag, msk), orc.metric_uncertainty_difference(diag, msk)])
+    got = host(eng.metrics(env_ids=[0]))[0]
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-4
