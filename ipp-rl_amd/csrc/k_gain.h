@@ -23,6 +23,12 @@ namespace ipp {
 #ifndef IPP_MINWAVES
 #define IPP_MINWAVES 4
 #endif
+#ifndef IPP_ABLATE
+#define IPP_ABLATE 0  // timing experiments only: 8 = no U row appends
+#endif
+#ifndef IPP_NT_STORES
+#define IPP_NT_STORES 1  // appended rows: -2 % kernel time (A/B on MI355X)
+#endif
 #ifndef IPP_NT_LOADS
 #define IPP_NT_LOADS 1  // +6..10 % on MI355X: rows are streamed once, Q / headers stay in L2
 #endif
@@ -59,6 +65,19 @@ __device__ __forceinline__ void load_stream(const float* p, float (&o)[VEC]) {
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&o)[VEC]) {
     *reinterpret_cast<typename VecIO<VEC>::T*>(p) = VecIO<VEC>::pack(o);
+}
+// appended rows are not read again before the next step's kernels: optional non-temporal hint
+template <int VEC>
+__device__ __forceinline__ void store_stream(float* p, const float (&o)[VEC]) {
+#if IPP_NT_STORES
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    vec_t t;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) t[c] = o[c];
+    __builtin_nontemporal_store(t, reinterpret_cast<vec_t*>(p));
+#else
+    store_vec<VEC>(p, o);
+#endif
 }
 
 // acc[c][j] += sum_k row_k[cell0 + c] * Q[k][j] over the `cnt` rows whose Q is staged in Qs (the prologue
@@ -276,10 +295,10 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
         // append the m new columns (rows of the [k][cell] layout): coalesced row writes
 #pragma unroll
         for (int j = 0; j < MC; ++j)
-            if (j < m) {
+            if (j < m && !((IPP_ABLATE & 8) && acc[0][0] != 12345.f)) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
-                store_vec<VEC>(cov_dst + (size_t)(h.rank + j) * v.Npad + cell0, outv);
+                store_stream<VEC>(cov_dst + (size_t)(h.rank + j) * v.Npad + cell0, outv);
             }
         if (tile == 0 && tid == 0) v.rank[h.dst] = h.rank + m;
     } else {
