@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--state", choices=["factor", "dense"], default="factor")
     ap.add_argument("--episode-steps", type=int, default=40)
     ap.add_argument("--tile-threads", type=int, default=0)
+    ap.add_argument("--window-rows", type=int, default=12,
+                    help="factor state: keep new columns of U within R grid rows of the footprint (truncated |Wc| < 3e-8 for "
+                         "the example prior, parity-tested at 1e-5); 0 = exact full columns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=40)
@@ -103,7 +106,7 @@ def main():
     total_envs = B * world
     lo, hi = rank * B, (rank + 1) * B  # contiguous env-id range per GPU, no exchange between shards
     env = VecIPPEnv(cfg, B, state=args.state, episode_steps=T, device=device, seed=1234, env_id_offset=lo,
-                    stagger=True, tile_threads=args.tile_threads)
+                    stagger=True, tile_threads=args.tile_threads, window_rows=args.window_rows)
     eng = env.engine
     n_total = T + args.warmup + 2 * args.steps
     # synthetic inputs resident in HBM before the timed region
@@ -150,6 +153,7 @@ def main():
 
     # ---- roofline leg: same steps again with HIP events around the streaming kernel (rank 0 reports)
     eng.profile(True)
+    eng.streamed_bytes(reset=True)
     rank_sum = torch.zeros((), dtype=torch.float64, device=device)
     ranks_buf = torch.empty(B, dtype=torch.int32, device=device)
     for _ in range(args.steps):
@@ -162,6 +166,7 @@ def main():
             env.step(actions[t_idx], after_step_hook=lambda: rank_sum.add_(eng.ranks(ranks_buf).double().sum()))
             t_idx += 1
     torch.cuda.synchronize()
+    counted_bytes = eng.streamed_bytes(reset=True) / args.steps  # device counter: rows x valid cells actually streamed
     gain_ms, gain_n = eng.profile_read(0)
     down_ms, down_n = eng.profile_read(1)
     prep_ms, prep_n = eng.profile_read(2)
@@ -175,7 +180,8 @@ def main():
     else:
         per_step = (4.0 * N * 25 + 8.0 * N) if args.predict_only else (8.0 * N * N + 16.0 * N)
         kernel_ms, kernel_name = (gain_ms, "k_gain") if args.predict_only else (down_ms, "k_downdate")
-    bytes_per_launch = per_step * B
+    formula_bytes = per_step * B  # SURVEY 8(d) formula with full columns
+    bytes_per_launch = counted_bytes if (args.state == "factor" and not args.predict_only) else formula_bytes
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     if rank == 0:
@@ -198,7 +204,7 @@ def main():
                             f"flight-time cost; {'predict-only (reward) calls' if args.predict_only else 'full fused env step (predict + observe + update)'}",
                 "envs_per_gpu": B, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,
                 "episode_steps": T, "episode_phase": "staggered (stationary rank mix)",
-                "mean_rank_after_step": mean_rank_after, "tile_threads": int(eng.info.tile_threads),
+                "mean_rank_after_step": mean_rank_after, "tile_threads": int(eng.info.tile_threads), "window_rows": int(eng.info.window_rows),
                 "items_with_nonzero_status": bad, "rng": "device Philox4x32-10",
             },
             "roofline": {
@@ -206,6 +212,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches": gain_n if kernel_name == "k_gain" else down_n,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "full_column_formula_bytes_per_launch": formula_bytes,
                 "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
             },
         }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 1
+#define IPP_ABI_VERSION 2
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -72,6 +72,10 @@ typedef struct ipp_config {
     int32_t max_batch;        /* largest n of one ipp_step / ipp_reset call */
     int32_t max_measurements; /* compile-time cap on m: 9 (default config) or 25 */
     int32_t tile_threads;     /* 0 = auto; threads per streaming workgroup (multiple of 64, <= 640) */
+    int32_t window_rows;      /* IPP_FACTOR: 0 = exact full columns; R > 0 = a new column of U is kept only on the
+                                 grid rows within R of its footprint (|Wc| < 3e-8 beyond 12 rows for the example
+                                 prior); streamed bytes shrink accordingly and are counted as such */
+    int32_t reserved0;
 } ipp_config;
 
 typedef struct ipp_info {
@@ -82,7 +86,7 @@ typedef struct ipp_info {
     int32_t n_tiles;      /* streaming workgroups per env */
     int32_t meas_cap;     /* compiled m cap in use (9 or 25) */
     int32_t fp_cap;       /* compiled footprint-cell cap in use (4 * meas_cap) */
-    int32_t reserved;
+    int32_t window_rows;
     uint64_t arena_bytes;     /* total bytes the engine carves from the caller's arena */
     uint64_t cov_slot_bytes;  /* bytes of covariance state per env slot */
 } ipp_info;
@@ -228,6 +232,10 @@ int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out /*[host]*/
  * kind: 0 = gain kernel, 1 = dense downdate kernel, 2 = prologue kernel.  Synchronises. */
 int ipp_profile_enable(void* engine, int32_t enable);
 int ipp_profile_read(void* engine, int32_t kind, double* avg_ms /*[host]*/, int64_t* launches /*[host]*/, int32_t reset);
+/* Bytes the gain kernel actually streamed / wrote since the last reset of the counter (rows x valid cells x 4 +
+ * per-cell mean / diag traffic), counted on the device per workgroup: the numerator of roofline.achieved when
+ * window_rows > 0.  Synchronises. */
+int ipp_streamed_bytes(void* engine, uint64_t* bytes /*[host]*/, int32_t reset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION = 1, 2, 4, 8, 16
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class IppConfig(C.Structure):
@@ -29,14 +29,14 @@ class IppConfig(C.Structure):
         ("value_threshold", C.c_double), ("interval_factor", C.c_double),
         ("cluster_radius", C.c_double),
         ("state_repr", C.c_int32), ("capacity", C.c_int32), ("rank_cap", C.c_int32), ("max_batch", C.c_int32),
-        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32),
+        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
 class IppInfo(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("n_cells", C.c_int32), ("n_pad", C.c_int32), ("tile_threads", C.c_int32),
-        ("n_tiles", C.c_int32), ("meas_cap", C.c_int32), ("fp_cap", C.c_int32), ("reserved", C.c_int32),
+        ("n_tiles", C.c_int32), ("meas_cap", C.c_int32), ("fp_cap", C.c_int32), ("window_rows", C.c_int32),
         ("arena_bytes", C.c_uint64), ("cov_slot_bytes", C.c_uint64),
     ]
 
@@ -82,6 +82,7 @@ PROTOTYPES = {
     "ipp_metrics": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "ipp_fill_normal": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "ipp_debug_step_item": (C.c_int, [_P, C.c_int32, C.POINTER(IppStepItem), _P]),
+    "ipp_streamed_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int32, _P]),
     "ipp_profile_enable": (C.c_int, [_P, C.c_int32]),
     "ipp_profile_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -23,7 +23,7 @@ struct ItemHdr {
     int xl, xr, yu, yd;
     int w, h, nx, ny;
     int rf, m, f, rows;      // rows = rank (factor) or f (dense): length of the streaming loop
-    int fallback, commit, pad0, pad1;
+    int fallback, commit, t_lo, t_hi;  // [t_lo, t_hi]: tiles that hold the column(s) this step appends
     float cost, sv, ls, nv;
     double cost_d, nv_d;
 };
@@ -32,6 +32,7 @@ struct ItemHdr {
 struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL
     int mode, cap, rank_cap, max_batch;
+    int window_rows, tile_cells;
     int meas_cap, fp_cap, q_stride, q_rows;
     uint64_t q_item;  // floats of Q scratch per item: (q_rows + 2*kPipe pad rows) * q_stride
     double res, tanx, tany, rf_alt, coeff_a, coeff_b, sv0, ls0, vmax, amax, thr, kf;
@@ -41,6 +42,8 @@ struct View {
     float* gt;       // [cap][Npad]
     double* prior;   // [cap][2]  (sigma^2, l)
     int* rank;       // [cap]
+    int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
+    unsigned long long* counters;  // [4] device counters (streamed cells x rows, ...)
     float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]
     uint64_t cov_slot;  // floats per env slot
     // per-call scratch

@@ -14,6 +14,7 @@
 
 #include "ipp_common.h"
 #include "k_gain.h"
+#include "k_gain_factor.h"
 #include "k_misc.h"
 #include "k_prepare.h"
 
@@ -69,7 +70,7 @@ struct Engine {
 
 struct Layout {
     int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
-    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
+    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
         off_partial, off_dbg, off_grfh, off_grfraw, off_grfraw2, total, cov_slot_floats;
 };
 
@@ -111,6 +112,14 @@ int plan(const ipp_config& c, Layout& L) {
     }
     L.n_tiles = (n4 + L.T - 1) / L.T;
     L.Npad = L.n_tiles * L.T * L.VEC;
+    if (c.state_repr == IPP_FACTOR && c.window_rows > 0) {
+        // windowed factor state: one workgroup per item, wave-granular tiles of 64 * VEC cells (k_gain_factor.h);
+        // tile_threads is the workgroup size (waves share the item's Q block and prior table in LDS)
+        L.T = (c.tile_threads > 0) ? c.tile_threads : 256;
+        if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
+        L.n_tiles = (n4 + 63) / 64;
+        L.Npad = L.n_tiles * 64 * L.VEC;
+    }
     L.q_rows = (c.state_repr == IPP_FACTOR) ? c.rank_cap : L.FC;
     L.cov_slot_floats = (c.state_repr == IPP_FACTOR) ? (uint64_t)c.rank_cap * L.Npad : (uint64_t)L.N * L.Npad;
     uint64_t o = 0;
@@ -120,6 +129,8 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_gt = o; o += up(cap * np * 4);
     L.off_prior = o; o += up(cap * 2 * 8);
     L.off_rank = o; o += up(cap * 4);
+    L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(cap * (uint64_t)c.rank_cap * 4) : 0;
+    L.off_cnt = o; o += up(64);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
     L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
@@ -225,7 +236,7 @@ void prof_drain(ProfSlot& p) {
 size_t gain_lds_bytes(const View& v, int q_chunk, int lut_cap) {
     const size_t MC = v.meas_cap, QS = v.q_stride;
     size_t b = std::max((size_t)(q_chunk + 2 * kPipe) * QS, (size_t)((lut_cap + 3) & ~3)) * 4 + ((MC * MC + 3) & ~(size_t)3) * 4 + ((MC + 3) & ~(size_t)3) * 4 + 16 * 8;
-    if (v.mode == IPP_DENSE) b += (size_t)q_chunk * 4;
+    b += (size_t)std::max(q_chunk, v.q_rows) * 4;  // rowidx: streaming index -> row of the covariance slab
     return (b + 15) & ~(size_t)15;
 }
 
@@ -248,12 +259,14 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
     {
         ProfScope ps(e, 0, s);
         const int grid = grid_for(n, v.n_tiles);
-        if (v.mode == IPP_FACTOR)
+        if (v.mode == IPP_FACTOR && v.window_rows > 0)
+            hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, n, flags, e->lut_cap, reward);
+        else if (v.mode == IPP_FACTOR)
             hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
         else
             hipLaunchKernelGGL((k_gain<MC, VEC, IPP_DENSE>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
     }
-    if (v.n_tiles > 1) hipLaunchKernelGGL(k_reward_finalize, dim3((n + 255) / 256), dim3(256), 0, s, v, n, reward);
+    if (v.n_tiles > 1 && !(v.mode == IPP_FACTOR && v.window_rows > 0)) hipLaunchKernelGGL(k_reward_finalize, dim3((n + 255) / 256), dim3(256), 0, s, v, n, reward);
     if (v.mode == IPP_DENSE && !(flags & IPP_PREDICT_ONLY)) {
         ProfScope ps(e, 1, s);
         const int grid = grid_for(n, e->n_bands * v.n_tiles);
@@ -374,6 +387,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.gt = reinterpret_cast<float*>(base + L.off_gt);
     v.prior = reinterpret_cast<double*>(base + L.off_prior);
     v.rank = reinterpret_cast<int*>(base + L.off_rank);
+    v.colspan = reinterpret_cast<int*>(base + L.off_span);
+    v.counters = reinterpret_cast<unsigned long long*>(base + L.off_cnt);
+    v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
+    v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;
     v.hdr = reinterpret_cast<ItemHdr*>(base + L.off_hdr);
@@ -393,6 +410,17 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     // prior table of the factor base term lives in LDS when the grid is small enough (<= 48 KiB)
     e->lut_cap = (v.mode == IPP_FACTOR && L.N <= 12288) ? L.N : 0;
     e->gain_lds = gain_lds_bytes(v, e->q_chunk, e->lut_cap);
+    if (v.mode == IPP_FACTOR && v.window_rows > 0) {
+        const size_t MCs = v.meas_cap, LQ = (MCs * MCs + MCs + 3) & ~(size_t)3;
+        e->gain_lds = (LQ + (size_t)(v.rank_cap + 8) * v.q_stride + ((e->lut_cap + 3) & ~3)) * 4 + 16 * 8 +
+                      (size_t)v.rank_cap * 4 + (size_t)(v.T / 64) * (v.rank_cap + 8) * 2;
+        e->gain_lds = (e->gain_lds + 15) & ~(size_t)15;
+        if (e->gain_lds > 160 * 1024) {
+            const size_t need = e->gain_lds;
+            delete e;
+            return fail(-1, "gain kernel needs %zu B of LDS (> 160 KiB): lower rank_cap", need);
+        }
+    }
     if (e->prep_lds > 160 * 1024) {
         delete e;
         return fail(-1, "prologue needs %zu B of LDS (> 160 KiB): lower rank_cap or max_measurements", e->prep_lds);
@@ -407,8 +435,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     const int glds = (int)e->gain_lds;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipGetLastError();
     // state starts zeroed (rank 0, padding 0); envs must still be ipp_reset before use
@@ -457,7 +487,7 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     out->n_tiles = e->v.n_tiles;
     out->meas_cap = e->v.meas_cap;
     out->fp_cap = e->v.fp_cap;
-    out->reserved = 0;
+    out->window_rows = e->v.window_rows;
     out->arena_bytes = e->used_bytes;
     out->cov_slot_bytes = e->v.cov_slot * 4;
     return 0;
@@ -702,6 +732,19 @@ int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out, void* str
         out->z[i] = d[(size_t)2 * MC * MC + i];
         out->y[i] = d[(size_t)2 * MC * MC + MC + i];
     }
+    return 0;
+}
+
+int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !bytes) return fail(-1, "null argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned long long cells = 0;
+    HIP_TRY(hipMemcpyAsync(&cells, e->v.counters, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *bytes = (uint64_t)cells * 4;
+    if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 64, s));
     return 0;
 }
 

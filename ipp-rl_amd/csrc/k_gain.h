@@ -82,7 +82,8 @@ __device__ __forceinline__ void store_stream(float* p, const float (&o)[VEC]) {
 
 // acc[c][j] += sum_k row_k[cell0 + c] * Q[k][j] over the `cnt` rows whose Q is staged in Qs (the prologue
 // stores Q with the sign of the update folded in).
-// rowidx (LDS) maps the streaming index to the row of the covariance slab (dense: footprint cell).
+// rowidx (LDS) maps the streaming index to the row of the covariance slab (dense: footprint cell of P;
+// factor: the columns of U stored on this tile).
 template <int MC, int VEC, int MODE>
 __device__ __forceinline__ void stream_rows(const float* __restrict__ cov_src,
                                             const int* rowidx, int k0, int cnt, int last_row, size_t npad, int cell0,
@@ -91,8 +92,7 @@ __device__ __forceinline__ void stream_rows(const float* __restrict__ cov_src,
     // the row base is wave-uniform (SGPR pair); only the 32-bit cell offset is per lane
     auto row_base = [&](int k) -> size_t {
         const int kc = min(k, last_row);  // rows past the end re-read the last row against a zero Q row
-        const int ridx = (MODE == IPP_FACTOR) ? kc : __builtin_amdgcn_readfirstlane(rowidx[kc]);
-        return (size_t)ridx * npad;
+        return (size_t)__builtin_amdgcn_readfirstlane(rowidx[kc]) * npad;
     };
     // ping-pong register buffers: while one group of kPipe rows is consumed the next is in flight
     auto consume = [&](const float (&u)[kPipe][VEC], int kbase) {
@@ -150,17 +150,49 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
         return;
     }
 
+    // tiles outside the span of the column(s) this step appends hold no part of Wc (window_rows > 0): nothing to do
+    if (MODE == IPP_FACTOR && (tile < h.t_lo || tile > h.t_hi)) {
+        if (tid == 0) {
+            if (v.n_tiles == 1) reward_out[item] = 0.f; else v.partial[(size_t)item * v.n_tiles + tile] = 0.0;
+        }
+        return;
+    }
+
     const int cell0 = tile * VEC * T + VEC * tid;
     constexpr int LQ = (MC * MC + MC + 3) & ~3;  // the item's scratch block is [L^-1 | y | pad | Q rows | zero rows]
     const float* __restrict__ qg = v.q + (size_t)item * v.q_item + LQ;
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
-    const int rows = h.rows;
 
     for (int i = tid; i < MC * MC; i += T) Ls[i] = v.linv[(size_t)item * MC * MC + i];
     if (tid < MC) ys[tid] = v.yv[(size_t)item * MC + tid];
-    if (MODE == IPP_DENSE)
+    int rows = h.rows;
+    if (MODE == IPP_DENSE) {
         for (int i = tid; i < rows; i += T) rowidx[i] = (h.yu + i / h.w) * v.W + h.xl + i % h.w;
+    } else {
+        // ordered compaction of the columns of U that are stored on this tile (all of them when window_rows == 0)
+        const int* __restrict__ span = v.colspan + (size_t)h.env * v.rank_cap;
+        const int lane = tid & (kWave - 1), wave = tid / kWave, nw = T / kWave;
+        int* wcount = reinterpret_cast<int*>(red);  // red[] is free until the epilogue
+        int base = 0;
+        for (int k0 = 0; k0 < h.rows; k0 += T) {
+            const int k = k0 + tid;
+            bool on = false;
+            if (k < h.rows) {
+                const int sp = span[k];
+                on = tile >= (sp & 0xffff) && tile <= (sp >> 16);
+            }
+            const unsigned long long mask = __ballot(on);
+            if (lane == 0) wcount[wave] = __popcll(mask);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wave; ++w) off += wcount[w];
+            if (on) rowidx[off + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+            for (int w = 0; w < nw; ++w) base += wcount[w];
+            __syncthreads();
+        }
+        rows = base;
+    }
     __syncthreads();
 
     float acc[VEC][MC];
@@ -209,10 +241,19 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
         const int cnt = min(q_chunk, rows - k0);
         if (k0 > 0) __syncthreads();
         {
-            const float4* src = reinterpret_cast<const float4*>(qg + (size_t)k0 * QS);
             float4* dst = reinterpret_cast<float4*>(Qs);
-            const int n4 = cnt * (QS / 4), tot4 = (cnt + 2 * kPipe) * (QS / 4);
-            for (int i = tid; i < tot4; i += T) dst[i] = (i < n4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            constexpr int Q4 = QS / 4;
+            const int n4 = cnt * Q4, tot4 = (cnt + 2 * kPipe) * Q4;
+            for (int i = tid; i < tot4; i += T) {
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n4) {
+                    const int a = i / Q4, part = i - a * Q4;
+                    // dense: Q rows are already in streaming order; factor: row of the a-th stored column
+                    const int qrow = (MODE == IPP_DENSE) ? (k0 + a) : rowidx[k0 + a];
+                    val = *reinterpret_cast<const float4*>(qg + (size_t)qrow * QS + 4 * part);
+                }
+                dst[i] = val;
+            }
         }
         __syncthreads();
         stream_rows<MC, VEC, MODE>(cov_src, rowidx, k0, cnt, rows - 1, (size_t)v.Npad, cell0, Qs, acc);
@@ -270,6 +311,11 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
             v.partial[(size_t)item * v.n_tiles + tile] = tot;
     }
 
+    if (tid == 0) {  // traffic accounting: rows streamed (+ appended) on this tile, mean / diag read (+ write)
+        const int valid = max(0, min(v.tile_cells, v.N - tile * v.tile_cells));
+        const unsigned long long units = (unsigned long long)(rows + (h.commit ? m + 4 : 2)) * valid;
+        atomicAdd(v.counters, units);
+    }
     if (!h.commit) return;
     float outv[VEC];
 #pragma unroll
@@ -300,7 +346,10 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
                 for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
                 store_stream<VEC>(cov_dst + (size_t)(h.rank + j) * v.Npad + cell0, outv);
             }
-        if (tile == 0 && tid == 0) v.rank[h.dst] = h.rank + m;
+        if (tile == h.t_lo) {  // one workgroup per item publishes the new rank and the span of the new columns
+            if (tid == 0) v.rank[h.dst] = h.rank + m;
+            if (tid < m) v.colspan[(size_t)h.dst * v.rank_cap + h.rank + tid] = h.t_lo | (h.t_hi << 16);
+        }
     } else {
         float* wc = v.wc + (size_t)item * MC * v.Npad + cell0;
 #pragma unroll

@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256) void k_fork(View v, const int* __restrict__ sr
             v.prior[2 * d + 0] = v.prior[2 * s + 0];
             v.prior[2 * d + 1] = v.prior[2 * s + 1];
         }
+        if (v.mode == IPP_FACTOR)
+            for (int i = threadIdx.x; i < r; i += blockDim.x)
+                v.colspan[(size_t)d * v.rank_cap + i] = v.colspan[(size_t)s * v.rank_cap + i];
     }
 }
 // rank is written by a second tiny launch so that k_fork never reads a rank another block already replaced
@@ -194,7 +197,13 @@ __global__ __launch_bounds__(256) void k_read_cov_factor(View v, int env, float*
     double acc = matern_d(ri - rj, ci - cj, v.res, sv, ls);
     const float* U = v.cov + (size_t)env * v.cov_slot;
     const int r = v.rank[env];
-    for (int k = 0; k < r; ++k) acc -= (double)U[(size_t)k * v.Npad + i] * (double)U[(size_t)k * v.Npad + j];
+    const int ti = i / v.tile_cells, tj = j / v.tile_cells;
+    const int* span = v.colspan + (size_t)env * v.rank_cap;
+    for (int k = 0; k < r; ++k) {
+        const int lo = span[k] & 0xffff, hi = span[k] >> 16;  // a column is zero outside its stored tiles
+        if (ti < lo || ti > hi || tj < lo || tj > hi) continue;
+        acc -= (double)U[(size_t)k * v.Npad + i] * (double)U[(size_t)k * v.Npad + j];
+    }
     out[(size_t)i * v.N + j] = (float)acc;
 }
 

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
         h.status = IPP_STATUS_OK;
         h.fallback = 0;
         h.commit = (flags & IPP_PREDICT_ONLY) ? 0 : 1;
-        h.pad0 = h.pad1 = 0;
+        h.t_lo = 0;
+        h.t_hi = v.n_tiles - 1;
         const double ax = action[3 * item + 0], ay = action[3 * item + 1], az = action[3 * item + 2];
         const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
         bool ok = isfinite(ax) && isfinite(ay) && isfinite(az) && h.env >= 0 && h.env < v.cap && h.dst >= 0 &&
@@ -126,6 +127,12 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
         if (MODE == IPP_FACTOR && h.status == IPP_STATUS_OK && h.commit && h.rank + h.m > v.rank_cap) {
             h.status = IPP_STATUS_RANK_FULL;
             h.commit = 0;
+        }
+        if (MODE == IPP_FACTOR && v.window_rows > 0 && ok) {
+            // the appended columns are kept on the grid rows within window_rows of the footprint (whole tiles)
+            const int row_lo = max(0, yu - v.window_rows), row_hi = min(v.H - 1, yd + v.window_rows);
+            h.t_lo = (row_lo * v.W) / v.tile_cells;
+            h.t_hi = ((row_hi + 1) * v.W - 1) / v.tile_cells;
         }
         h.rows = (MODE == IPP_FACTOR) ? h.rank : h.f;
         if (h.status == IPP_STATUS_BAD_FOOTPRINT) { h.m = 0; h.f = 0; h.rows = 0; h.commit = 0; }
@@ -241,9 +248,12 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
         if (i < m) {
             const int cnt = bcnt[i];
             const int c0 = bcell[4 * i], c1 = bcell[4 * i + 1], c2 = bcell[4 * i + 2], c3 = bcell[4 * i + 3];
+            const int t0 = c0 / v.tile_cells, t1 = c1 / v.tile_cells, t2 = c2 / v.tile_cells, t3 = c3 / v.tile_cells;
             const float w = (float)bwt[i];
+            const int* __restrict__ span = v.colspan + (size_t)h.env * v.rank_cap;
             // 8 rows per pass: all (<= 32) 4-byte loads of a pass are issued before the first LDS store, so a
-            // thread pays one memory round trip per 8 rows instead of one per row
+            // thread pays one memory round trip per 8 rows instead of one per row.  A column contributes only
+            // where it is stored (its tile span): cells outside hold nothing and count as zero.
             constexpr int KS = kPrepThreads / MP, UN = 8;
             for (int k0 = tid / MP; k0 < r; k0 += UN * KS) {
                 float sacc[UN];
@@ -251,9 +261,10 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
                 for (int u = 0; u < UN; ++u) {
                     const int k = min(k0 + u * KS, r - 1);
                     const float* row = cov_env + (size_t)k * v.Npad;
-                    float t = row[c0];
-                    if (cnt > 1) t += row[c1];
-                    if (cnt > 2) t += row[c2] + row[c3];
+                    const int sp = span[k], lo = sp & 0xffff, hi = sp >> 16;
+                    float t = (t0 >= lo && t0 <= hi) ? row[c0] : 0.f;
+                    if (cnt > 1) t += (t1 >= lo && t1 <= hi) ? row[c1] : 0.f;
+                    if (cnt > 2) t += ((t2 >= lo && t2 <= hi) ? row[c2] : 0.f) + ((t3 >= lo && t3 <= hi) ? row[c3] : 0.f);
                     sacc[u] = t;
                 }
 #pragma unroll

@@ -70,7 +70,7 @@ class IPPEngine:
 
     def __init__(self, cfg: EngineConfig, capacity: int, state: str = "factor", rank_cap: int = 360,
                  max_batch: Optional[int] = None, device: str = "cuda:0", max_measurements: int = 9,
-                 tile_threads: int = 0):
+                 tile_threads: int = 0, window_rows: int = 0):
         torch = _torch()
         self._lib = _ffi.load()
         if not torch.cuda.is_available():
@@ -96,6 +96,7 @@ class IPPEngine:
             raise ValueError("state must be 'factor' or 'dense'")
         c.capacity, c.rank_cap, c.max_batch = self.capacity, int(rank_cap), self.max_batch
         c.max_measurements, c.tile_threads = int(max_measurements), int(tile_threads)
+        c.window_rows = int(window_rows)
         self._c = c
         nbytes = C.c_uint64(0)
         _ffi.check(self._lib.ipp_engine_arena_bytes(C.byref(c), C.byref(nbytes)))
@@ -305,6 +306,12 @@ class IPPEngine:
             S=np.array(it.S[: m * m]).reshape(m, m), Linv=np.array(it.Linv[: m * m]).reshape(m, m),
             z=np.array(it.z[:m]), y=np.array(it.y[:m]),
         )
+
+    def streamed_bytes(self, reset: bool = True) -> int:
+        """Bytes the gain kernel streamed / wrote since the last reset (device counter; synchronises)."""
+        b = C.c_uint64(0)
+        _ffi.check(self._lib.ipp_streamed_bytes(self._h, C.byref(b), 1 if reset else 0, self.stream))
+        return int(b.value)
 
     def profile(self, enable: bool):
         _ffi.check(self._lib.ipp_profile_enable(self._h, 1 if enable else 0))

@@ -52,7 +52,7 @@ class VecIPPEnv:
     def __init__(self, cfg: EngineConfig, num_envs: int, state: str = "factor", episode_steps: int = 40,
                  device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
                  rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
-                 adaptive: bool = True, use_flight_time: bool = True):
+                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0):
         import torch
 
         self.torch = torch
@@ -65,7 +65,7 @@ class VecIPPEnv:
         self.adaptive, self.use_flight_time = adaptive, use_flight_time
         rank_cap = int(rank_cap) if rank_cap else 9 * self.episode_steps
         self.engine = IPPEngine(cfg, capacity=self.num_envs, state=state, rank_cap=rank_cap, device=device,
-                                tile_threads=tile_threads)
+                                tile_threads=tile_threads, window_rows=window_rows)
         dev = self.engine.device
         self.device = dev
         B = self.num_envs

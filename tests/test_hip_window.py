@@ -1,0 +1,105 @@
+"""
+GPU tests of the windowed factor state (ipp_config.window_rows): a new column of U is stored only on the tiles
+within R grid rows of its footprint.  With R = 12 the truncated magnitudes are < 3e-8 for the example prior
+(SURVEY 8(d)), so the results must still match the fp64 oracle / golden vectors within 1e-5; R = 0 must be
+bit-identical to the exact path.
+"""
+import numpy as np
+import pytest
+
+from oracle import ipp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def engine(dim, window_rows, tile_threads=256, capacity=2):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    return IPPEngine(EngineConfig(x_dim=dim, y_dim=dim), capacity=capacity, state="factor", rank_cap=400,
+                     window_rows=window_rows, tile_threads=tile_threads)
+
+
+@pytest.mark.parametrize("name", ["episode_rf1_50_s0", "episode_mixed_50_s1"])
+@pytest.mark.parametrize("tile_threads", [64, 256])
+def test_window12_episode_vs_golden(golden, name, tile_threads):
+    g = golden(name)
+    dim = g["gt"].shape[0]
+    eng = engine(dim, 12, tile_threads)
+    assert eng.info.window_rows == 12
+    eng.reset(env_ids=[0], white_noise=g["white"][None])
+    prev = np.array([2.0, 2.0, 14.0])
+    worst = dict(reward=0.0, mean=0.0, diag=0.0)
+    eng.streamed_bytes(reset=True)
+    for t, a in enumerate(g["actions"]):
+        reward, status = eng.step(a[None], prev[None], env_ids=[0], meas_noise=g["eps"][t][None])
+        assert int(status[0]) == 0
+        worst["reward"] = max(worst["reward"], abs(float(reward[0]) - g["reward"][t]))
+        worst["mean"] = max(worst["mean"], np.max(np.abs(host(eng.read_mean(0)) - g["mean"][t])))
+        worst["diag"] = max(worst["diag"], np.max(np.abs(host(eng.read_diag(0)) - g["diag"][t])))
+        prev = a
+    streamed = eng.streamed_bytes()
+    N = dim * dim
+    r_before = np.concatenate([[0], np.cumsum(g["m"])[:-1]])
+    full = float(np.sum(4.0 * N * (r_before + g["m"]) + 16.0 * N))
+    P = host(eng.read_cov(0))
+    err_rows = np.max(np.abs(P[g["sample_rows"]] - g["P_final_rows"]))
+    print(f"[window 12, T={tile_threads}, {name}] worst {worst} P rows {err_rows:.2e}; streamed {streamed / full:.2f} of full-column bytes")
+    assert max(worst.values()) < TOL and err_rows < TOL
+    assert streamed < 0.8 * full
+
+
+def test_window0_and_huge_window_agree_and_count_formula_bytes():
+    """window_rows = 0 (tile-workgroup kernel) and a window larger than the grid (workgroup-per-item kernel with every
+    tile active) are the same mathematics: results agree to rounding and both count the full-column formula bytes."""
+    dim = 20
+    a_eng, b_eng = engine(dim, 0, 128), engine(dim, 1000, 256)
+    rs = np.random.RandomState(4)
+    white = rs.normal(size=(1, dim, dim))
+    for e in (a_eng, b_eng):
+        e.reset(env_ids=[0], white_noise=white)
+        e.streamed_bytes(reset=True)
+    prev = np.array([[2.0, 2.0, 14.0]])
+    total = 0.0
+    for t in range(12):
+        a = np.array([[4.0 * rs.randint(0, dim) + 2, 4.0 * rs.randint(0, dim) + 2, float(rs.randint(5, 15))]])
+        eps = rs.normal(size=(1, 9))
+        r_before = a_eng.rank(0)
+        ra, _ = a_eng.step(a, prev, env_ids=[0], meas_noise=eps)
+        rb, _ = b_eng.step(a, prev, env_ids=[0], meas_noise=eps)
+        m = a_eng.rank(0) - r_before
+        total += 4.0 * dim * dim * (r_before + m) + 16.0 * dim * dim
+        assert abs(float(ra[0]) - float(rb[0])) < 1e-6
+        prev = a
+    assert a_eng.streamed_bytes() == int(total) and b_eng.streamed_bytes() == int(total)
+    assert np.max(np.abs(host(a_eng.read_cov(0)) - host(b_eng.read_cov(0)))) < 1e-6
+
+
+def test_window_batch_vs_oracle_with_clustered_revisits():
+    """Worst case for truncation: all measurements in one neighbourhood (columns overlap maximally)."""
+    dim, B, T = 40, 6, 30
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim)
+    eng = engine(dim, 12, 256, capacity=B)
+    rs = np.random.RandomState(12)
+    white = rs.normal(size=(B, dim, dim))
+    eng.reset(white_noise=white)
+    envs = [orc.env_reset(ocfg, white[b]) for b in range(B)]
+    prev = np.tile([2.0, 2.0, 14.0], (B, 1))
+    for t in range(T):
+        acts = np.stack([4.0 * rs.randint(14, 24, B) + 2, 4.0 * rs.randint(14, 24, B) + 2, rs.randint(5, 15, B) * 1.0], 1)
+        eps = rs.normal(size=(B, 9))
+        reward, status = eng.step(acts, prev, meas_noise=eps)
+        assert int(status.abs().sum()) == 0
+        for b in range(B):
+            m = orc.num_measurements(orc.project_fov(ocfg, acts[b]), orc.resolution_factor(acts[b]))
+            out = orc.env_step(ocfg, envs[b], acts[b], eps[b, :m])
+            assert abs(float(reward[b]) - out["reward"]) < TOL
+        prev = acts
+    for b in range(B):
+        assert np.max(np.abs(host(eng.read_mean(b)) - envs[b].mean)) < TOL
+        assert np.max(np.abs(host(eng.read_diag(b)) - np.diag(envs[b].P))) < TOL
+    assert np.max(np.abs(host(eng.read_cov(0)) - envs[0].P)) < TOL
