@@ -46,7 +46,7 @@ def test_struct_layouts_match_header_order():
     txt = open(os.path.join(ROOT, "include", "ipp_engine.h")).read()
     body = re.search(r"typedef struct ipp_config \{(.*?)\} ipp_config;", txt, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"(?:int32_t|double)\s+([a-z_]+);", body)
+    fields = re.findall(r"(?:int32_t|double)\s+([a-z_0-9]+);", body)
     assert fields == [f[0] for f in _ffi.IppConfig._fields_]
     assert ctypes.sizeof(_ffi.IppConfig) == 8 + 13 * 8 + 8 * 4
 
