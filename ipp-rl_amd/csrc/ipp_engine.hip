@@ -15,6 +15,8 @@
 #include "ipp_common.h"
 #include "k_gain.h"
 #include "k_gain_factor.h"
+#include "k_step_factor.h"
+#include "k_gain_wave.h"
 #include "k_misc.h"
 #include "k_prepare.h"
 
@@ -61,6 +63,7 @@ struct Engine {
     int lut_cap;
     bool profile = false;
     int step_chunks = 0;  // 0 = auto
+    bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     hipStream_t side = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_prep[8] = {};
@@ -115,7 +118,7 @@ int plan(const ipp_config& c, Layout& L) {
     if (c.state_repr == IPP_FACTOR && c.window_rows > 0) {
         // windowed factor state: one workgroup per item, wave-granular tiles of 64 * VEC cells (k_gain_factor.h);
         // tile_threads is the workgroup size (waves share the item's Q block and prior table in LDS)
-        L.T = (c.tile_threads > 0) ? c.tile_threads : 256;
+        L.T = (c.tile_threads > 0) ? c.tile_threads : 64;  // 64: one wave per item (k_gain_wave.h), 256: fused workgroup kernel
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;
@@ -147,9 +150,9 @@ int plan(const ipp_config& c, Layout& L) {
 }
 
 size_t prep_lds_bytes(const Layout& L, const ipp_config& c) {
-    const size_t MC = L.MC, FC = L.FC, LD = MC + 1;
-    size_t b = (3 * MC * LD + 3 * MC + 2 * FC) * sizeof(double) + sizeof(ItemHdr) + 16 +
-               (FC + 8 * MC + ((MC + 3) & ~(size_t)3)) * sizeof(int) + MC * sizeof(double);
+    const size_t MC = L.MC, FC = L.FC;
+    const size_t small = (L.MC == 9) ? prep_small_bytes<9>() : prep_small_bytes<25>();
+    size_t b = (small + 15) & ~(size_t)15;
     if (c.state_repr == IPP_FACTOR)
         b += MC * (size_t)((c.rank_cap + 3) & ~3) * sizeof(float);
     else
@@ -246,6 +249,13 @@ template <int MC, int VEC>
 void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
                   const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
                   hipEvent_t prep_done) {
+    if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
+        ProfScope ps(e, 0, s);
+        hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev,
+                           noise, flags, e->lut_cap, status, reward);
+        if (prep_done) (void)hipEventRecord(prep_done, s);
+        return;
+    }
     {
         ProfScope ps(e, 2, s);
         if (v.mode == IPP_FACTOR)
@@ -259,7 +269,9 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
     {
         ProfScope ps(e, 0, s);
         const int grid = grid_for(n, v.n_tiles);
-        if (v.mode == IPP_FACTOR && v.window_rows > 0)
+        if (v.mode == IPP_FACTOR && v.window_rows > 0 && v.T == kWave)
+            hipLaunchKernelGGL((k_gain_wave<MC, VEC>), dim3(n), dim3(kWave), e->gain_lds, s, v, v.q, n, flags, reward);
+        else if (v.mode == IPP_FACTOR && v.window_rows > 0)
             hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, n, flags, e->lut_cap, reward);
         else if (v.mode == IPP_FACTOR)
             hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
@@ -412,8 +424,14 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->gain_lds = gain_lds_bytes(v, e->q_chunk, e->lut_cap);
     if (v.mode == IPP_FACTOR && v.window_rows > 0) {
         const size_t MCs = v.meas_cap, LQ = (MCs * MCs + MCs + 3) & ~(size_t)3;
-        e->gain_lds = (LQ + (size_t)(v.rank_cap + 8) * v.q_stride + ((e->lut_cap + 3) & ~3)) * 4 + 16 * 8 +
+        e->fused = (v.T == kStepThreads);
+        if (const char* fu = getenv("IPP_FUSED")) e->fused = e->fused && atoi(fu) != 0;  // A/B experiments
+        const int lutf = e->fused ? ((v.meas_cap == 9) ? step_scratch_floats<9>(e->lut_cap) : step_scratch_floats<25>(e->lut_cap)) : e->lut_cap;
+        e->gain_lds = (LQ + (size_t)(v.rank_cap + 8) * v.q_stride + ((lutf + 3) & ~3)) * 4 + 16 * 8 +
                       (size_t)v.rank_cap * 4 + (size_t)(v.T / 64) * (v.rank_cap + 8) * 2;
+        if (v.T == kWave)
+            e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
+                          (size_t)(v.rank_cap + 8) * 2;
         e->gain_lds = (e->gain_lds + 15) & ~(size_t)15;
         if (e->gain_lds > 160 * 1024) {
             const size_t need = e->gain_lds;
@@ -437,6 +455,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);

@@ -25,56 +25,41 @@
 
 namespace ipp {
 
+// LDS layout shared by k_gain_factor and k_step_factor.
+template <int MC>
+struct GainLds {
+    static constexpr int QS = (MC + 3) & ~3;
+    static constexpr int LQ = (MC * MC + MC + 3) & ~3;
+    float* Ls; float* ys; float* Qs; float* lut; double* red; int* next_tile; int* done_waves; int* span_s;
+    unsigned short* ridx_all;
+    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int lut_floats) {
+        Ls = reinterpret_cast<float*>(base);
+        ys = Ls + MC * MC;
+        Qs = Ls + LQ;
+        lut = Qs + (size_t)(rank_cap + 8) * QS;
+        red = reinterpret_cast<double*>(lut + ((lut_floats + 3) & ~3));
+        next_tile = reinterpret_cast<int*>(red + 15);  // red[15] is unused by the reduction
+        done_waves = next_tile + 1;
+        span_s = reinterpret_cast<int*>(red + 16);
+        ridx_all = reinterpret_cast<unsigned short*>(span_s + rank_cap);
+    }
+};
+
+// Tile loop + per-item results; expects Ls / ys / Qs (rows 0..r-1 and a zero row r), the prior table (when
+// use_lut), span_s[0..r) and the two counters (zeroed) in LDS, visible to the whole workgroup.
 template <int MC, int VEC>
-__global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, int n_items, unsigned flags, int lut_cap,
-                                                                   float* __restrict__ reward_out) {
+__device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, bool use_lut,
+                                           const GainLds<MC>& lds, float* __restrict__ reward_out) {
     constexpr int kWaveTile = VEC * kWave;  // cells per wave tile
     constexpr int KP = IPP_GF_PIPE;          // rows per ping-pong group (2 groups in flight per wave)
     constexpr int QS = (MC + 3) & ~3;
-    constexpr int LQ = (MC * MC + MC + 3) & ~3;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    // LDS carve: blk = [L^-1 | y | pad | Q rows (rank_cap + 8)] | lut[lut_cap] | red[16] f64 | span[rank_cap] i32 |
-    //            ridx[waves][rank_cap + 8] u16
-    float* Ls = reinterpret_cast<float*>(smem_gf);
-    float* ys = Ls + MC * MC;
-    float* Qs = Ls + LQ;
-    float* lut = Qs + (size_t)(v.rank_cap + 8) * QS;
-    double* red = reinterpret_cast<double*>(lut + ((lut_cap + 3) & ~3));
-    int* next_tile = reinterpret_cast<int*>(red + 15);                     // tile hand-out counter (red[15] is unused)
-    int* done_waves = next_tile + 1;                                        // waves that have published their partial
-    int* span_s = reinterpret_cast<int*>(red + 16);                        // [rank_cap] tile spans of the stored columns
-    unsigned short* ridx_all = reinterpret_cast<unsigned short*>(span_s + v.rank_cap);
-
-    const int item = blockIdx.x;
-    if (item >= n_items) return;
+    float* Ls = lds.Ls; float* ys = lds.ys; float* Qs = lds.Qs; float* lut = lds.lut; double* red = lds.red;
+    int* next_tile = lds.next_tile; int* done_waves = lds.done_waves; int* span_s = lds.span_s;
+    unsigned short* ridx_all = lds.ridx_all;
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid / kWave, nw = T / kWave;
-    const ItemHdr h = v.hdr[item];
     const int m = h.m, r = h.rank;
-
-    if (m == 0 || h.status == IPP_STATUS_NOT_PD) {
-        if (tid == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;
-        return;
-    }
-
-    // ------------------------------------------------------------------ per-item staging (once per workgroup)
-    {
-        const float4* src = reinterpret_cast<const float4*>(v.q + (size_t)item * v.q_item);
-        float4* dst = reinterpret_cast<float4*>(Ls);
-        const int blk4 = (LQ + (r + 8) * QS) / 4;  // k_prepare zero-fills the 8 rows after Q: row r is the zero row
-        for (int i = tid; i < blk4; i += T) dst[i] = src[i];
-    }
-    if (tid == 0) { *next_tile = 0; *done_waves = 0; }
-    for (int k = tid; k < r; k += T) span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
     const float s3 = (float)(kSqrt3 * v.res) / h.ls;
-    const bool use_lut = v.N <= lut_cap;
-    if (use_lut) {
-        for (int i = tid; i < v.N; i += T) {
-            const int dr = i / v.W, dc = i - dr * v.W;
-            lut[i] = matern_f(dr, dc, s3, h.sv);
-        }
-    }
-    __syncthreads();
 
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
@@ -241,6 +226,43 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, in
         if (h.commit) v.rank[h.dst] = r + m;
     }
     if (h.commit && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+}
+
+// Stand-alone gain kernel (after k_prepare): stages the item's scratch block and the prior table, then gain_tiles.
+template <int MC, int VEC>
+__global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, int n_items, unsigned flags, int lut_cap,
+                                                                   float* __restrict__ reward_out) {
+    constexpr int QS = (MC + 3) & ~3;
+    constexpr int LQ = (MC * MC + MC + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
+    const GainLds<MC> lds(smem_gf, v.rank_cap, lut_cap);
+    const int item = blockIdx.x;
+    if (item >= n_items) return;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const ItemHdr h = v.hdr[item];
+    const int r = h.rank;
+    if (h.m == 0 || h.status == IPP_STATUS_NOT_PD) {
+        if (tid == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;
+        return;
+    }
+    {
+        const float4* src = reinterpret_cast<const float4*>(v.q + (size_t)item * v.q_item);
+        float4* dst = reinterpret_cast<float4*>(lds.Ls);
+        const int blk4 = (LQ + (r + 8) * QS) / 4;  // k_prepare zero-fills the 8 rows after Q: row r is the zero row
+        for (int i = tid; i < blk4; i += T) dst[i] = src[i];
+    }
+    if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; }
+    for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
+    const bool use_lut = v.N <= lut_cap;
+    if (use_lut) {
+        const float s3 = (float)(kSqrt3 * v.res) / h.ls;
+        for (int i = tid; i < v.N; i += T) {
+            const int dr = i / v.W, dc = i - dr * v.W;
+            lds.lut[i] = matern_f(dr, dc, s3, h.sv);
+        }
+    }
+    __syncthreads();
+    gain_tiles<MC, VEC>(v, h, item, flags, use_lut, lds, reward_out);
 }
 
 }  // namespace ipp

@@ -33,19 +33,36 @@ __device__ inline double area_weight(int src, int dst, int d, int s) {
     return w;
 }
 
-template <int MC, int MODE>
-__global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(View v, const int* __restrict__ env_ids,
-                                                          const int* __restrict__ dst_ids, int n_items,
-                                                          const double* __restrict__ action,
-                                                          const double* __restrict__ prev_action,
-                                                          const float* __restrict__ meas_noise, unsigned flags,
-                                                          int* __restrict__ status_out, float* __restrict__ obs_out,
-                                                          int* __restrict__ obs_m, int* __restrict__ obs_shape) {
+// LDS bytes of the small fp64 / table scratch of prepare_item (everything except the HT / P_FF staging area).
+template <int MC>
+__host__ __device__ constexpr size_t prep_small_bytes() {
+    return (3 * MC * (MC + 1) + 3 * MC + 2 * 4 * MC) * sizeof(double) + sizeof(ItemHdr) + 16 +
+           (4 * MC + 8 * MC + ((MC + 3) & ~3)) * sizeof(int) + MC * sizeof(double);
+}
+
+// The per-item prologue as a device function so that it can run as its own kernel (k_prepare: dense state, exact
+// factor state, ipp_observe) or at the head of the fused factor step kernel (k_step_factor.h).
+//   small        LDS scratch of prep_small_bytes<MC>() bytes (16-byte aligned); the ItemHdr lives inside it
+//   big, si, sk  staging area of HT (factor: HT(i,k) = big[i*si + k*sk]; si <= 0 selects the row-major
+//                [MC][round4(rank)] layout) or P_FF (dense: [FC][FC+1])
+//   q_out        Q rows [k][QS] (global scratch, or LDS where q_out == big with sk == QS: in place)
+//   linv_f/_f2, y_f/_f2   fp32 copies of L^-1 and y for the streaming kernels (second pointers may be null)
+//   span_s       optional LDS array receiving the tile spans of the stored columns (factor)
+// Returns a pointer to the item header in LDS; header.m == 0 or status NOT_PD means nothing to stream.
+template <int MC, int MODE, int NT>
+__device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, const int* __restrict__ env_ids,
+                                                 const int* __restrict__ dst_ids, const double* __restrict__ action,
+                                                 const double* __restrict__ prev_action,
+                                                 const float* __restrict__ meas_noise, unsigned flags,
+                                                 int* __restrict__ status_out, float* __restrict__ obs_out,
+                                                 int* __restrict__ obs_m, int* __restrict__ obs_shape,
+                                                 unsigned char* small, float* big, int si, int sk, float* q_out,
+                                                 float* linv_f, float* linv_f2, float* y_f, float* y_f2, int* span_s) {
+    constexpr int kPrepThreads = NT;
     constexpr int FC = 4 * MC;
     constexpr int LD = MC + 1;  // padded leading dimension of the small fp64 matrices
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // ---- LDS carve (all offsets multiples of 16 B)
-    double* S = reinterpret_cast<double*>(smem);          // [MC][LD]
+    // ---- LDS carve (all offsets multiples of 8 B)
+    double* S = reinterpret_cast<double*>(small);         // [MC][LD]
     double* L = S + MC * LD;                              // [MC][LD]   lower Cholesky factor / work
     double* Li = L + MC * LD;                             // [MC][LD]   upper-triangular inverse (or S^-1)
     double* zz = Li + MC * LD;                            // [MC] observation
@@ -60,11 +77,8 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
     int* bfi = bcell + 4 * MC;                             // [MC][4] footprint-local indices of block i
     int* bcnt = bfi + 4 * MC;                              // [MC] cells in block i (1, 2 or 4)
     double* bwt = reinterpret_cast<double*>(bcnt + ((MC + 3) & ~3));  // [MC] weight of block i
-    float* big = reinterpret_cast<float*>(bwt + MC);       // factor: HT[MC][ht_ld]   dense: PFF[FC][FC+1]
 
-    const int item = blockIdx.x;
     const int tid = threadIdx.x;
-    if (item >= n_items) return;
 
     // ------------------------------------------------------------------ header (thread 0, fp64 like NumPy)
     if (tid == 0) {
@@ -142,12 +156,7 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
     __syncthreads();
     const ItemHdr h = *hs;
     const int m = h.m, f = h.f, r = h.rank;
-    float* linv_out = v.linv + (size_t)item * MC * MC;
-    float* y_out = v.yv + (size_t)item * MC;
     double* dbg = v.dbg + (size_t)item * (2 * MC * MC + 2 * MC);
-    constexpr int LQ = (MC * MC + MC + 3) & ~3;
-    float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]: one DMA block for k_gain
-    float* q_out = blk_out + LQ;
 
     if (m == 0) {  // bad footprint: nothing to stream
         if (tid == 0) {
@@ -155,9 +164,9 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
             if (status_out) status_out[item] = h.status;
             if (obs_m) obs_m[item] = 0;
         }
-        for (int i = tid; i < MC * MC; i += kPrepThreads) { linv_out[i] = 0.f; blk_out[i] = 0.f; }
-        for (int i = tid; i < MC; i += kPrepThreads) { y_out[i] = 0.f; blk_out[MC * MC + i] = 0.f; }
-        return;
+        for (int i = tid; i < MC * MC; i += kPrepThreads) { linv_f[i] = 0.f; if (linv_f2) linv_f2[i] = 0.f; }
+        for (int i = tid; i < MC; i += kPrepThreads) { y_f[i] = 0.f; if (y_f2) y_f2[i] = 0.f; }
+        return hs;
     }
 
     const double sv = v.prior[2 * h.env + 0], ls = v.prior[2 * h.env + 1];
@@ -234,8 +243,9 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
                 obs_shape[2 * item + 1] = (h.rf == 1) ? h.w : (h.h + h.rf - 1) / h.rf;
             }
             if (status_out) status_out[item] = h.status;
+            hs->m = 0;  // nothing to stream
         }
-        return;
+        return hs;
     }
 
     // ------------------------------------------------------------------ gather the state rows of the footprint
@@ -244,13 +254,16 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
     if (MODE == IPP_FACTOR) {
         // HT[i][k] = sum_{cells of block i} w * U[k][cell]   (m x r)
         ht_ld = (r + 3) & ~3;
+        const int SI = (si > 0) ? si : ht_ld, SK = (si > 0) ? sk : 1;
+        const int* __restrict__ span = v.colspan + (size_t)h.env * v.rank_cap;
+        if (span_s)
+            for (int k = tid; k < r; k += kPrepThreads) span_s[k] = span[k];
         const int i = tid & (MP - 1);
         if (i < m) {
             const int cnt = bcnt[i];
             const int c0 = bcell[4 * i], c1 = bcell[4 * i + 1], c2 = bcell[4 * i + 2], c3 = bcell[4 * i + 3];
             const int t0 = c0 / v.tile_cells, t1 = c1 / v.tile_cells, t2 = c2 / v.tile_cells, t3 = c3 / v.tile_cells;
             const float w = (float)bwt[i];
-            const int* __restrict__ span = v.colspan + (size_t)h.env * v.rank_cap;
             // 8 rows per pass: all (<= 32) 4-byte loads of a pass are issued before the first LDS store, so a
             // thread pays one memory round trip per 8 rows instead of one per row.  A column contributes only
             // where it is stored (its tile span): cells outside hold nothing and count as zero.
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
                 }
 #pragma unroll
                 for (int u = 0; u < UN; ++u)
-                    if (k0 + u * KS < r) big[i * ht_ld + k0 + u * KS] = sacc[u] * w;
+                    if (k0 + u * KS < r) big[i * SI + (k0 + u * KS) * SK] = sacc[u] * w;
             }
         }
     } else {
@@ -311,9 +324,10 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
                     }
                 }
                 if (MODE == IPP_FACTOR) {
-                    const float* hi = big + i * ht_ld;
-                    const float* hj = big + j * ht_ld;
-                    for (int k = sl; k < r; k += GL) acc -= (double)hi[k] * (double)hj[k];
+                    const int SI = (si > 0) ? si : ht_ld, SK = (si > 0) ? sk : 1;
+                    const float* hi = big + i * SI;
+                    const float* hj = big + j * SI;
+                    for (int k = sl; k < r; k += GL) acc -= (double)hi[k * SK] * (double)hj[k * SK];
                 }
             }
 #pragma unroll
@@ -410,15 +424,15 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
     for (int idx = tid; idx < MC * MC; idx += kPrepThreads) {
         const int i = idx / MC, j = idx - i * MC;
         const double val = (!dead && i < m && j < m) ? Li[i * LD + j] : 0.0;
-        linv_out[idx] = (float)val;
-        blk_out[idx] = (float)val;
+        linv_f[idx] = (float)val;
+        if (linv_f2) linv_f2[idx] = (float)val;
         dbg[MC * MC + idx] = val;
         dbg[idx] = (i < m && j < m) ? S[i * LD + j] : 0.0;
     }
     for (int i = tid; i < MC; i += kPrepThreads) {
         const double yval = (!dead && !cov_only && i < m) ? yy[i] : 0.0;
-        y_out[i] = (float)yval;
-        blk_out[MC * MC + i] = (float)yval;
+        y_f[i] = (float)yval;
+        if (y_f2) y_f2[i] = (float)yval;
         dbg[2 * MC * MC + i] = (i < m) ? zz[i] : 0.0;
         dbg[2 * MC * MC + MC + i] = yval;
     }
@@ -430,9 +444,10 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
         if (j < QS) {
             for (int k = tid / QP; k < r; k += kPrepThreads / QP) {
                 double sacc = 0.0;
+                const int SI = (si > 0) ? si : ht_ld, SK = (si > 0) ? sk : 1;
                 if (!dead && j < m)
-                    for (int i = 0; i <= j; ++i) sacc += (double)big[i * ht_ld + k] * Li[i * LD + j];
-                q_out[k * QS + j] = (float)(-sacc);
+                    for (int i = 0; i <= j; ++i) sacc += (double)big[i * SI + k * SK] * Li[i * LD + j];
+                q_out[k * QS + j] = (float)(-sacc);  // (fused kernel: in place over HT row k, reads precede the write)
             }
         }
     } else {
@@ -458,8 +473,31 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
         ho.fallback = fallback;
         if (dead) { ho.commit = 0; ho.rows = 0; }
         v.hdr[item] = ho;
+        *hs = ho;
         if (status_out) status_out[item] = status;
     }
+    return hs;
+}
+
+// Stand-alone prologue kernel: one workgroup per item.
+template <int MC, int MODE>
+__global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(View v, const int* __restrict__ env_ids,
+                                                          const int* __restrict__ dst_ids, int n_items,
+                                                          const double* __restrict__ action,
+                                                          const double* __restrict__ prev_action,
+                                                          const float* __restrict__ meas_noise, unsigned flags,
+                                                          int* __restrict__ status_out, float* __restrict__ obs_out,
+                                                          int* __restrict__ obs_m, int* __restrict__ obs_shape) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int item = blockIdx.x;
+    if (item >= n_items) return;
+    constexpr int LQ = (MC * MC + MC + 3) & ~3;
+    float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]: one block for the gain kernel
+    float* big = reinterpret_cast<float*>(smem + ((prep_small_bytes<MC>() + 15) & ~(size_t)15));
+    prepare_item<MC, MODE, kPrepThreads>(v, item, env_ids, dst_ids, action, prev_action, meas_noise, flags, status_out,
+                                         obs_out, obs_m, obs_shape, smem, big, 0, 1, blk_out + LQ,
+                                         v.linv + (size_t)item * MC * MC, blk_out, v.yv + (size_t)item * MC,
+                                         blk_out + MC * MC, nullptr);
 }
 
 }  // namespace ipp

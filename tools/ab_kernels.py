@@ -24,10 +24,10 @@ from ipp_rl_amd.engine import IPPEngine  # noqa: E402
 from ipp_rl_amd.vec_env import cell_centre_actions  # noqa: E402
 
 
-def make_engine(lib_path, cfg, B, tile_threads):
+def make_engine(lib_path, cfg, B, tile_threads, window_rows=0):
     _ffi._lib = None
     _ffi.LIB_PATH = lib_path
-    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, tile_threads=tile_threads)
+    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, tile_threads=tile_threads, window_rows=window_rows)
     return eng
 
 
@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=60)
+    ap.add_argument("--window-rows", type=int, default=12)
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
     cfg = EngineConfig(x_dim=50, y_dim=50)
@@ -51,7 +52,7 @@ def main():
     for spec in args.variants:
         name, rest = spec.split("=")
         path, _, tt = rest.partition(":")
-        eng = make_engine(os.path.abspath(path), cfg, B, int(tt or 0))
+        eng = make_engine(os.path.abspath(path), cfg, B, int(tt or 0), args.window_rows)
         eng.reset(gt=gt)
         engines.append((name, eng, init.clone()))
     reward = torch.empty(B, dtype=torch.float32, device="cuda")

@@ -86,6 +86,43 @@ __global__ __launch_bounds__(640, 4) void k_stream_fma(const float* __restrict__
     if (t == 123.456f) out[0] = t;
 }
 
+// one wave per item: the wave walks `ntile` 256-cell tiles of its env, streaming `R` rows per tile with 36 FMAs per
+// float4 against 12 values that arrive through SCALAR loads (one Q row per streamed row), 4 waves / SIMD.
+template <int PIPE, bool SCALARQ>
+__global__ __launch_bounds__(64, 4) void k_wave_item(const float* __restrict__ base, size_t slot, int npad, int ntile,
+                                                     const int* __restrict__ rows, const float* __restrict__ q, float* out) {
+    __shared__ __attribute__((aligned(16))) float Qs[368 * 12];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int R = rows[env];
+    const float* __restrict__ qrow = q + (size_t)env * 368 * 12;
+    if (!SCALARQ) { for (int i = lane; i < 368 * 12; i += 64) Qs[i] = qrow[i]; __syncthreads(); }
+    float tot = 0.f;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int t = 0; t < ntile; ++t) {
+        const float* p = base + (size_t)env * slot + (size_t)((t * 3) % 10) * 256 + 4 * lane;
+        float acc[4][9];
+        for (int c = 0; c < 4; ++c) for (int j = 0; j < 9; ++j) acc[c][j] = 0.f;
+        for (int k = 0; k < R; k += PIPE) {
+            f4 v[PIPE];
+#pragma unroll
+            for (int i = 0; i < PIPE; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + (size_t)min(k + i, R - 1) * npad));
+#pragma unroll
+            for (int i = 0; i < PIPE; ++i) {
+                const int kk = min(k + i, R - 1);
+                float qv[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) qv[j] = SCALARQ ? qrow[kk * 12 + j] : Qs[kk * 12 + j];
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c][j] = fmaf(v[i][c], qv[j], acc[c][j]);
+            }
+        }
+        for (int c = 0; c < 4; ++c) for (int j = 0; j < 9; ++j) tot += acc[c][j];
+    }
+    if (tot == 123.456f) out[0] = tot;
+}
+
 int main() {
     const int B = 4096, npad = 2560, rcap = 360;
     const size_t slot = (size_t)rcap * npad;
@@ -105,6 +142,19 @@ int main() {
     };
     time_it([&] { hipLaunchKernelGGL(k_flat, dim3(256 * 8), dim3(256), 0, 0, (const float4*)d, total / 4, out); }, total * 4.0, "flat read 15 GB, 2048x256");
     time_it([&] { hipLaunchKernelGGL(k_flat, dim3(256 * 32), dim3(256), 0, 0, (const float4*)d, total / 4, out); }, total * 4.0, "flat read 15 GB, 8192x256");
+    {
+        float* q; CK(hipMalloc(&q, (size_t)B * 368 * 12 * 4)); CK(hipMemset(q, 0, (size_t)B * 368 * 12 * 4));
+        std::vector<int> h(B);
+        double rs = 0;
+        for (int e = 0; e < B; ++e) { h[e] = (int)(0.6 * 5.9 * ((e % 40) + 0.5)) + 1; rs += h[e]; }
+        CK(hipMemcpy(rows, h.data(), B * 4, hipMemcpyHostToDevice));
+        const int ntile = 6;
+        const double bytes = rs * ntile * 256 * 4.0;
+        time_it([&] { hipLaunchKernelGGL((k_wave_item<2, true>), dim3(B), dim3(64), 0, 0, d, slot, npad, ntile, rows, q, out); }, bytes, "wave-per-item scalarQ pipe2 (6 tiles x 0.6R rows)");
+        time_it([&] { hipLaunchKernelGGL((k_wave_item<4, true>), dim3(B), dim3(64), 0, 0, d, slot, npad, ntile, rows, q, out); }, bytes, "wave-per-item scalarQ pipe4");
+        time_it([&] { hipLaunchKernelGGL((k_wave_item<8, true>), dim3(B), dim3(64), 0, 0, d, slot, npad, ntile, rows, q, out); }, bytes, "wave-per-item scalarQ pipe8");
+        time_it([&] { hipLaunchKernelGGL((k_wave_item<4, false>), dim3(B), dim3(64), 0, 0, d, slot, npad, ntile, rows, q, out); }, bytes, "wave-per-item ldsQ(17KB) pipe4");
+    }
     for (int mode = 0; mode < 2; ++mode) {
         std::vector<int> h(B);
         double rs = 0;
