@@ -50,7 +50,13 @@ def parse():
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--predict-only", action="store_true", help="time the predict-only rate (tree-search call)")
+    ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
     return ap.parse_args()
+
+
+def workload_key(args):
+    return {"envs": args.envs, "grid": args.grid, "state": args.state, "window_rows": args.window_rows,
+            "tile_threads": args.tile_threads, "episode_steps": args.episode_steps, "predict_only": bool(args.predict_only)}
 
 
 def cpu_baseline(cfg, args):
@@ -84,8 +90,31 @@ def cpu_baseline(cfg, args):
     }
 
 
+def pmc_traffic(kernel_name, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command line
+    (tools/pmc_run.sh -> tools/pmc_summary.py -> profiles/*_pmc_summary.json): FETCH_SIZE x 2 (gfx950 correction,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB.  None when no matching summary is committed:
+    counters cannot be collected from inside the timed process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as fh:
+            summary = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    want = summary.get("_bench_args")
+    if want != workload_key(args):
+        return None
+    for name, counters in summary.items():
+        if name.startswith("ipp::" + kernel_name + "<") and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 def main():
     args = parse()
+    if args.print_args:
+        print(json.dumps(workload_key(args)))
+        return
     import torch
     import torch.distributed as dist
 
@@ -177,6 +206,10 @@ def main():
         # 4N(r + m) + 16N bytes per committed step; predict-only reads 4N r + 8N (mean, diag)
         per_step = 4.0 * N * mean_rank_after + (8.0 * N if args.predict_only else 16.0 * N)
         kernel_ms, kernel_name = gain_ms, "k_gain"
+        if int(eng.info.window_rows) > 0:  # mirrors the kernel selection in csrc/ipp_engine.hip launch_chunk()
+            tt = int(eng.info.tile_threads)
+            fused = tt == 256 and os.environ.get("IPP_FUSED", "1") != "0"
+            kernel_name = "k_step_factor" if fused else ("k_gain_wave" if tt == 64 else "k_gain_factor")
     else:
         per_step = (4.0 * N * 25 + 8.0 * N) if args.predict_only else (8.0 * N * N + 16.0 * N)
         kernel_ms, kernel_name = (gain_ms, "k_gain") if args.predict_only else (down_ms, "k_downdate")
@@ -209,8 +242,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches": gain_n if kernel_name == "k_gain" else down_n,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, args),
+                "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "full_column_formula_bytes_per_launch": formula_bytes,
                 "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},

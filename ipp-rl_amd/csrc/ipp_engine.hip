@@ -118,7 +118,7 @@ int plan(const ipp_config& c, Layout& L) {
     if (c.state_repr == IPP_FACTOR && c.window_rows > 0) {
         // windowed factor state: one workgroup per item, wave-granular tiles of 64 * VEC cells (k_gain_factor.h);
         // tile_threads is the workgroup size (waves share the item's Q block and prior table in LDS)
-        L.T = (c.tile_threads > 0) ? c.tile_threads : 64;  // 64: one wave per item (k_gain_wave.h), 256: fused workgroup kernel
+        L.T = (c.tile_threads > 0) ? c.tile_threads : 256;  // 256: fused workgroup kernel (k_step_factor.h), 64: one wave per item (k_gain_wave.h)
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;

@@ -18,8 +18,11 @@
 #include "ipp_common.h"
 #include "k_gain.h"
 
+#ifndef IPP_GW_PINGPONG
+#define IPP_GW_PINGPONG 0
+#endif
 #ifndef IPP_GW_PIPE
-#define IPP_GW_PIPE 4
+#define IPP_GW_PIPE (IPP_GW_PINGPONG ? 4 : 12)  // rows of U requested per group (A/B on MI355X: 4: 0.46 ms, 8: 0.42, 12: 0.40)
 #endif
 #ifndef IPP_GW_ABLATE
 #define IPP_GW_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no Q loads
@@ -158,7 +161,13 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
         if (nact > 0) {
             const int last = r - 1;
             auto col_of = [&](int a) -> int { return __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]); };
-            auto consume = [&](const float (&u)[KP][VEC], const int (&kq)[KP]) {
+            // the row registers stay VEC-wide vector values so that the loop-carried group is one register tuple per
+            // row (scalarised, the back edge needs copies, and every copy waits for its load)
+            typedef float rowv __attribute__((ext_vector_type(VEC)));
+            auto fetch = [&](int k) -> rowv {
+                return __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)min(k, last) * npad + cell0));
+            };
+            auto consume = [&](const rowv (&u)[KP], const int (&kq)[KP]) {
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     const float* __restrict__ qr = qrows + (size_t)kq[i] * QS;
@@ -171,27 +180,45 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
                         for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(u[i][c], qv[j], acc[c][j]);
                 }
             };
-            float ua[KP][VEC], ub[KP][VEC];
+#if IPP_GW_PINGPONG
+            rowv ua[KP], ub[KP];
             int ka[KP], kb[KP];
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
                 ka[i] = col_of(i);
-                load_stream<VEC>(cov_src + (size_t)min(ka[i], last) * npad + cell0, ua[i]);
+                ua[i] = fetch(ka[i]);
             }
             for (int a = 0; a < nact; a += 2 * KP) {
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     kb[i] = col_of(a + KP + i);
-                    load_stream<VEC>(cov_src + (size_t)min(kb[i], last) * npad + cell0, ub[i]);
+                    ub[i] = fetch(kb[i]);
                 }
                 consume(ua, ka);
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     ka[i] = col_of(a + 2 * KP + i);
-                    load_stream<VEC>(cov_src + (size_t)min(ka[i], last) * npad + cell0, ua[i]);
+                    ua[i] = fetch(ka[i]);
                 }
                 consume(ub, kb);
             }
+#else
+            // Groups of KP rows, requested together and then consumed in order.  No row registers are carried
+            // across the back edge: hipcc turns a carried (ping-pong) group into register copies at the loop end,
+            // and each copy waits for its load, which empties the memory pipe once per iteration.  Overlap across
+            // groups comes from the other 15 waves of the CU.
+            for (int a = 0; a < nact; a += KP) {
+                rowv u[KP];
+                int kk[KP];
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    kk[i] = col_of(a + i);
+                    u[i] = fetch(kk[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
+                consume(u, kk);
+            }
+#endif
         }
 
         // ---- epilogue for this tile

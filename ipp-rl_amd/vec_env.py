@@ -49,6 +49,8 @@ def cell_centre_actions(cfg: EngineConfig, step: int, env_lo: int, env_hi: int, 
 
 
 class VecIPPEnv:
+    NOISE_RING = 16
+
     def __init__(self, cfg: EngineConfig, num_envs: int, state: str = "factor", episode_steps: int = 40,
                  device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
                  rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
@@ -76,16 +78,22 @@ class VecIPPEnv:
         self.phase = (torch.arange(B, device=dev) + self.env_id_offset) % self.episode_steps if stagger else \
             torch.zeros(B, dtype=torch.int64, device=dev)
         self.t = 0
-        self.episode = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.episode = np.zeros(B, dtype=np.int64)  # completed-episode counters (host side, never read by kernels)
         self._reset_ids_by_phase = None
         if stagger:
-            self._reset_ids_by_phase = [
-                torch.nonzero(self.phase == p).flatten().to(torch.int32) for p in range(self.episode_steps)
-            ]
+            ph = self.phase.cpu().numpy()
+            self._reset_ids_host = [np.nonzero(ph == p)[0].astype(np.int32) for p in range(self.episode_steps)]
+            self._reset_ids_by_phase = [torch.as_tensor(i, device=dev) for i in self._reset_ids_host]
+            # per-phase index tensors / rows for the single index_copy_ that returns the UAVs to init_action
+            self._reset_idl_by_phase = [i.long() for i in self._reset_ids_by_phase]
+            self._reset_prev_rows = [self.init_prev[i] for i in self._reset_idl_by_phase]
         self._white = torch.empty((B, cfg.n_cells), dtype=torch.float32, device=dev)
-        # staggered runs prepare the next reset's ground truths on a side stream while the step kernels run
-        # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip)
+        # staggered runs prepare the next resets' ground truths on a side stream while the step kernels run
+        # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
+        # for the resets after step t+1 is started at the beginning of step t, so it has two steps to finish
         self._side = torch.cuda.Stream(device=dev) if stagger else None
+        self._pending = None      # (ids, buffer, n) staged for the resets at the end of the current step
+        self._pending_for = -1    # step index the staged fields belong to
         if stagger:
             n_max = max(int(i.numel()) for i in self._reset_ids_by_phase)
             self._staged = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -94,7 +102,10 @@ class VecIPPEnv:
             self._staged_free = [torch.cuda.Event() for _ in range(2)]
             for ev in self._staged_free:
                 ev.record(torch.cuda.current_stream(dev))
-        self._noise = torch.empty((B, self.engine.meas_cap), dtype=torch.float32, device=dev)
+        # measurement noise for NOISE_RING steps per generator launch
+        self._noise_ring = torch.empty((self.NOISE_RING, B, self.engine.meas_cap), dtype=torch.float32, device=dev)
+        self._noise_pos = 0
+        self._noise_fills = 0
         self.reward = torch.empty(B, dtype=torch.float32, device=dev)
         self.status = torch.empty(B, dtype=torch.int32, device=dev)
         self._flags = (4 if adaptive else 0) | (8 if use_flight_time else 0)
@@ -110,10 +121,12 @@ class VecIPPEnv:
             out[k, 1] = rs.uniform(0.8 * self.cfg.length_scale, 1.2 * self.cfg.length_scale)
         return out
 
-    def reset(self, env_ids=None, white_noise=None, gt=None, prior_scale=None):
+    def reset(self, env_ids=None, white_noise=None, gt=None, prior_scale=None, _phase=None):
         """Reset the given slots (all when None).  white_noise / gt: [n, H, W] NumPy or tensor (parity)."""
         torch = self.torch
-        if env_ids is None:
+        if _phase is not None:  # scheduled reset of step(): index tensors prepared at construction
+            ids = self._reset_ids_by_phase[_phase]
+        elif env_ids is None:
             ids = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
         else:
             ids = torch.as_tensor(env_ids, dtype=torch.int32, device=self.device)
@@ -128,9 +141,38 @@ class VecIPPEnv:
         if prior_scale is None and self.shuffle_prior_cov:
             prior_scale = self._prior_scale(ids.cpu().numpy(), self.t)
         self.engine.reset(env_ids=ids, prior_scale=prior_scale, gt=gt, white_noise=white_noise)
-        idl = ids.long()
-        self.prev[idl] = self.init_prev[idl]
-        self.episode[idl] += 1
+        if _phase is not None:
+            self.prev.index_copy_(0, self._reset_idl_by_phase[_phase], self._reset_prev_rows[_phase])
+            self.episode[self._reset_ids_host[_phase]] += 1
+        else:
+            idl = ids.long()
+            self.prev.index_copy_(0, idl, self.init_prev[idl])
+            if env_ids is None:
+                self.episode += 1
+            elif not torch.is_tensor(env_ids):
+                self.episode[np.asarray(env_ids, dtype=np.int64)] += 1
+            else:
+                self.episode[ids.cpu().numpy()] += 1
+
+    def _phase_ending_at(self, t: int) -> int:
+        """Phase whose envs finish their episode with step index t: env e has done (t + 1 + phase_e) steps."""
+        return (self.episode_steps - ((t + 1) % self.episode_steps)) % self.episode_steps
+
+    def _stage(self, t: int):
+        """Start, on the side stream, the ground truths for the resets at the end of step index t."""
+        torch = self.torch
+        p = self._phase_ending_at(t)
+        n = int(self._reset_ids_by_phase[p].numel())
+        if n == 0:
+            return None
+        k = t % 2
+        self._side.wait_event(self._staged_free[k])
+        with torch.cuda.stream(self._side):
+            white = self._staged_white[k][:n]
+            self.engine.normal(n * self.cfg.n_cells, self.seed, self._subseq_for_reset(), out=white)
+            self.engine.generate_grf(white, out=self._staged[k][:n], stream=self._side)
+            self._staged_ready[k].record(self._side)
+        return (p, k, n)
 
     def _subseq_for_reset(self) -> int:
         self._reset_calls = getattr(self, "_reset_calls", 0) + 1
@@ -148,25 +190,22 @@ class VecIPPEnv:
         main = torch.cuda.current_stream(self.device)
         scheduled = None
         if auto_reset and self._reset_ids_by_phase is not None:
-            # envs whose episode ends with this step: env e has done (t + 1 + phase_e) steps modulo T afterwards
-            p = (self.episode_steps - ((self.t + 1) % self.episode_steps)) % self.episode_steps
-            ids = self._reset_ids_by_phase[p]
-            if ids.numel() and self.shuffle_prior_cov is False:
-                k = self.t % 2
-                n = int(ids.numel())
-                self._side.wait_event(self._staged_free[k])
-                with torch.cuda.stream(self._side):
-                    white = self._staged_white[k][:n]
-                    self.engine.normal(n * self.cfg.n_cells, self.seed, self._subseq_for_reset(), out=white)
-                    self.engine.generate_grf(white, out=self._staged[k][:n])
-                    self._staged_ready[k].record(self._side)
-                scheduled = (ids, k, n)
-            elif ids.numel():
-                scheduled = (ids, None, int(ids.numel()))
+            if self.shuffle_prior_cov is False:
+                if self._pending_for != self.t:  # first step (or the schedule was disturbed): stage for this step now
+                    self._pending, self._pending_for = self._stage(self.t), self.t
+                scheduled = self._pending
+                self._pending, self._pending_for = self._stage(self.t + 1), self.t + 1
+            else:
+                p = self._phase_ending_at(self.t)
+                if self._reset_ids_by_phase[p].numel():
+                    scheduled = (p, None, int(self._reset_ids_by_phase[p].numel()))
         if meas_noise is None:
-            nz = self._noise
-            self._step_calls = getattr(self, "_step_calls", 0) + 1
-            self.engine.normal(nz.numel(), self.seed ^ 0x5DEECE66D, (self.env_id_offset << 24) + self._step_calls, out=nz)
+            if self._noise_pos == 0:
+                self._noise_fills += 1
+                self.engine.normal(self._noise_ring.numel(), self.seed ^ 0x5DEECE66D,
+                                   (self.env_id_offset << 24) + self._noise_fills, out=self._noise_ring)
+            nz = self._noise_ring[self._noise_pos]
+            self._noise_pos = (self._noise_pos + 1) % self.NOISE_RING
         else:
             nz = meas_noise
         self.engine.step(a, self.prev, env_ids=env_ids, meas_noise=nz, adaptive=self.adaptive,
@@ -179,12 +218,12 @@ class VecIPPEnv:
         if after_step_hook is not None:
             after_step_hook()
         if scheduled is not None:
-            ids, k, n = scheduled
+            p, k, n = scheduled
             if k is None:
-                self.reset(ids)
+                self.reset(_phase=p)
             else:
                 main.wait_event(self._staged_ready[k])
-                self.reset(ids, gt=self._staged[k][:n])
+                self.reset(gt=self._staged[k][:n], _phase=p)
                 self._staged_free[k].record(main)
         return self.reward, self.status
 

@@ -239,6 +239,52 @@ def test_vec_env_staged_ground_truth_matches_direct_reset():
     assert np.max(np.abs(gt - ref)) < TOL
 
 
+def test_vec_env_staggered_schedule_and_determinism():
+    """Staggered VecIPPEnv loop (bench driver): scheduled resets land on the right envs at the right steps, the
+    side-stream ground truths staged one step ahead are the ones a direct reset would draw, and two instances
+    with the same seed agree bit for bit (no dependence on stream timing)."""
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+    import torch
+
+    dim, B, T, steps = 20, 24, 6, 15
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    alts = [6.0, 8.0, 12.0]
+    envs = [VecIPPEnv(cfg, B, state="factor", episode_steps=T, seed=77, stagger=True, window_rows=w)
+            for w in (0, 0, 100)]
+    for env in envs:
+        env.reset()
+    phase = envs[0].phase.cpu().numpy()
+    m_hist = np.zeros(B, dtype=np.int64)
+    rewards = []
+    for t in range(steps):
+        acts = cell_centre_actions(cfg, t, 0, B, B, alts)
+        out = []
+        for env in envs:
+            r, s = env.step(acts)
+            assert int(s.abs().sum()) == 0
+            out.append(r.clone())
+        assert torch.equal(out[0], out[1])
+        assert torch.allclose(out[0], out[2], atol=1e-5, rtol=1e-5)  # window covering the whole grid == exact columns
+        rewards.append(host(out[0]))
+        ranks = host(envs[0].engine.ranks())
+        done = (t + 1 + phase) % T == 0  # env e finishes an episode after (t + 1 + phase_e) steps
+        assert np.all(ranks[done] == 0) and np.all(ranks[~done] > 0)
+        assert np.array_equal(envs[0].episode, 1 + (t + 1 + phase) // T)  # 1: the initial reset of every slot
+        prev = host(envs[0].prev)
+        assert np.allclose(prev[done], [2.0, 2.0, 14.0]) and np.allclose(prev[~done], acts[~done])
+    for e in range(B):
+        assert np.array_equal(host(envs[0].ground_truth(e)), host(envs[1].ground_truth(e)))
+    # the staged fields are a pure function of (seed, reset-call counter): a third party can regenerate one
+    env = envs[0]
+    last_p = env._phase_ending_at(steps - 1)
+    ids = env._reset_ids_host[last_p]
+    calls_before = steps  # one staging call per step with a non-empty phase (every phase is non-empty here), +1 ahead
+    white = env.engine.normal(len(ids) * dim * dim, env.seed, (env.env_id_offset << 24) + calls_before + 1)
+    gt = env.engine.generate_grf(white.reshape(len(ids), -1))
+    assert np.array_equal(host(gt[0]), host(env.ground_truth(int(ids[0]))).reshape(-1))
+
+
 def test_philox_normals_deterministic_and_standard():
     from ipp_rl_amd import EngineConfig, IPPEngine
 

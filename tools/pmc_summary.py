@@ -30,4 +30,8 @@ for k, cs in acc.items():
         continue
     out[k] = {c: sum(v) / len(v) for c, v in cs.items()}
     out[k]["dispatches"] = max(len(v) for v in cs.values())
+key_path = os.path.join(root, "bench_args.json")  # written by tools/pmc_run.sh: the bench command line the passes ran
+if os.path.exists(key_path):
+    with open(key_path) as fh:
+        out["_bench_args"] = json.load(fh)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-end measurement on the GPU box: tests, bench lines, kernel trace, PMC passes. Outputs under gpurun_out/round/.
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/round; rm -rf $O; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-400
+python bench.py --no-cpu-baseline --window-rows 0 > $O/bench_exact.log 2>&1; tail -1 $O/bench_exact.log | cut -c1-300
+python bench.py --no-cpu-baseline --tile-threads 64 > $O/bench_wave.log 2>&1; tail -1 $O/bench_wave.log | cut -c1-300
+python bench.py --no-cpu-baseline --state dense --envs 256 > $O/bench_dense.log 2>&1; tail -1 $O/bench_dense.log | cut -c1-300
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o kt -- python3 bench.py --no-cpu-baseline > $O/trace.log 2>&1
+find $O/trace -name "*kernel_stats.csv" | head -2
+bash tools/pmc_run.sh $O/pmc > $O/pmc_run.log 2>&1
+python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 300 $O/pmc_summary.json
+# keep the merge-back small: drop raw per-dispatch csvs except stats
+find $O/pmc -name "*.csv" -size +2M -delete; find $O/trace -name "*kernel_trace.csv" -size +2M -delete
+du -sh $O
