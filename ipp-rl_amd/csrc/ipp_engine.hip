@@ -79,7 +79,8 @@ struct Layout {
 
 uint64_t q_item_floats(const Layout& L) {
     const uint64_t lq = ((uint64_t)L.MC * L.MC + L.MC + 3) & ~(uint64_t)3;
-    return lq + (uint64_t)(L.q_rows + 8) * L.QS;
+    // multiple of 16 floats: item blocks start on 64-byte lines (no scalar-cache line shared between two items)
+    return (lq + (uint64_t)(L.q_rows + 8) * L.QS + 15) & ~(uint64_t)15;
 }
 
 int plan(const ipp_config& c, Layout& L) {
@@ -251,7 +252,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                   hipEvent_t prep_done) {
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
         ProfScope ps(e, 0, s);
-        hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev,
+        hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, v.q, env_ids, n, action, prev,
                            noise, flags, e->lut_cap, status, reward);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
@@ -272,7 +273,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
         if (v.mode == IPP_FACTOR && v.window_rows > 0 && v.T == kWave)
             hipLaunchKernelGGL((k_gain_wave<MC, VEC>), dim3(n), dim3(kWave), e->gain_lds, s, v, v.q, n, flags, reward);
         else if (v.mode == IPP_FACTOR && v.window_rows > 0)
-            hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, n, flags, e->lut_cap, reward);
+            hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_cap, reward);
         else if (v.mode == IPP_FACTOR)
             hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
         else
@@ -426,9 +427,13 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         const size_t MCs = v.meas_cap, LQ = (MCs * MCs + MCs + 3) & ~(size_t)3;
         e->fused = (v.T == kStepThreads);
         if (const char* fu = getenv("IPP_FUSED")) e->fused = e->fused && atoi(fu) != 0;  // A/B experiments
-        const int lutf = e->fused ? ((v.meas_cap == 9) ? step_scratch_floats<9>(e->lut_cap) : step_scratch_floats<25>(e->lut_cap)) : e->lut_cap;
-        e->gain_lds = (LQ + (size_t)(v.rank_cap + 8) * v.q_stride + ((lutf + 3) & ~3)) * 4 + 16 * 8 +
-                      (size_t)v.rank_cap * 4 + (size_t)(v.T / 64) * (v.rank_cap + 8) * 2;
+        const int waves = v.T / 64;
+        if (v.meas_cap == 9)
+            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap, e->lut_cap), step_small_floats<9>(), waves)
+                                   : GainLds<9>::bytes(v.rank_cap, e->lut_cap, 0, waves);
+        else
+            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap, e->lut_cap), step_small_floats<25>(), waves)
+                                   : GainLds<25>::bytes(v.rank_cap, e->lut_cap, 0, waves);
         if (v.T == kWave)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;

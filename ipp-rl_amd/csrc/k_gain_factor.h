@@ -2,22 +2,28 @@
 //
 //   Wc = P0[:,F] H_F^T L^-1  -  U (U[F,:]^T H_F^T L^-1)          (mapping/mappings.py:188, P = P0 - U U^T)
 //
-// The workgroup stages the item's scratch block ([L^-1 | y | Q], written by k_prepare) and the prior table
-// P0(|drow|, |dcol|) in LDS once; then every wave walks over the (64 x VEC)-cell tiles assigned to it.  Per tile a wave
+// The workgroup keeps L^-1, y, the tile spans of the stored columns and the prior table P0(|drow|, |dcol|) in LDS;
+// every wave then walks over (64 x VEC)-cell tiles handed out by an LDS counter.  Per tile a wave
 //   * compacts (ballot / popcount, in increasing k) the columns of U that are stored on the tile -- all of them
 //     when window_rows == 0, else those whose footprint lies within window_rows grid rows (ipp_config),
-//   * evaluates the prior term from the table, streams the stored rows (1 KiB per wave instruction,
-//     non-temporal, 2 x KP deep ping-pong) against Q broadcast from LDS,
+//   * evaluates the prior term from the table (4 x VEC lookups in flight per measurement block),
+//   * streams the stored rows in groups of KP (1 KiB per wave instruction, non-temporal) against Q rows that
+//     arrive through the SCALAR cache: Q row k is wave-uniform, so it is read from the item's global scratch
+//     block with s_load and used as an SGPR operand of the FMAs -- no VGPRs and no LDS for Q, which is what
+//     leaves room for KP = 12 rows (12 KiB) in flight per wave at 4 waves / SIMD,
 //   * runs the fused epilogue: masked trace reduction (reward), diag -= |Wc_i|^2, mean += Wc y, append the m new
 //     rows of U on the tile (planning/common/rewards.py:8-31, mapping/mappings.py:190-197).
-// Tiles are handed out to waves dynamically; there is no workgroup barrier inside the tile loop; tiles outside the span of the appended columns are skipped.
+// No workgroup barrier inside the tile loop; tiles outside the span of the appended columns are skipped.
 // HBM-bound: 4*MC FMAs per streamed float4; the prologue is paid once per item, not once per tile.
 #pragma once
 #include "ipp_common.h"
 #include "k_gain.h"
 
 #ifndef IPP_GF_PIPE
-#define IPP_GF_PIPE 2
+#define IPP_GF_PIPE 12  // rows of U requested per group, stand-alone gain kernel
+#endif
+#ifndef IPP_SF_PIPE
+#define IPP_SF_PIPE 8   // same, fused step kernel (A/B on MI355X: 6: see DESIGN.md, 8: 0.428 ms, 10: 0.436, 12: 0.446)
 #endif
 #ifndef IPP_GF_MINWAVES
 #define IPP_GF_MINWAVES 4
@@ -26,36 +32,65 @@
 namespace ipp {
 
 // LDS layout shared by k_gain_factor and k_step_factor.
+//   work: prior table (lut_floats) -- in the fused kernel first the prologue's HT staging rows, which are dead
+//         once Q has been written to the item's global scratch block
+//   small: the fused prologue's fp64 scratch (0 floats for the stand-alone gain kernel)
 template <int MC>
 struct GainLds {
     static constexpr int QS = (MC + 3) & ~3;
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
-    float* Ls; float* ys; float* Qs; float* lut; double* red; int* next_tile; int* done_waves; int* span_s;
-    unsigned short* ridx_all;
-    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int lut_floats) {
+    float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
+    int* span_s; int* fb_yx; float* fb_w; unsigned short* ridx_all;
+    __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int small_floats, int waves) {
+        size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
+        b += (size_t)rank_cap * 4 + (size_t)8 * MC * 4 + (size_t)waves * (rank_cap + 8) * 2;
+        return (b + 15) & ~(size_t)15;
+    }
+    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int small_floats) {
         Ls = reinterpret_cast<float*>(base);
         ys = Ls + MC * MC;
-        Qs = Ls + LQ;
-        lut = Qs + (size_t)(rank_cap + 8) * QS;
-        red = reinterpret_cast<double*>(lut + ((lut_floats + 3) & ~3));
+        work = Ls + LQ;
+        lut = work;
+        small = reinterpret_cast<unsigned char*>(work + ((work_floats + 3) & ~3));
+        red = reinterpret_cast<double*>(small + (size_t)((small_floats + 3) & ~3) * 4);
         next_tile = reinterpret_cast<int*>(red + 15);  // red[15] is unused by the reduction
         done_waves = next_tile + 1;
         span_s = reinterpret_cast<int*>(red + 16);
-        ridx_all = reinterpret_cast<unsigned short*>(span_s + rank_cap);
+        fb_yx = span_s + rank_cap;                         // [MC][4] footprint cell (row << 16 | col) of block b
+        fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);   // [MC][4] weight of that cell (0 for padding)
+        ridx_all = reinterpret_cast<unsigned short*>(fb_w + 4 * MC);
     }
 };
 
-// Tile loop + per-item results; expects Ls / ys / Qs (rows 0..r-1 and a zero row r), the prior table (when
-// use_lut), span_s[0..r) and the two counters (zeroed) in LDS, visible to the whole workgroup.
-template <int MC, int VEC>
+// Measurement blocks of the footprint (sensors/models/sensor_models.py:57-79) as flat (cell, weight) tables.
+template <int MC>
+__device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, float* fb_w) {
+    const int tid = threadIdx.x;
+    if (tid < MC) {
+        const int m = h.m;
+        const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);
+        for (int a = 0; a < 4; ++a) {
+            const int aa = min(a, bb.count() - 1);
+            fb_yx[4 * tid + a] = ((h.yu + bb.y0 + aa / bb.bw) << 16) | (h.xl + bb.x0 + aa % bb.bw);
+            fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
+        }
+    }
+}
+
+// Tile loop + per-item results; expects Ls / ys, the block tables, the prior table (when use_lut), span_s[0..r)
+// and the two counters (zeroed) in LDS, visible to the whole workgroup.
+// qrows: the item's Q rows [k][QS] in global scratch, followed by >= 8 zero rows.  It must be a pointer the
+// compiler can prove read-only (a `const float* __restrict__` kernel argument): only then are the wave-uniform row
+// reads emitted as scalar loads.
+template <int MC, int VEC, int KP>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, bool use_lut,
-                                           const GainLds<MC>& lds, float* __restrict__ reward_out) {
+                                           const GainLds<MC>& lds, const float* __restrict__ qrows,
+                                           float* __restrict__ reward_out) {
     constexpr int kWaveTile = VEC * kWave;  // cells per wave tile
-    constexpr int KP = IPP_GF_PIPE;          // rows per ping-pong group (2 groups in flight per wave)
     constexpr int QS = (MC + 3) & ~3;
-    float* Ls = lds.Ls; float* ys = lds.ys; float* Qs = lds.Qs; float* lut = lds.lut; double* red = lds.red;
-    int* next_tile = lds.next_tile; int* done_waves = lds.done_waves; int* span_s = lds.span_s;
-    unsigned short* ridx_all = lds.ridx_all;
+    const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut; double* red = lds.red;
+    int* next_tile = lds.next_tile; int* done_waves = lds.done_waves; const int* span_s = lds.span_s;
+    const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid / kWave, nw = T / kWave;
     const int m = h.m, r = h.rank;
@@ -63,7 +98,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
-    unsigned short* ridx = ridx_all + (size_t)wave * (v.rank_cap + 8);
+    unsigned short* ridx = lds.ridx_all + (size_t)wave * (v.rank_cap + 8);
     const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
     const size_t npad = (size_t)v.Npad;
     double wave_part = 0.0;
@@ -102,59 +137,69 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         for (int c = 0; c < VEC; ++c)
 #pragma unroll
             for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+        {
+            int crow[VEC], ccol[VEC];
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            const int cell = min(cell0 + c, v.N - 1);
-            const int row = cell / v.W, col = cell - row * v.W;
+            for (int c = 0; c < VEC; ++c) {
+                const int cell = min(cell0 + c, v.N - 1);
+                crow[c] = cell / v.W;
+                ccol[c] = cell - crow[c] * v.W;
+            }
+            // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
+            // flight, so the LDS latency is paid once per block instead of once per lookup
             for (int b = 0; b < m; ++b) {
-                const Block blk = block_of(b, h.nx, h.rf, h.w, h.h);
-                float cb = 0.f;
-                for (int a = 0; a < blk.count(); ++a) {
-                    const int ly = blk.y0 + a / blk.bw, lx = blk.x0 + a % blk.bw;
-                    const int dr = abs(row - (h.yu + ly)), dc = abs(col - (h.xl + lx));
-                    cb += use_lut ? lut[dr * v.W + dc] : matern_f(dr, dc, s3, h.sv);
-                }
-                cb *= (float)blk.weight;
+                float cb[VEC];
 #pragma unroll
-                for (int j = 0; j < MC; ++j) acc[c][j] = fmaf(cb, Ls[b * MC + j], acc[c][j]);
+                for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int yx = fb_yx[4 * b + a];
+                    const float wa = fb_w[4 * b + a];
+                    const int fy = yx >> 16, fx = yx & 0xffff;
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+                        const int dr = abs(crow[c] - fy), dc = abs(ccol[c] - fx);
+                        const float p0 = use_lut ? lut[dr * v.W + dc] : matern_f(dr, dc, s3, h.sv);
+                        cb[c] = fmaf(wa, p0, cb[c]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MC; ++j) {
+                    const float l = Ls[b * MC + j];
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                }
             }
         }
 
         // ---- stream the stored rows: acc += row_k[cells] * Q[k,:]  (Q carries the sign of the downdate)
-        {
-            const int last = max(r - 1, 0);
-            auto urow = [&](int a) -> const float* {
-                const int k = __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]);
-                return cov_src + (size_t)min(k, last) * npad + cell0;
-            };
-            auto consume = [&](const float (&u)[KP][VEC], int abase) {
+        if (nact > 0) {
+            const int last = r - 1;
+            typedef float rowv __attribute__((ext_vector_type(VEC)));
+            auto col_of = [&](int a) -> int { return __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]); };
+            // Groups of KP rows, requested together and then consumed in order.  No row registers are carried
+            // across the back edge: hipcc turns a carried (ping-pong) group into register copies at the loop end,
+            // and each copy waits for its load, which empties the memory pipe once per iteration.  Overlap across
+            // groups comes from the other waves of the CU.  Indices past nact hit the zero Q row.
+            for (int a = 0; a < nact; a += KP) {
+                rowv u[KP];
+                int kk[KP];
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
-                    const int k = __builtin_amdgcn_readfirstlane((int)ridx[abase + i]);
-                    float qv[QS];
+                    kk[i] = col_of(a + i);
+                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)min(kk[i], last) * npad + cell0));
+                }
+                __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
 #pragma unroll
-                    for (int t4 = 0; t4 < QS / 4; ++t4) {
-                        const float4 q4 = *reinterpret_cast<const float4*>(&Qs[k * QS + 4 * t4]);
-                        qv[4 * t4 + 0] = q4.x; qv[4 * t4 + 1] = q4.y; qv[4 * t4 + 2] = q4.z; qv[4 * t4 + 3] = q4.w;
-                    }
+                for (int i = 0; i < KP; ++i) {
+                    const float* __restrict__ qr = qrows + (size_t)kk[i] * QS;  // wave-uniform -> s_load
+                    float qv[MC];
+#pragma unroll
+                    for (int j = 0; j < MC; ++j) qv[j] = qr[j];
 #pragma unroll
                     for (int j = 0; j < MC; ++j)
 #pragma unroll
                         for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(u[i][c], qv[j], acc[c][j]);
-                }
-            };
-            if (nact > 0) {
-                float ua[KP][VEC], ub[KP][VEC];
-#pragma unroll
-                for (int i = 0; i < KP; ++i) load_stream<VEC>(urow(i), ua[i]);
-                for (int a = 0; a < nact; a += 2 * KP) {
-#pragma unroll
-                    for (int i = 0; i < KP; ++i) load_stream<VEC>(urow(a + KP + i), ub[i]);
-                    consume(ua, a);
-#pragma unroll
-                    for (int i = 0; i < KP; ++i) load_stream<VEC>(urow(a + 2 * KP + i), ua[i]);
-                    // second half of the ping-pong: indices a + KP .. may run past nact: they hit the zero Q row
-                    consume(ub, min(a + KP, nact));
                 }
             }
         }
@@ -228,14 +273,15 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     if (h.commit && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
 }
 
-// Stand-alone gain kernel (after k_prepare): stages the item's scratch block and the prior table, then gain_tiles.
+// Stand-alone gain kernel (after k_prepare): stages L^-1 | y, the spans and the prior table, then gain_tiles.
+// q_all == v.q, passed separately so that it is a read-only kernel argument (scalar loads of the Q rows).
 template <int MC, int VEC>
-__global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, int n_items, unsigned flags, int lut_cap,
+__global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, const float* __restrict__ q_all, int n_items,
+                                                                   unsigned flags, int lut_cap,
                                                                    float* __restrict__ reward_out) {
-    constexpr int QS = (MC + 3) & ~3;
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    const GainLds<MC> lds(smem_gf, v.rank_cap, lut_cap);
+    const GainLds<MC> lds(smem_gf, v.rank_cap, lut_cap, 0);
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -245,14 +291,11 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, in
         if (tid == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;
         return;
     }
-    {
-        const float4* src = reinterpret_cast<const float4*>(v.q + (size_t)item * v.q_item);
-        float4* dst = reinterpret_cast<float4*>(lds.Ls);
-        const int blk4 = (LQ + (r + 8) * QS) / 4;  // k_prepare zero-fills the 8 rows after Q: row r is the zero row
-        for (int i = tid; i < blk4; i += T) dst[i] = src[i];
-    }
+    const float* __restrict__ blk = q_all + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]
+    for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; }
     for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
+    fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
     const bool use_lut = v.N <= lut_cap;
     if (use_lut) {
         const float s3 = (float)(kSqrt3 * v.res) / h.ls;
@@ -262,7 +305,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, in
         }
     }
     __syncthreads();
-    gain_tiles<MC, VEC>(v, h, item, flags, use_lut, lds, reward_out);
+    gain_tiles<MC, VEC, IPP_GF_PIPE>(v, h, item, flags, use_lut, lds, blk + LQ, reward_out);
 }
 
 }  // namespace ipp
