@@ -54,6 +54,17 @@ def parse():
     return ap.parse_args()
 
 
+def baseline_config_name(args):
+    """Which BASELINE.json config the command line is."""
+    if args.grid == 50 and args.envs == 4096 and args.episode_steps == 40:
+        return "BASELINE configs[1]"
+    if args.grid == 100 and args.envs == 32768 and args.episode_steps == 16:
+        return "BASELINE configs[2]"
+    if args.grid == 50 and args.envs == 32768 and args.episode_steps == 40:
+        return "BASELINE configs[3] (per-GPU share)"
+    return "custom config"
+
+
 def workload_key(args):
     return {"envs": args.envs, "grid": args.grid, "state": args.state, "window_rows": args.window_rows,
             "tile_threads": args.tile_threads, "episode_steps": args.episode_steps, "predict_only": bool(args.predict_only)}
@@ -214,7 +225,9 @@ def main():
         per_step = (4.0 * N * 25 + 8.0 * N) if args.predict_only else (8.0 * N * N + 16.0 * N)
         kernel_ms, kernel_name = (gain_ms, "k_gain") if args.predict_only else (down_ms, "k_downdate")
     formula_bytes = per_step * B  # SURVEY 8(d) formula with full columns
-    bytes_per_launch = counted_bytes if (args.state == "factor" and not args.predict_only) else formula_bytes
+    # factor state: the device counter holds what the launch really streamed (windowed columns, SURVEY 8(d): "N must be
+    # replaced by the window size actually streamed"); dense state: the formula is exact
+    bytes_per_launch = counted_bytes if args.state == "factor" else formula_bytes
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     if rank == 0:
@@ -232,7 +245,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: {B} parallel envs per GPU, {args.grid}x{args.grid} grid, 10 altitude "
+                "workload": f"{baseline_config_name(args)}: {B} parallel envs per GPU, {args.grid}x{args.grid} grid, 10 altitude "
                             f"levels 5-14 m, example.yaml sensor/prior/UAV, GRF ground truth, adaptive reward with "
                             f"flight-time cost; {'predict-only (reward) calls' if args.predict_only else 'full fused env step (predict + observe + update)'}",
                 "envs_per_gpu": B, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,

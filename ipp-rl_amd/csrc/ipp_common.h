@@ -55,6 +55,8 @@ struct View {
     double* partial; // [max_batch][n_tiles]
     double* dbg;     // [max_batch][2*MC*MC + 2*MC]   S, Linv, z, y in fp64 (tests)
     double* grf_h;   // [H][W] circular-convolution kernel of the GRF
+    double2* grf_cs; // [W] (cos, sin)(2 pi j / W)          (k_grf_dft.h)
+    double* grf_g;   // [H/2+1][W] column-convolution kernels  (k_grf_dft.h)
     float* grf_raw;  // [max_batch][Npad] un-normalised field (ipp_reset)
     float* grf_raw2; // [max_batch][Npad] un-normalised field (ipp_generate_grf, may run on a side stream)
 };

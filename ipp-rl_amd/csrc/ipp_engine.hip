@@ -18,6 +18,7 @@
 #include "k_step_factor.h"
 #include "k_gain_wave.h"
 #include "k_misc.h"
+#include "k_grf_dft.h"
 #include "k_prepare.h"
 
 using namespace ipp;
@@ -60,6 +61,8 @@ struct Engine {
     size_t prep_lds;
     size_t gain_lds;
     int q_chunk;
+    bool grf_dft = false;  // even square grids up to 100: k_grf_dft instead of k_grf_conv + k_grf_norm
+    int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
     bool profile = false;
     int step_chunks = 0;  // 0 = auto
@@ -74,7 +77,7 @@ struct Engine {
 struct Layout {
     int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
-        off_partial, off_dbg, off_grfh, off_grfraw, off_grfraw2, total, cov_slot_floats;
+        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, total, cov_slot_floats;
 };
 
 uint64_t q_item_floats(const Layout& L) {
@@ -144,6 +147,8 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_partial = o; o += up(mb * L.n_tiles * 8);
     L.off_dbg = o; o += up(mb * (2 * L.MC * L.MC + 2 * L.MC) * 8);
     L.off_grfh = o; o += up((uint64_t)L.N * 8);
+    L.off_grfcs = o; o += up((uint64_t)c.x_dim * 16);                       // (cos, sin)(2 pi j / n)
+    L.off_grfg = o; o += up((uint64_t)(c.y_dim / 2 + 1) * c.x_dim * 8);    // g_k[d], k = 0 .. n/2 (k_grf_dft.h)
     L.off_grfraw = o; o += up(mb * np * 4);
     L.off_grfraw2 = o; o += up(mb * np * 4);
     L.total = o;
@@ -333,9 +338,46 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
 }
 
 // white [n][N] -> normalised field, either into the env slots (gt_out == nullptr) or into gt_out [n][N]
+// Tables of k_grf_dft.h: cs[j] = (cos, sin)(2 pi j / n); g[k][d] = c_k / n * sum_l amp[k][l] cos(2 pi l d / n).
+void grf_dft_tables_host(int n, double c, std::vector<double>& cs, std::vector<double>& g) {
+    std::vector<int> kidx;
+    for (int i = 0; i <= n / 2; ++i) kidx.push_back(i);
+    for (int i = n / 2 - 1; i >= 1; --i) kidx.push_back(-i);  // ground_truths.py:7-11 (n entries for even n)
+    cs.resize((size_t)2 * n);
+    for (int j = 0; j < n; ++j) {
+        cs[2 * j] = std::cos(2.0 * M_PI * j / n);
+        cs[2 * j + 1] = std::sin(2.0 * M_PI * j / n);
+    }
+    const int n_k = n / 2 + 1;
+    g.assign((size_t)n_k * n, 0.0);
+    std::vector<double> amp(n);
+    for (int k = 0; k < n_k; ++k) {
+        for (int l = 0; l < n; ++l) {
+            const double kk = std::sqrt((double)kidx[k] * kidx[k] + (double)kidx[l] * kidx[l]);
+            amp[l] = (kidx[k] == 0 && kidx[l] == 0) ? 0.0 : std::sqrt(std::pow(kk, -c));
+        }
+        const double ck = (k == 0 || k == n / 2) ? 1.0 : 2.0;
+        for (int d = 0; d < n; ++d) {
+            double acc = 0.0;
+            for (int l = 0; l < n; ++l) acc += amp[l] * cs[2 * (int)((long)l * d % n)];
+            g[(size_t)k * n + d] = ck * acc / n;
+        }
+    }
+}
+
 int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
     const View& v = e->v;
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
+    if (e->grf_dft) {  // even n <= 100: half-spectrum DFT, normalisation fused (k_grf_dft.h)
+        const int rows = (v.W + (kGrfThreads / v.W) - 1) / (kGrfThreads / v.W);
+        const size_t lds = grf_dft_lds_bytes(v.W, e->grf_kc);
+        if (rows <= 10)
+            hipLaunchKernelGGL((k_grf_dft<10>), dim3(n), dim3(kGrfThreads), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+        else
+            hipLaunchKernelGGL((k_grf_dft<50>), dim3(n), dim3(kGrfThreads), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const size_t lds = (size_t)v.N * (sizeof(double) + sizeof(float));
     const bool use_lds = lds <= 120 * 1024;
     const int ot = (v.W <= 64) ? 5 : 8;
@@ -414,6 +456,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.partial = reinterpret_cast<double*>(base + L.off_partial);
     v.dbg = reinterpret_cast<double*>(base + L.off_dbg);
     v.grf_h = reinterpret_cast<double*>(base + L.off_grfh);
+    v.grf_cs = reinterpret_cast<double2*>(base + L.off_grfcs);
+    v.grf_g = reinterpret_cast<double*>(base + L.off_grfg);
     v.grf_raw = reinterpret_cast<float*>(base + L.off_grfraw);
     v.grf_raw2 = reinterpret_cast<float*>(base + L.off_grfraw2);
     e->n_bands = (L.N + kBandRows - 1) / kBandRows;
@@ -473,6 +517,18 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         std::vector<double> h;
         grf_kernel_host(cfg->y_dim, cfg->x_dim, cfg->cluster_radius, h);
         HIP_TRY(hipMemcpy(v.grf_h, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        const int n = cfg->x_dim;
+        e->grf_dft = (n % 2 == 0) && n >= 4 && n <= 100;  // odd n: the reference's amp is not even (ground_truths.py:8-11)
+        if (const char* gc = getenv("IPP_GRF_CONV")) e->grf_dft = e->grf_dft && atoi(gc) == 0;  // A/B experiments
+        if (e->grf_dft) {
+            std::vector<double> cs, g;
+            grf_dft_tables_host(n, cfg->cluster_radius, cs, g);
+            HIP_TRY(hipMemcpy(v.grf_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(v.grf_g, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+            const long budget = (n <= 64) ? 32768 : 65536;
+            const long fixed = (long)n * n * 4 + (long)n * 16 + 64;
+            e->grf_kc = (int)std::max(1L, std::min((long)(n / 2 + 1), (budget - fixed) / ((long)n * 40)));
+        }
     }
     if (const char* ch = getenv("IPP_STEP_CHUNKS")) e->step_chunks = atoi(ch);
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess) {
