@@ -5,6 +5,19 @@
 
 #include "../../include/ipp_engine.h"
 
+// Debug builds only (-DIPP_PHASE_TIMING=1): thread 0 of every workgroup adds the time since the previous tick
+// (100 MHz wall clock) to counters[k]; ipp_streamed_bytes prints the sums.
+#ifndef IPP_PHASE_TIMING
+#define IPP_PHASE_TIMING 0
+#endif
+#if IPP_PHASE_TIMING
+#define IPP_TICK_DECL(t) unsigned long long t = wall_clock64()
+#define IPP_TICK(v, k, t) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&(v).counters[k], n_ - (t)); (t) = n_; } } while (0)
+#else
+#define IPP_TICK_DECL(t) ((void)0)
+#define IPP_TICK(v, k, t) ((void)0)
+#endif
+
 namespace ipp {
 
 constexpr int kWave = 64;          // CDNA wavefront

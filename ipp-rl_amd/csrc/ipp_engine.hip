@@ -825,6 +825,13 @@ int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* strea
     HIP_TRY(hipMemcpyAsync(&cells, e->v.counters, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *bytes = (uint64_t)cells * 4;
+#if IPP_PHASE_TIMING
+    {
+        unsigned long long c[8];
+        HIP_TRY(hipMemcpy(c, e->v.counters, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[phase timing, 10 ns ticks summed over workgroups] hdr+tables %llu obs %llu gather %llu S %llu chol %llu out/Q %llu\n", c[1], c[2], c[3], c[4], c[5], c[6]);
+    }
+#endif
     if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 64, s));
     return 0;
 }

@@ -25,6 +25,9 @@
 #ifndef IPP_SF_PIPE
 #define IPP_SF_PIPE 8   // same, fused step kernel (A/B on MI355X: 6: see DESIGN.md, 8: 0.428 ms, 10: 0.436, 12: 0.446)
 #endif
+#ifndef IPP_GF_ABLATE
+#define IPP_GF_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no row stream, 8 = no compaction
+#endif
 #ifndef IPP_GF_MINWAVES
 #define IPP_GF_MINWAVES 4
 #endif
@@ -117,7 +120,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
         int nact = 0;
-        for (int k0 = 0; k0 < r; k0 += kWave) {
+        for (int k0 = 0; k0 < ((IPP_GF_ABLATE & 8) ? 0 : r); k0 += kWave) {
             const int k = k0 + lane;
             bool on = false;
             if (k < r) {
@@ -147,7 +150,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
-            for (int b = 0; b < m; ++b) {
+            for (int b = 0; b < ((IPP_GF_ABLATE & 1) ? 0 : m); ++b) {
                 float cb[VEC];
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
@@ -173,7 +176,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         }
 
         // ---- stream the stored rows: acc += row_k[cells] * Q[k,:]  (Q carries the sign of the downdate)
-        if (nact > 0) {
+        if (nact > 0 && !(IPP_GF_ABLATE & 4)) {
             const int last = r - 1;
             typedef float rowv __attribute__((ext_vector_type(VEC)));
             auto col_of = [&](int a) -> int { return __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]); };
@@ -229,7 +232,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         wave_part += wave_sum(part);
         const int valid_cells = max(0, min(kWaveTile, v.N - tile * kWaveTile));
         units += (unsigned long long)(nact + (h.commit ? m + 4 : 2)) * valid_cells;
-        if (h.commit) {
+        if (h.commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];

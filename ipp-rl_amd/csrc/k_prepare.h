@@ -79,21 +79,45 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
     double* bwt = reinterpret_cast<double*>(bcnt + ((MC + 3) & ~3));  // [MC] weight of block i
 
     const int tid = threadIdx.x;
+    IPP_TICK_DECL(tick);
 
-    // ------------------------------------------------------------------ header (thread 0, fp64 like NumPy)
-    if (tid == 0) {
-        ItemHdr h;
-        h.env = env_ids ? env_ids[item] : item + v.env_base;
-        h.dst = dst_ids ? dst_ids[item] : h.env;
+    // The prologue is a chain of dependent global-memory round trips, and under the streaming kernels' load every
+    // trip costs 4-5 us.  Loads are therefore issued in two batches: (1) everything whose address does not depend
+    // on the footprint, then the header arithmetic (done redundantly by every thread: no LDS broadcast, no
+    // barrier), (2) everything that does (ground-truth crop, mean at the footprint, the first pass of U rows).
+    constexpr int MP = (MC <= 16) ? 16 : 32;  // lanes per streaming index: i = tid % MP, no runtime division
+    constexpr int KS = kPrepThreads / MP;     // rows of U gathered per step of a pass
+    constexpr int UN = (kPrepThreads >= 256) ? 12 : 8;  // rows per thread and pass, all in flight together
+
+    // ------------------------------------------------------------------ batch 1
+    const int env0 = env_ids ? env_ids[item] : item + v.env_base;
+    const int dst0 = dst_ids ? dst_ids[item] : env0;
+    const bool slots_ok = env0 >= 0 && env0 < v.cap && dst0 >= 0 && dst0 < v.cap;
+    const int envc = slots_ok ? env0 : 0;  // speculative loads stay in bounds
+    const double ax = action[3 * item + 0], ay = action[3 * item + 1], az = action[3 * item + 2];
+    const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
+    const int rank_ld = (MODE == IPP_FACTOR) ? v.rank[envc] : 0;
+    const double sv = v.prior[2 * envc + 0], ls = v.prior[2 * envc + 1];
+    const float eps_ld = (meas_noise && tid < MC) ? meas_noise[(size_t)item * MC + tid] : 0.f;
+    const int* __restrict__ span = v.colspan + (size_t)envc * v.rank_cap;
+    int sp_pre[UN];  // tile spans of this thread's first-pass rows (factor)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int k = tid / MP + u * KS;
+        sp_pre[u] = (MODE == IPP_FACTOR && k < v.rank_cap) ? span[k] : 0;
+    }
+
+    // ------------------------------------------------------------------ header (every thread, fp64 like NumPy)
+    ItemHdr h;
+    {
+        h.env = env0;
+        h.dst = dst0;
         h.status = IPP_STATUS_OK;
         h.fallback = 0;
         h.commit = (flags & IPP_PREDICT_ONLY) ? 0 : 1;
         h.t_lo = 0;
         h.t_hi = v.n_tiles - 1;
-        const double ax = action[3 * item + 0], ay = action[3 * item + 1], az = action[3 * item + 2];
-        const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
-        bool ok = isfinite(ax) && isfinite(ay) && isfinite(az) && h.env >= 0 && h.env < v.cap && h.dst >= 0 &&
-                  h.dst < v.cap;
+        bool ok = isfinite(ax) && isfinite(ay) && isfinite(az) && slots_ok;
         int xl = 0, xr = 0, yu = 0, yd = 0;
         if (ok) {
             const double ext_x = 2 * az * v.tanx, ext_y = 2 * az * v.tany;           // cameras.py:44-45
@@ -125,13 +149,9 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         }
         h.cost_d = cost;
         h.cost = (float)cost;
-        h.rank = 0;
-        h.sv = h.ls = 0.f;
-        if (ok) {
-            h.rank = (MODE == IPP_FACTOR) ? v.rank[h.env] : 0;
-            h.sv = (float)v.prior[2 * h.env + 0];
-            h.ls = (float)v.prior[2 * h.env + 1];
-        }
+        h.rank = ok ? rank_ld : 0;
+        h.sv = ok ? (float)sv : 0.f;
+        h.ls = ok ? (float)ls : 0.f;
         if (!ok || h.m > MC || h.f > FC) h.status = IPP_STATUS_BAD_FOOTPRINT;
         if (h.status == IPP_STATUS_OK && h.rf > 1 && !(flags & IPP_COV_ONLY)) {
             // area resampler is only restated for shrinking scales
@@ -150,11 +170,11 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         }
         h.rows = (MODE == IPP_FACTOR) ? h.rank : h.f;
         if (h.status == IPP_STATUS_BAD_FOOTPRINT) { h.m = 0; h.f = 0; h.rows = 0; h.commit = 0; }
+    }
+    if (tid == 0) {
         *hs = h;
         okflag[0] = 1;
     }
-    __syncthreads();
-    const ItemHdr h = *hs;
     const int m = h.m, f = h.f, r = h.rank;
     double* dbg = v.dbg + (size_t)item * (2 * MC * MC + 2 * MC);
 
@@ -166,39 +186,92 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         }
         for (int i = tid; i < MC * MC; i += kPrepThreads) { linv_f[i] = 0.f; if (linv_f2) linv_f2[i] = 0.f; }
         for (int i = tid; i < MC; i += kPrepThreads) { y_f[i] = 0.f; if (y_f2) y_f2[i] = 0.f; }
+        __syncthreads();  // *hs visible to the caller's threads
         return hs;
     }
 
-    const double sv = v.prior[2 * h.env + 0], ls = v.prior[2 * h.env + 1];
     const float* mean_env = v.mean + (size_t)h.env * v.Npad;
     const float* gt_env = v.gt + (size_t)h.env * v.Npad;
     const float* cov_env = v.cov + (size_t)h.env * v.cov_slot;
     const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
     const bool cov_only = (flags & IPP_COV_ONLY) != 0;
+    IPP_TICK(v, 1, tick);
+
+    // ------------------------------------------------------------------ batch 2: footprint-dependent loads
+    // (a) ground-truth crop (simulations/__init__.py:24-25), one cell per thread (f <= FC <= threads)
+    float gt_ld[(FC + kPrepThreads - 1) / kPrepThreads];
+#pragma unroll
+    for (int q = 0; q < (FC + kPrepThreads - 1) / kPrepThreads; ++q) {
+        const int fi = tid + q * kPrepThreads;
+        const int ly = fi / h.w, lx = fi - ly * h.w;
+        gt_ld[q] = (!cov_only && fi < f) ? gt_env[(h.yu + ly) * v.W + h.xl + lx] : 0.f;
+    }
+    // (b) mean over the cells of measurement block tid (H x, mappings.py:195)
+    const Block myb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+    float mean_ld[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int aa = min(a, myb.count() - 1);
+        const int cell = (h.yu + myb.y0 + aa / myb.bw) * v.W + h.xl + myb.x0 + aa % myb.bw;
+        mean_ld[a] = (!cov_only && tid < m && a < myb.count()) ? mean_env[cell] : 0.f;
+    }
+    // (c) factor: first pass of the HT gather, HT[i][k] = sum_{cells of block i} w * U[k][cell]   (m x r).
+    // A column contributes only where it is stored (its tile span): cells outside hold nothing and count as zero.
+    const int gi = tid & (MP - 1);
+    const Block gb = block_of(min(gi, m - 1), h.nx, h.rf, h.w, h.h);
+    int gc[4], gtile[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int aa = min(a, gb.count() - 1);
+        gc[a] = (h.yu + gb.y0 + aa / gb.bw) * v.W + h.xl + gb.x0 + aa % gb.bw;
+        gtile[a] = gc[a] / v.tile_cells;
+    }
+    const int gcnt = gb.count();
+    const float gw = (float)gb.weight;
+    auto gather_rows = [&](int k0, const int (&sp)[UN], float (&sacc)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = min(k0 + u * KS, r - 1);
+            const float* row = cov_env + (size_t)k * v.Npad;
+            const int lo = sp[u] & 0xffff, hi = sp[u] >> 16;
+            float t = (gtile[0] >= lo && gtile[0] <= hi) ? row[gc[0]] : 0.f;
+            if (gcnt > 1) t += (gtile[1] >= lo && gtile[1] <= hi) ? row[gc[1]] : 0.f;
+            if (gcnt > 2) t += ((gtile[2] >= lo && gtile[2] <= hi) ? row[gc[2]] : 0.f) + ((gtile[3] >= lo && gtile[3] <= hi) ? row[gc[3]] : 0.f);
+            sacc[u] = t;
+        }
+    };
+    float sacc0[UN];
+    const bool gather_on = (MODE == IPP_FACTOR) && gi < m && r > 0;
+    if (gather_on) {
+        // rows past the rank clamp to r - 1: their span was read for an unused column, the value is discarded below
+        gather_rows(tid / MP, sp_pre, sacc0);
+    }
 
     // ------------------------------------------------------------------ footprint tables (no divisions later)
     for (int fi = tid; fi < f; fi += kPrepThreads) {
         const int ly = fi / h.w, lx = fi - ly * h.w;
         cellidx[fi] = (h.yu + ly) * v.W + h.xl + lx;
     }
-    for (int i = tid; i < m; i += kPrepThreads) {
-        const Block b = block_of(i, h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
-        bcnt[i] = b.count();
-        bwt[i] = b.weight;
+    if (tid < m) {
+        bcnt[tid] = myb.count();
+        bwt[tid] = myb.weight;
         for (int a = 0; a < 4; ++a) {
-            const int aa = min(a, b.count() - 1);
-            const int ly = b.y0 + aa / b.bw, lx = b.x0 + aa % b.bw;
-            bfi[4 * i + a] = ly * h.w + lx;
-            bcell[4 * i + a] = (h.yu + ly) * v.W + h.xl + lx;
+            const int aa = min(a, myb.count() - 1);
+            const int ly = myb.y0 + aa / myb.bw, lx = myb.x0 + aa % myb.bw;
+            bfi[4 * tid + a] = ly * h.w + lx;
+            bcell[4 * tid + a] = (h.yu + ly) * v.W + h.xl + lx;
         }
     }
     if (MODE == IPP_FACTOR && tid < f) ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv, ls);
+#pragma unroll
+    for (int q = 0; q < (FC + kPrepThreads - 1) / kPrepThreads; ++q) {
+        const int fi = tid + q * kPrepThreads;
+        if (!cov_only && fi < f) sub[fi] = (double)gt_ld[q];
+    }
     __syncthreads();
 
     // ------------------------------------------------------------------ observation + innovation
     if (!cov_only) {
-        for (int i = tid; i < f; i += kPrepThreads) sub[i] = (double)gt_env[cellidx[i]];  // simulations/__init__.py:24-25
-        __syncthreads();
         if (tid < m) {
             double val;
             if (h.rf == 1) {
@@ -217,20 +290,21 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
                     }
                 }
             }
-            const double eps = meas_noise ? (double)meas_noise[(size_t)item * MC + tid] : 0.0;
+            const double eps = (double)eps_ld;
             if (flags & IPP_GIVEN_OBSERVATION)
                 val = eps;  // caller supplies z (update_grid_map(pos, z), mappings.py:114-121)
             else
                 val = fmin(fmax(val + h.nv_d * eps, 0.0), 1.0);  // sensor_manipulations.py:56-57 (variance used as std)
             zz[tid] = val;
             double hx = 0.0;
-            for (int a = 0; a < bcnt[tid]; ++a) hx += bwt[tid] * (double)mean_env[bcell[4 * tid + a]];
+            for (int a = 0; a < myb.count(); ++a) hx += myb.weight * (double)mean_ld[a];
             vv[tid] = val - hx;  // mappings.py:195
         }
     } else if (tid < MC) {
         zz[tid] = 0.0;
         vv[tid] = 0.0;
     }
+    IPP_TICK(v, 2, tick);
 
     if (obs_out) {  // ipp_observe: observation only
         __syncthreads();
@@ -245,44 +319,31 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
             if (status_out) status_out[item] = h.status;
             hs->m = 0;  // nothing to stream
         }
+        __syncthreads();
         return hs;
     }
 
     // ------------------------------------------------------------------ gather the state rows of the footprint
-    constexpr int MP = (MC <= 16) ? 16 : 32;  // lanes per streaming index: i = tid % MP, no runtime division
     int ht_ld = 0;
     if (MODE == IPP_FACTOR) {
-        // HT[i][k] = sum_{cells of block i} w * U[k][cell]   (m x r)
         ht_ld = (r + 3) & ~3;
         const int SI = (si > 0) ? si : ht_ld, SK = (si > 0) ? sk : 1;
-        const int* __restrict__ span = v.colspan + (size_t)h.env * v.rank_cap;
         if (span_s)
             for (int k = tid; k < r; k += kPrepThreads) span_s[k] = span[k];
-        const int i = tid & (MP - 1);
-        if (i < m) {
-            const int cnt = bcnt[i];
-            const int c0 = bcell[4 * i], c1 = bcell[4 * i + 1], c2 = bcell[4 * i + 2], c3 = bcell[4 * i + 3];
-            const int t0 = c0 / v.tile_cells, t1 = c1 / v.tile_cells, t2 = c2 / v.tile_cells, t3 = c3 / v.tile_cells;
-            const float w = (float)bwt[i];
-            // 8 rows per pass: all (<= 32) 4-byte loads of a pass are issued before the first LDS store, so a
-            // thread pays one memory round trip per 8 rows instead of one per row.  A column contributes only
-            // where it is stored (its tile span): cells outside hold nothing and count as zero.
-            constexpr int KS = kPrepThreads / MP, UN = 8;
-            for (int k0 = tid / MP; k0 < r; k0 += UN * KS) {
-                float sacc[UN];
+        if (gather_on) {
+            const int k00 = tid / MP;
 #pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int k = min(k0 + u * KS, r - 1);
-                    const float* row = cov_env + (size_t)k * v.Npad;
-                    const int sp = span[k], lo = sp & 0xffff, hi = sp >> 16;
-                    float t = (t0 >= lo && t0 <= hi) ? row[c0] : 0.f;
-                    if (cnt > 1) t += (t1 >= lo && t1 <= hi) ? row[c1] : 0.f;
-                    if (cnt > 2) t += ((t2 >= lo && t2 <= hi) ? row[c2] : 0.f) + ((t3 >= lo && t3 <= hi) ? row[c3] : 0.f);
-                    sacc[u] = t;
-                }
+            for (int u = 0; u < UN; ++u)
+                if (k00 + u * KS < r) big[gi * SI + (k00 + u * KS) * SK] = sacc0[u] * gw;
+            for (int k0 = k00 + UN * KS; k0 < r; k0 += UN * KS) {  // further passes (rank > UN * KS)
+                int sp[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) sp[u] = span[min(k0 + u * KS, r - 1)];
+                float sacc[UN];
+                gather_rows(k0, sp, sacc);
 #pragma unroll
                 for (int u = 0; u < UN; ++u)
-                    if (k0 + u * KS < r) big[i * SI + (k0 + u * KS) * SK] = sacc[u] * w;
+                    if (k0 + u * KS < r) big[gi * SI + (k0 + u * KS) * SK] = sacc[u] * gw;
             }
         }
     } else {
@@ -291,6 +352,7 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
             for (int b = tid & 31; b < f; b += 32) big[a * (FC + 1) + b] = cov_env[(size_t)cellidx[a] * v.Npad + cellidx[b]];
     }
     __syncthreads();
+    IPP_TICK(v, 3, tick);
 
     // ------------------------------------------------------------------ S = H P_FF H^T + R  (mappings.py:182-183)
     // one 8-lane group per (i <= j) pair: prior / P_FF part over the <= rf^4 cell combinations, factor part
@@ -340,6 +402,7 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         }
     }
     __syncthreads();
+    IPP_TICK(v, 4, tick);
 
     // ------------------------------------------------------------------ Cholesky S = C C^T (C lower), fp64
     // np.linalg.cholesky(S) returns C; the reference uses L = C^T (upper).  mappings.py:185
@@ -418,6 +481,7 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         status = IPP_STATUS_NOT_PD;  // factor form cannot hold an indefinite update
     }
     __syncthreads();
+    IPP_TICK(v, 5, tick);
 
     // ------------------------------------------------------------------ outputs for the streaming kernels
     const bool dead = (MODE == IPP_FACTOR) && !pd;
@@ -476,6 +540,7 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         *hs = ho;
         if (status_out) status_out[item] = status;
     }
+    IPP_TICK(v, 6, tick);
     return hs;
 }
 
