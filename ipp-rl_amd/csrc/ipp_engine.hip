@@ -473,11 +473,11 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         if (const char* fu = getenv("IPP_FUSED")) e->fused = e->fused && atoi(fu) != 0;  // A/B experiments
         const int waves = v.T / 64;
         if (v.meas_cap == 9)
-            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap, e->lut_cap), step_small_floats<9>(), waves)
-                                   : GainLds<9>::bytes(v.rank_cap, e->lut_cap, 0, waves);
+            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), e->lut_cap, step_small_floats<9>(), waves)
+                                   : GainLds<9>::bytes(v.rank_cap, 0, e->lut_cap, 0, waves);
         else
-            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap, e->lut_cap), step_small_floats<25>(), waves)
-                                   : GainLds<25>::bytes(v.rank_cap, e->lut_cap, 0, waves);
+            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), e->lut_cap, step_small_floats<25>(), waves)
+                                   : GainLds<25>::bytes(v.rank_cap, 0, e->lut_cap, 0, waves);
         if (v.T == kWave)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;
@@ -829,7 +829,7 @@ int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* strea
     {
         unsigned long long c[8];
         HIP_TRY(hipMemcpy(c, e->v.counters, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[phase timing, 10 ns ticks summed over workgroups] hdr+tables %llu obs %llu gather %llu S %llu chol %llu out/Q %llu\n", c[1], c[2], c[3], c[4], c[5], c[6]);
+        fprintf(stderr, "[phase timing, 10 ns ticks summed over workgroups] c1 hdr %llu c2 obs %llu c3 gather %llu c4 %llu c5 %llu c6 %llu c7 %llu\n", c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
     }
 #endif
     if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 64, s));

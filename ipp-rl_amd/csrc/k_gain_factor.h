@@ -23,7 +23,7 @@
 #define IPP_GF_PIPE 12  // rows of U requested per group, stand-alone gain kernel
 #endif
 #ifndef IPP_SF_PIPE
-#define IPP_SF_PIPE 8   // same, fused step kernel (A/B on MI355X: 6: see DESIGN.md, 8: 0.428 ms, 10: 0.436, 12: 0.446)
+#define IPP_SF_PIPE 10  // same, fused step kernel (A/B on MI355X: 6..12 within 3 %, 10 the most consistent)
 #endif
 #ifndef IPP_GF_ABLATE
 #define IPP_GF_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no row stream, 8 = no compaction
@@ -43,21 +43,24 @@ struct GainLds {
     static constexpr int QS = (MC + 3) & ~3;
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
-    int* span_s; int* fb_yx; float* fb_w; unsigned short* ridx_all;
-    __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int small_floats, int waves) {
-        size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
+    int* solve_flag; int* span_s; int* fb_yx; float* fb_w; unsigned short* ridx_all;
+    __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves) {
+        size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
         b += (size_t)rank_cap * 4 + (size_t)8 * MC * 4 + (size_t)waves * (rank_cap + 8) * 2;
         return (b + 15) & ~(size_t)15;
     }
-    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int small_floats) {
+    // work: HT staging rows of the fused prologue (0 floats for the stand-alone kernel); lut: prior table;
+    // small: the fused prologue's fp64 scratch (0 floats for the stand-alone kernel)
+    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats) {
         Ls = reinterpret_cast<float*>(base);
         ys = Ls + MC * MC;
         work = Ls + LQ;
-        lut = work;
-        small = reinterpret_cast<unsigned char*>(work + ((work_floats + 3) & ~3));
+        lut = work + ((work_floats + 3) & ~3);
+        small = reinterpret_cast<unsigned char*>(lut + ((lut_floats + 3) & ~3));
         red = reinterpret_cast<double*>(small + (size_t)((small_floats + 3) & ~3) * 4);
-        next_tile = reinterpret_cast<int*>(red + 15);  // red[15] is unused by the reduction
+        next_tile = reinterpret_cast<int*>(red + 15);  // red[8..15] are unused by the reduction (<= 8 waves)
         done_waves = next_tile + 1;
+        solve_flag = reinterpret_cast<int*>(red + 14);  // fused kernel: 0 = L^-1 / y pending, 1 = ready, 2 = S not PD
         span_s = reinterpret_cast<int*>(red + 16);
         fb_yx = span_s + rank_cap;                         // [MC][4] footprint cell (row << 16 | col) of block b
         fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);   // [MC][4] weight of that cell (0 for padding)
@@ -85,7 +88,11 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // qrows: the item's Q rows [k][QS] in global scratch, followed by >= 8 zero rows.  It must be a pointer the
 // compiler can prove read-only (a `const float* __restrict__` kernel argument): only then are the wave-uniform row
 // reads emitted as scalar loads.
-template <int MC, int VEC, int KP>
+// PRE (fused kernel): qrows holds the rows of -HT (HT = H_F U[F,:]^T, m values per column) instead of Q = -HT L^-1,
+// the accumulators hold Wc L = P[:,F] H_F^T per cell, and the tile epilogue applies L^-1 (upper triangular, 45 FMAs
+// per cell) once lds.solve_flag says wave 0 has finished the m x m algebra.  The stream therefore starts right
+// after the gather instead of after S / Cholesky / L^-1 / Q.
+template <int MC, int VEC, int KP, bool PRE>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, bool use_lut,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out) {
@@ -106,6 +113,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const size_t npad = (size_t)v.Npad;
     double wave_part = 0.0;
     unsigned long long units = 0;
+    bool solved = !PRE, dead = false;
+#if IPP_PHASE_TIMING
+    const unsigned long long loop0_ = wall_clock64();
+#endif
 
     // tiles are handed out dynamically (LDS counter): a wave that finishes a short tile takes the next one
     for (;;) {
@@ -150,8 +161,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
-            for (int b = 0; b < ((IPP_GF_ABLATE & 1) ? 0 : m); ++b) {
-                float cb[VEC];
+            auto block_term = [&](int b, float (&cb)[VEC]) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
 #pragma unroll
@@ -166,11 +176,27 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                         cb[c] = fmaf(wa, p0, cb[c]);
                     }
                 }
+            };
+            if (PRE) {
 #pragma unroll
-                for (int j = 0; j < MC; ++j) {
-                    const float l = Ls[b * MC + j];
+                for (int b = 0; b < MC; ++b) {  // unrolled: acc[.][b] must be a static register index
+                    if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                        float cb[VEC];
+                        block_term(b, cb);
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                        for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
+                    }
+                }
+            } else {
+                for (int b = 0; b < ((IPP_GF_ABLATE & 1) ? 0 : m); ++b) {
+                    float cb[VEC];
+                    block_term(b, cb);
+#pragma unroll
+                    for (int j = 0; j < MC; ++j) {
+                        const float l = Ls[b * MC + j];
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                    }
                 }
             }
         }
@@ -207,6 +233,37 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
         }
 
+        if (PRE) {
+            // wait (first tile only) until wave 0 has published L^-1 and y, then Wc = (P[:,F] H_F^T) L^-1 in place:
+            // column j needs the untransformed entries b <= j, so j runs downwards
+            if (!solved) {
+#if IPP_PHASE_TIMING
+                const unsigned long long w0_ = wall_clock64();
+#endif
+                while (__hip_atomic_load(lds.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+                solved = true;
+                dead = __hip_atomic_load(lds.solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
+#if IPP_PHASE_TIMING
+                if (lane == 0) atomicAdd(&v.counters[6], wall_clock64() - w0_);
+#endif
+            }
+#pragma unroll
+            for (int j = MC - 1; j >= 0; --j) {
+                float t[VEC];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) t[c] = 0.f;
+#pragma unroll
+                for (int b = 0; b <= j; ++b) {
+                    const float l = Ls[b * MC + j];
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) t[c] = fmaf(acc[c][b], l, t[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc[c][j] = t[c];
+            }
+        }
+        const bool commit = h.commit && !dead;
+
         // ---- epilogue for this tile
         float dred[VEC], dmean[VEC];
         double part = 0.0;
@@ -231,8 +288,8 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         }
         wave_part += wave_sum(part);
         const int valid_cells = max(0, min(kWaveTile, v.N - tile * kWaveTile));
-        units += (unsigned long long)(nact + (h.commit ? m + 4 : 2)) * valid_cells;
-        if (h.commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
+        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * valid_cells;
+        if (commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
@@ -253,6 +310,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         __builtin_amdgcn_wave_barrier();
     }
 
+#if IPP_PHASE_TIMING
+    if (lane == 0) atomicAdd(&v.counters[7], wall_clock64() - loop0_);
+#endif
     // ------------------------------------------------------------------ per-item results
     // No closing barrier: a wave that has no tile left publishes its partial sum and exits, freeing its slot;
     // the last wave to arrive (LDS counter) adds the partials in wave order (bit-reproducible) and writes the
@@ -267,13 +327,15 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     arrived = __builtin_amdgcn_readfirstlane(arrived);
     if (arrived != nw - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (PRE) dead = __hip_atomic_load(lds.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without tiles never looked)
+    const bool commit_item = h.commit && !dead;
     if (lane == 0) {
         double tot = 0.0;
         for (int w = 0; w < nw; ++w) tot += red[w];
-        reward_out[item] = (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
-        if (h.commit) v.rank[h.dst] = r + m;
+        reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
+        if (commit_item) v.rank[h.dst] = r + m;
     }
-    if (h.commit && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+    if (commit_item && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
 }
 
 // Stand-alone gain kernel (after k_prepare): stages L^-1 | y, the spans and the prior table, then gain_tiles.
@@ -284,7 +346,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
                                                                    float* __restrict__ reward_out) {
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    const GainLds<MC> lds(smem_gf, v.rank_cap, lut_cap, 0);
+    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_cap, 0);
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -308,7 +370,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
         }
     }
     __syncthreads();
-    gain_tiles<MC, VEC, IPP_GF_PIPE>(v, h, item, flags, use_lut, lds, blk + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_GF_PIPE, false>(v, h, item, flags, use_lut, lds, blk + LQ, reward_out);
 }
 
 }  // namespace ipp

@@ -40,6 +40,34 @@ __host__ __device__ constexpr size_t prep_small_bytes() {
            (4 * MC + 8 * MC + ((MC + 3) & ~3)) * sizeof(int) + MC * sizeof(double);
 }
 
+// Carve of the prologue's fp64 LDS scratch (prep_small_bytes<MC>() bytes, all offsets multiples of 8 B).
+template <int MC>
+struct PrepLds {
+    static constexpr int FC = 4 * MC;
+    static constexpr int LD = MC + 1;  // padded leading dimension of the small fp64 matrices
+    double* S; double* L; double* Li; double* zz; double* vv; double* yy; double* sub; double* ktab;
+    ItemHdr* hs; int* okflag; int* cellidx; int* bcell; int* bfi; int* bcnt; double* bwt;
+    __device__ __forceinline__ explicit PrepLds(unsigned char* small) {
+        S = reinterpret_cast<double*>(small);          // [MC][LD]
+        L = S + MC * LD;                               // [MC][LD]   lower Cholesky factor / work
+        Li = L + MC * LD;                              // [MC][LD]   upper-triangular inverse (or S^-1)
+        zz = Li + MC * LD;                             // [MC] observation
+        vv = zz + MC;                                  // [MC] innovation
+        yy = vv + MC;                                  // [MC]
+        sub = yy + MC;                                 // [FC] ground-truth crop
+        ktab = sub + FC;                               // [FC] prior between footprint cells by (|drow|, |dcol|)
+        hs = reinterpret_cast<ItemHdr*>(ktab + FC);
+        okflag = reinterpret_cast<int*>(hs + 1);       // [4]
+        cellidx = okflag + 4;                          // [FC] flat cell index of footprint cell fi
+        bcell = cellidx + FC;                          // [MC][4] flat cell indices of block i
+        bfi = bcell + 4 * MC;                          // [MC][4] footprint-local indices of block i
+        bcnt = bfi + 4 * MC;                           // [MC] cells in block i (1, 2 or 4)
+        bwt = reinterpret_cast<double*>(bcnt + ((MC + 3) & ~3));  // [MC] weight of block i
+    }
+};
+
+struct NoMidWork { __device__ __forceinline__ void operator()(const ItemHdr&) const {} };
+
 // The per-item prologue as a device function so that it can run as its own kernel (k_prepare: dense state, exact
 // factor state, ipp_observe) or at the head of the fused factor step kernel (k_step_factor.h).
 //   small        LDS scratch of prep_small_bytes<MC>() bytes (16-byte aligned); the ItemHdr lives inside it
@@ -49,34 +77,26 @@ __host__ __device__ constexpr size_t prep_small_bytes() {
 //   linv_f/_f2, y_f/_f2   fp32 copies of L^-1 and y for the streaming kernels (second pointers may be null)
 //   span_s       optional LDS array receiving the tile spans of the stored columns (factor)
 // Returns a pointer to the item header in LDS; header.m == 0 or status NOT_PD means nothing to stream.
-template <int MC, int MODE, int NT>
-__device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, const int* __restrict__ env_ids,
-                                                 const int* __restrict__ dst_ids, const double* __restrict__ action,
-                                                 const double* __restrict__ prev_action,
-                                                 const float* __restrict__ meas_noise, unsigned flags,
-                                                 int* __restrict__ status_out, float* __restrict__ obs_out,
-                                                 int* __restrict__ obs_m, int* __restrict__ obs_shape,
-                                                 unsigned char* small, float* big, int si, int sk, float* q_out,
-                                                 float* linv_f, float* linv_f2, float* y_f, float* y_f2, int* span_s) {
+//   FRONT_ONLY   stop after the gather (HT / P_FF staged in `big`, z and the innovation in the scratch): the fused
+//                kernel lets one wave finish the m x m algebra (solve_wave) while the others already stream
+//   mid_work     called once between issuing the footprint-dependent loads and consuming them (free compute slot)
+template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid>
+__device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int item, const int* __restrict__ env_ids,
+                                                    const int* __restrict__ dst_ids, const double* __restrict__ action,
+                                                    const double* __restrict__ prev_action,
+                                                    const float* __restrict__ meas_noise, unsigned flags,
+                                                    int* __restrict__ status_out, float* __restrict__ obs_out,
+                                                    int* __restrict__ obs_m, int* __restrict__ obs_shape,
+                                                    unsigned char* small, float* big, int si, int sk, float* q_out,
+                                                    float* linv_f, float* linv_f2, float* y_f, float* y_f2, int* span_s,
+                                                    Mid mid_work) {
     constexpr int kPrepThreads = NT;
     constexpr int FC = 4 * MC;
-    constexpr int LD = MC + 1;  // padded leading dimension of the small fp64 matrices
-    // ---- LDS carve (all offsets multiples of 8 B)
-    double* S = reinterpret_cast<double*>(small);         // [MC][LD]
-    double* L = S + MC * LD;                              // [MC][LD]   lower Cholesky factor / work
-    double* Li = L + MC * LD;                             // [MC][LD]   upper-triangular inverse (or S^-1)
-    double* zz = Li + MC * LD;                            // [MC] observation
-    double* vv = zz + MC;                                 // [MC] innovation
-    double* yy = vv + MC;                                 // [MC]
-    double* sub = yy + MC;                                // [FC] ground-truth crop
-    double* ktab = sub + FC;                              // [FC] prior between footprint cells by (|drow|, |dcol|)
-    ItemHdr* hs = reinterpret_cast<ItemHdr*>(ktab + FC);
-    int* okflag = reinterpret_cast<int*>(hs + 1);          // [4]
-    int* cellidx = okflag + 4;                             // [FC] flat cell index of footprint cell fi
-    int* bcell = cellidx + FC;                             // [MC][4] flat cell indices of block i
-    int* bfi = bcell + 4 * MC;                             // [MC][4] footprint-local indices of block i
-    int* bcnt = bfi + 4 * MC;                              // [MC] cells in block i (1, 2 or 4)
-    double* bwt = reinterpret_cast<double*>(bcnt + ((MC + 3) & ~3));  // [MC] weight of block i
+    constexpr int LD = MC + 1;
+    const PrepLds<MC> pl(small);
+    double* S = pl.S; double* L = pl.L; double* Li = pl.Li; double* zz = pl.zz; double* vv = pl.vv; double* yy = pl.yy;
+    double* sub = pl.sub; double* ktab = pl.ktab; ItemHdr* hs = pl.hs; int* okflag = pl.okflag; int* cellidx = pl.cellidx;
+    int* bcell = pl.bcell; int* bfi = pl.bfi; int* bcnt = pl.bcnt; double* bwt = pl.bwt;
 
     const int tid = threadIdx.x;
     IPP_TICK_DECL(tick);
@@ -246,6 +266,7 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
         // rows past the rank clamp to r - 1: their span was read for an unused column, the value is discarded below
         gather_rows(tid / MP, sp_pre, sacc0);
     }
+    mid_work(h);
 
     // ------------------------------------------------------------------ footprint tables (no divisions later)
     for (int fi = tid; fi < f; fi += kPrepThreads) {
@@ -353,6 +374,7 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
     }
     __syncthreads();
     IPP_TICK(v, 3, tick);
+    if (FRONT_ONLY) return hs;
 
     // ------------------------------------------------------------------ S = H P_FF H^T + R  (mappings.py:182-183)
     // one 8-lane group per (i <= j) pair: prior / P_FF part over the <= rf^4 cell combinations, factor part
@@ -542,6 +564,149 @@ __device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, 
     }
     IPP_TICK(v, 6, tick);
     return hs;
+}
+
+template <int MC, int MODE, int NT>
+__device__ __forceinline__ ItemHdr* prepare_item(const View& v, const int item, const int* __restrict__ env_ids,
+                                                 const int* __restrict__ dst_ids, const double* __restrict__ action,
+                                                 const double* __restrict__ prev_action,
+                                                 const float* __restrict__ meas_noise, unsigned flags,
+                                                 int* __restrict__ status_out, float* __restrict__ obs_out,
+                                                 int* __restrict__ obs_m, int* __restrict__ obs_shape,
+                                                 unsigned char* small, float* big, int si, int sk, float* q_out,
+                                                 float* linv_f, float* linv_f2, float* y_f, float* y_f2, int* span_s) {
+    return prepare_item_ex<MC, MODE, NT, false>(v, item, env_ids, dst_ids, action, prev_action, meas_noise, flags, status_out,
+                                                obs_out, obs_m, obs_shape, small, big, si, sk, q_out, linv_f, linv_f2, y_f,
+                                                y_f2, span_s, NoMidWork());
+}
+
+// The m x m algebra of a factor-state item by ONE wave (no workgroup barrier): S = H P_FF H^T + R from the prior
+// and the HT rows staged in LDS (HT(i,k) = ht[k*QS + i]), Cholesky, L^-1, y.  Called by wave 0 of the fused step
+// kernel after prepare_item_ex<FRONT_ONLY> while the other waves already stream.  Writes L^-1 / y (fp32) for the
+// tile epilogues, the debug copies, the final item header and status.  Returns the item status.
+// mapping/mappings.py:178-197.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS writes of this wave visible to its other lanes
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int MC>
+__device__ __forceinline__ int solve_wave(const View& v, const ItemHdr& h, const int item, unsigned flags,
+                                          unsigned char* small, const float* ht, float* linv_f, float* y_f,
+                                          int* __restrict__ status_out) {
+    constexpr int LD = MC + 1;
+    constexpr int QS = (MC + 3) & ~3;
+    const PrepLds<MC> pl(small);
+    double* S = pl.S; double* L = pl.L; double* Li = pl.Li; double* zz = pl.zz; double* vv = pl.vv; double* yy = pl.yy;
+    const double* ktab = pl.ktab; const int* bfi = pl.bfi; const int* bcnt = pl.bcnt; const double* bwt = pl.bwt;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int m = h.m, r = h.rank;
+    const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
+    const bool cov_only = (flags & IPP_COV_ONLY) != 0;
+    double* dbg = v.dbg + (size_t)item * (2 * MC * MC + 2 * MC);
+
+    {   // S: one 8-lane group per (i <= j) pair, fp64
+        constexpr int GL = 8;
+        const int grp = lane / GL, sl = lane & (GL - 1), n_grp = kWave / GL;
+        const int npairs = m * (m + 1) / 2;
+        for (int p0 = 0; p0 < npairs; p0 += n_grp) {
+            const int p = p0 + grp;
+            const bool on = p < npairs;
+            int i = 0, j = 0;
+            if (on) {
+                j = (int)((sqrtf(8.0f * p + 1.0f) - 1.0f) * 0.5f);
+                while (j * (j + 1) / 2 > p) --j;
+                while ((j + 1) * (j + 2) / 2 <= p) ++j;
+                i = p - j * (j + 1) / 2;  // i <= j
+            }
+            double acc = 0.0;
+            if (on) {
+                const int ci = bcnt[i], cj = bcnt[j];        // 1, 2 or 4
+                const int sh = (cj == 4) ? 2 : (cj == 2 ? 1 : 0);
+                const double wij = bwt[i] * bwt[j];
+                for (int c = sl; c < ci * cj; c += GL) {
+                    const int fa = bfi[4 * i + (c >> sh)], fb = bfi[4 * j + (c & (cj - 1))];
+                    const int lya = fa / h.w, lxa = fa - lya * h.w, lyb = fb / h.w, lxb = fb - lyb * h.w;
+                    acc += wij * ktab[abs(lya - lyb) * h.w + abs(lxa - lxb)];
+                }
+                for (int k = sl; k < r; k += GL) acc -= (double)ht[k * QS + i] * (double)ht[k * QS + j];
+            }
+#pragma unroll
+            for (int off = GL / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, GL);
+            if (on && sl == 0) {
+                if (i == j) acc += R;
+                S[i * LD + j] = acc;
+                S[j * LD + i] = acc;
+            }
+        }
+    }
+    wave_lds_sync();
+
+    // Cholesky S = C C^T (C lower), fp64; the reference uses L = C^T (upper).  mappings.py:185
+    bool pd = true;
+    for (int c = 0; c < m; ++c) {
+        double d = 0.0;
+        if (lane == 0) {
+            d = S[c * LD + c];
+            for (int k = 0; k < c; ++k) d -= L[c * LD + k] * L[c * LD + k];
+            L[c * LD + c] = sqrt(d);
+        }
+        d = __shfl(d, 0, kWave);
+        if (!(d > 0.0)) { pd = false; break; }
+        wave_lds_sync();
+        if (lane > c && lane < m) {
+            double sacc = S[lane * LD + c];
+            for (int k = 0; k < c; ++k) sacc -= L[lane * LD + k] * L[c * LD + k];
+            L[lane * LD + c] = sacc / L[c * LD + c];
+        }
+        wave_lds_sync();
+    }
+    int status = h.status;
+    if (pd) {
+        // L_inv = inv(C^T): column j by back substitution on the upper factor U = C^T. mappings.py:186
+        if (lane < m) {
+            const int j = lane;
+            for (int i = 0; i < m; ++i) Li[i * LD + j] = 0.0;
+            Li[j * LD + j] = 1.0 / L[j * LD + j];
+            for (int i = j - 1; i >= 0; --i) {
+                double sacc = 0.0;
+                for (int k = i + 1; k <= j; ++k) sacc += L[k * LD + i] * Li[k * LD + j];  // U[i][k] = C[k][i]
+                Li[i * LD + j] = -sacc / L[i * LD + i];
+            }
+        }
+        wave_lds_sync();
+        if (lane < m) {  // y = L_inv^T v   (mappings.py:189,196: W v = Wc L^-T v)
+            double sacc = 0.0;
+            for (int i = 0; i <= lane; ++i) sacc += Li[i * LD + lane] * vv[i];
+            yy[lane] = sacc;
+        }
+        wave_lds_sync();
+    } else {
+        status = IPP_STATUS_NOT_PD;  // factor form cannot hold an indefinite update
+    }
+    const bool dead = !pd;
+    for (int idx = lane; idx < MC * MC; idx += kWave) {
+        const int i = idx / MC, j = idx - i * MC;
+        const double val = (!dead && i < m && j < m) ? Li[i * LD + j] : 0.0;
+        linv_f[idx] = (float)val;
+        dbg[MC * MC + idx] = val;
+        dbg[idx] = (i < m && j < m) ? S[i * LD + j] : 0.0;
+    }
+    for (int i = lane; i < MC; i += kWave) {
+        const double yval = (!dead && !cov_only && i < m) ? yy[i] : 0.0;
+        y_f[i] = (float)yval;
+        dbg[2 * MC * MC + i] = (i < m) ? zz[i] : 0.0;
+        dbg[2 * MC * MC + MC + i] = yval;
+    }
+    if (lane == 0) {
+        ItemHdr ho = h;
+        ho.status = status;
+        ho.fallback = 0;
+        if (dead) { ho.commit = 0; ho.rows = 0; }
+        v.hdr[item] = ho;
+        if (status_out) status_out[item] = status;
+    }
+    return status;
 }
 
 // Stand-alone prologue kernel: one workgroup per item.

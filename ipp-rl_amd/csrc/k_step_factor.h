@@ -1,11 +1,15 @@
 // Fused factor-state env step: ONE kernel, one 256-thread workgroup per item.
-//   phase A  prepare_item (k_prepare.h): footprint, observation, S, Cholesky, L^-1, y, Q -- the gathered HT rows
-//            stay in LDS; Q (17 KB per item) is written to the item's global scratch block, from where phase B
-//            reads it back through the scalar cache
-//   phase B  gain_tiles (k_gain_factor.h): prior term + streaming of the stored columns of U + epilogue
-// Phase A is latency-bound (dependent loads, fp64 9x9 algebra) and phase B is HBM-bound; with several
-// workgroups resident per CU one item's prologue runs under other items' streams, which a separate prologue
-// kernel cannot do.  The prior table is built over the HT staging rows after phase A.
+//   phase A  prepare_item_ex<FRONT_ONLY> (k_prepare.h): footprint, observation, gather of HT = H_F U[F,:]^T into LDS;
+//            -HT (17 KB per item) is written to the item's global scratch block, from where phase B reads it back
+//            through the scalar cache
+//   then     wave 0: S, Cholesky, L^-1, y (solve_wave); waves 1..3 go straight to
+//   phase B  gain_tiles<PRE> (k_gain_factor.h): prior term + streaming of the stored columns of U against -HT,
+//            L^-1 applied in the tile epilogue, fused reward / diag / mean / append
+// Under the streaming load every dependent memory round trip of the prologue costs several microseconds and the
+// m x m algebra another ~20 us, during which a workgroup holds its registers without streaming; starting the
+// stream before the algebra is done and filling the load latency with the table builds shortens that window.
+// With several workgroups resident per CU one item's prologue also runs under other items' streams, which a
+// separate prologue kernel cannot do.
 #pragma once
 #include "ipp_common.h"
 #include "k_gain_factor.h"
@@ -15,22 +19,22 @@ namespace ipp {
 
 constexpr int kStepThreads = 256;
 
-// LDS work area of the fused kernel: HT staging rows during the prologue, then the prior table.
+// LDS work area of the fused kernel: the HT staging rows (rank_cap + 8 rows of QS floats).
 template <int MC>
-__host__ __device__ constexpr int step_work_floats(int rank_cap, int lut_cap) {
-    return ((rank_cap + 8) * ((MC + 3) & ~3)) > lut_cap ? ((rank_cap + 8) * ((MC + 3) & ~3)) : lut_cap;
+__host__ __device__ constexpr int step_work_floats(int rank_cap) {
+    return (rank_cap + 8) * ((MC + 3) & ~3);
 }
 template <int MC>
 __host__ __device__ constexpr int step_small_floats() {
     return (int)((prep_small_bytes<MC>() + 15) / 16 * 4);
 }
 
-// q_ro == v.q.  The prologue writes the item's Q rows through v.q (vector stores, complete at the workgroup
-// barrier below: __syncthreads waits for vmcnt(0) and the stores are write-through to L2), the tile loop reads
-// them through q_ro, which the compiler may treat as read-only and therefore fetches with scalar loads.  The two
-// never overlap in time within a workgroup, no other workgroup touches this item's block, blocks are 64-byte
-// aligned (no scalar-cache line shared between items) and the scalar cache is invalidated at every kernel launch,
-// so it cannot hold lines of a previous step.
+// q_ro == v.q.  Phase A writes the item's -HT rows through v.q (vector stores, complete at the workgroup barrier
+// below: __syncthreads waits for vmcnt(0) and the stores are write-through to L2), the tile loop reads them
+// through q_ro, which the compiler may treat as read-only and therefore fetches with scalar loads.  The two never
+// overlap in time within a workgroup, no other workgroup touches this item's block, blocks are 64-byte aligned
+// (no scalar-cache line shared between items) and the scalar cache is invalidated at every kernel launch, so it
+// cannot hold lines of a previous step.
 template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     View v, const float* __restrict__ q_ro, const int* __restrict__ env_ids, int n_items,
@@ -39,37 +43,53 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     constexpr int QS = (MC + 3) & ~3;
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
-    const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap, lut_cap), step_small_floats<MC>());
+    const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_cap, step_small_floats<MC>());
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x;
+    const bool use_lut = v.N <= lut_cap;
 
-    // ---- phase A: HT rows are gathered into the LDS work area as HT(i,k) = work[k*QS + i]; Q goes to global scratch
-    float* qblk = v.q + (size_t)item * v.q_item;
-    ItemHdr* hs = prepare_item<MC, IPP_FACTOR, kStepThreads>(v, item, env_ids, nullptr, action, prev_action, meas_noise,
-                                                              flags, status_out, nullptr, nullptr, nullptr, lds.small,
-                                                              lds.work, 1, QS, qblk + LQ, lds.Ls, nullptr, lds.ys, nullptr,
-                                                              lds.span_s);
-    __syncthreads();
-    const ItemHdr h = *hs;
-    if (h.m == 0 || h.status == IPP_STATUS_NOT_PD) {
-        if (tid == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;
+    // ---- phase A: header, observation, gather of HT(i,k) = work[k*QS + i].  While the footprint-dependent loads are
+    // in flight the workgroup builds the prior table and the block tables (pure arithmetic on the header).
+    auto mid = [&](const ItemHdr& hh) {
+        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; }
+        fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
+        if (use_lut) {
+            const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
+            for (int i = tid; i < v.N; i += kStepThreads) {
+                const int dr = i / v.W, dc = i - dr * v.W;
+                lds.lut[i] = matern_f(dr, dc, s3, hh.sv);
+            }
+        }
+    };
+    ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true>(
+        v, item, env_ids, nullptr, action, prev_action, meas_noise, flags, status_out, nullptr, nullptr, nullptr, lds.small,
+        lds.work, 1, QS, nullptr, lds.Ls, nullptr, lds.ys, nullptr, lds.span_s, mid);
+    const ItemHdr h = *hs;  // (every path of the prologue ends with a barrier)
+    IPP_TICK_DECL(tick);
+    if (h.m == 0) {
+        if (tid == 0) reward_out[item] = 0.f;
         return;
     }
-    if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; }
-    fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
-    const bool use_lut = v.N <= lut_cap;
-    if (use_lut) {  // over the HT staging rows: every thread is past its last read of them (barrier above)
-        const float s3 = (float)(kSqrt3 * v.res) / h.ls;
-        for (int i = tid; i < v.N; i += kStepThreads) {
-            const int dr = i / v.W, dc = i - dr * v.W;
-            lds.lut[i] = matern_f(dr, dc, s3, h.sv);
-        }
+    // -HT rows (sign of the downdate folded in, padding lanes zero) and the zero rows behind them -> global scratch
+    float* qrows_w = v.q + (size_t)item * v.q_item + LQ;
+    for (int idx = tid; idx < (h.rank + 8) * QS; idx += kStepThreads) {
+        const int k = idx / QS, i = idx - k * QS;
+        qrows_w[idx] = (k < h.rank && i < h.m) ? -lds.work[idx] : 0.f;
     }
     __syncthreads();
+    IPP_TICK(v, 4, tick);
+
+    // ---- wave 0 finishes the m x m algebra while waves 1..3 already stream (they need L^-1 only in a tile epilogue)
+    if (tid < kWave) {
+        const int status = solve_wave<MC>(v, h, item, flags, lds.small, lds.work, lds.Ls, lds.ys, status_out);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        IPP_TICK(v, 5, tick);
+    }
 
     // ---- phase B
-    gain_tiles<MC, VEC, IPP_SF_PIPE>(v, h, item, flags, use_lut, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_SF_PIPE, true>(v, h, item, flags, use_lut, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
 }
 
 }  // namespace ipp
