@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 2
+#define IPP_ABI_VERSION 3
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -40,6 +40,9 @@ extern "C" {
 #define IPP_USE_FLIGHT_TIME 8u /* cost = flight time, else distance (planning/common/actions.py:8-12)     */
 #define IPP_GIVEN_OBSERVATION 16u /* meas_noise holds the observation z itself (update_grid_map(pos, z),  */
                                   /* mapping/mappings.py:114-121): no crop / noise / clip is applied       */
+#define IPP_UPDATE_PREV     32u /* after the cost is taken, prev_action[item] <- action[item]: the driver's    */
+                                /* "previous_action = action" (planning/mcts_zero/episode_generators.py:146)  */
+                                /* without a copy kernel; prev_action must then be writable device memory     */
 
 /* per-item status written by ipp_step */
 #define IPP_STATUS_OK            0
@@ -137,6 +140,15 @@ int ipp_engine_info(void* engine, ipp_info* out /*[host]*/);
  */
 int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
               const float* white_noise, void* stream);
+
+/*
+ * ipp_reset plus the UAV's return to the mission start: prev_action[env][0..2] <- init_action for every reset
+ * env (Mission.init_action, planning/missions.py:69), in the same kernel.
+ *   prev_action [dev] double[capacity][3] indexed by ENV id (the batched driver's previous-waypoint table), or NULL
+ *   init_action [host] double[3]
+ */
+int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
+                      const float* white_noise, double* prev_action, const double* init_action, void* stream);
 
 /*
  * Ground-truth generation only: white noise [n][H][W] -> min-max normalised Gaussian random field into the

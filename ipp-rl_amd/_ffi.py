@@ -11,10 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPP_HIP_LIB") or os.path.join(_HERE, "lib", "libipp_hip.so")  # override: A/B builds only
 
 IPP_DENSE, IPP_FACTOR = 0, 1
-IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION = 1, 2, 4, 8, 16
+IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class IppConfig(C.Structure):
@@ -64,6 +64,7 @@ PROTOTYPES = {
     "ipp_engine_destroy": (C.c_int, [_P]),
     "ipp_engine_info": (C.c_int, [_P, C.POINTER(IppInfo)]),
     "ipp_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
+    "ipp_reset_episode": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),

@@ -574,17 +574,20 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     return 0;
 }
 
-int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
-              const float* white_noise, void* stream) {
+int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
+                      const float* white_noise, double* prev_action, const double* init_action, void* stream) {
     Engine* e = as_engine(engine);
     if (!e) return fail(-1, "null engine");
     if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
     if (n == 0) return 0;
     if (!env_ids && n > e->v.cap) return fail(-1, "n exceeds capacity");
+    if (prev_action && !init_action) return fail(-1, "prev_action needs init_action");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const View& v = e->v;
     HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_reset_small, dim3((v.Npad + 255) / 256, n), dim3(256), 0, s, v, env_ids, n, prior_scale, gt);
+    InitAction ia = {{0.0, 0.0, 0.0}};
+    if (init_action) for (int k = 0; k < 3; ++k) ia.p[k] = init_action[k];
+    hipLaunchKernelGGL(k_reset_small, dim3((v.Npad + 255) / 256, n), dim3(256), 0, s, v, env_ids, n, prior_scale, gt, prev_action, ia);
     if (!gt && white_noise) {
         if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
         if (int rc = launch_grf(e, n, white_noise, v.grf_raw, env_ids, nullptr, s)) return rc;
@@ -598,6 +601,11 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
     return 0;
 }
 
+int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
+              const float* white_noise, void* stream) {
+    return ipp_reset_episode(engine, env_ids, n, prior_scale, gt, white_noise, nullptr, nullptr, stream);
+}
+
 int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
              const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
              void* stream) {
@@ -607,7 +615,7 @@ int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32
     if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
     if (n == 0) return 0;
     if (!env_ids && n > e->v.cap) return fail(-1, "n exceeds capacity");
-    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_GIVEN_OBSERVATION)) return fail(-1, "unknown flag bits 0x%x", flags);
+    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_GIVEN_OBSERVATION | IPP_UPDATE_PREV)) return fail(-1, "unknown flag bits 0x%x", flags);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
     e->last_n = n;

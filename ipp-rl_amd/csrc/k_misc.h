@@ -6,8 +6,11 @@ namespace ipp {
 
 // mean <- 0.5, diag <- sigma^2, rank <- 0, prior <- (sigma^2, l); optional ground-truth install.
 // mapping/mappings.py:235-240,259-261.
+struct InitAction { double p[3]; };  // Mission.init_action (planning/missions.py:69), by value
+
 __global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_items,
-                              const double* __restrict__ prior_scale, const float* __restrict__ gt_in) {
+                              const double* __restrict__ prior_scale, const float* __restrict__ gt_in,
+                              double* __restrict__ prev_out, InitAction init) {
     const int item = blockIdx.y;
     if (item >= n_items) return;
     const int env = env_ids ? env_ids[item] : item;
@@ -19,6 +22,8 @@ __global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_ite
         v.rank[env] = 0;
         v.prior[2 * env + 0] = sv;
         v.prior[2 * env + 1] = ls;
+        if (prev_out)
+            for (int k = 0; k < 3; ++k) prev_out[3 * env + k] = init.p[k];
     }
     if (cell >= v.Npad) return;
     const bool valid = cell < v.N;

@@ -207,6 +207,10 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         for (int i = tid; i < MC * MC; i += kPrepThreads) { linv_f[i] = 0.f; if (linv_f2) linv_f2[i] = 0.f; }
         for (int i = tid; i < MC; i += kPrepThreads) { y_f[i] = 0.f; if (y_f2) y_f2[i] = 0.f; }
         __syncthreads();  // *hs visible to the caller's threads
+        if ((flags & IPP_UPDATE_PREV) && tid == 0) {
+            double* pw = const_cast<double*>(prev_action);
+            pw[3 * item + 0] = ax; pw[3 * item + 1] = ay; pw[3 * item + 2] = az;
+        }
         return hs;
     }
 
@@ -374,6 +378,11 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     }
     __syncthreads();
     IPP_TICK(v, 3, tick);
+    if ((flags & IPP_UPDATE_PREV) && tid == 0) {
+        // every thread has taken its copy of prev_action (batch 1) before the barrier above
+        double* pw = const_cast<double*>(prev_action);
+        pw[3 * item + 0] = ax; pw[3 * item + 1] = ay; pw[3 * item + 2] = az;
+    }
     if (FRONT_ONLY) return hs;
 
     // ------------------------------------------------------------------ S = H P_FF H^T + R  (mappings.py:182-183)

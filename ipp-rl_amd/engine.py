@@ -147,14 +147,24 @@ class IPPEngine:
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
     # ------------------------------------------------------------------ C-ABI calls
-    def reset(self, env_ids=None, prior_scale=None, gt=None, white_noise=None, n: Optional[int] = None):
+    def reset(self, env_ids=None, prior_scale=None, gt=None, white_noise=None, n: Optional[int] = None, prev=None,
+              init_action=None):
+        """prev / init_action: also return the UAVs of the reset envs to the mission start in the same kernel
+        (prev: [capacity, 3] float64 device tensor indexed by env id; ipp_reset_episode)."""
         torch = _torch()
         ids = self._dev(env_ids, torch.int32)
         n = int(ids.numel()) if ids is not None else int(n if n is not None else self.capacity)
         ps = self._dev(prior_scale, torch.float64, (n, 2))
         g = self._dev(gt, torch.float32, (n, self.n_cells))
         w = self._dev(white_noise, torch.float32, (n, self.n_cells))
-        _ffi.check(self._lib.ipp_reset(self._h, self._ptr(ids), n, self._ptr(ps), self._ptr(g), self._ptr(w), self.stream))
+        if prev is None:
+            _ffi.check(self._lib.ipp_reset(self._h, self._ptr(ids), n, self._ptr(ps), self._ptr(g), self._ptr(w), self.stream))
+        else:
+            if prev.dtype != torch.float64 or not prev.is_contiguous() or prev.numel() != 3 * self.capacity:
+                raise ValueError("prev must be a contiguous float64 [capacity, 3] device tensor")
+            ia = (C.c_double * 3)(*[float(x) for x in init_action])
+            _ffi.check(self._lib.ipp_reset_episode(self._h, self._ptr(ids), n, self._ptr(ps), self._ptr(g), self._ptr(w),
+                                                   self._ptr(prev), ia, self.stream))
         self._keep = (ids, ps, g, w)
 
     def generate_grf(self, white_noise, out=None, stream=None):
@@ -171,7 +181,7 @@ class IPPEngine:
 
     def step(self, actions, prev_actions, env_ids=None, dst_ids=None, meas_noise=None, *, cov_only=False,
              predict_only=False, adaptive=True, use_flight_time=True, given_observation=False, reward_out=None,
-             status_out=None):
+             status_out=None, update_prev=False):
         torch = _torch()
         a = self._dev(actions, torch.float64).reshape(-1, 3)
         p = self._dev(prev_actions, torch.float64).reshape(-1, 3)
@@ -189,7 +199,9 @@ class IPPEngine:
         status = status_out if status_out is not None else torch.empty(n, dtype=torch.int32, device=self.device)
         flags = (_ffi.IPP_COV_ONLY if cov_only else 0) | (_ffi.IPP_PREDICT_ONLY if predict_only else 0) | \
                 (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0) | \
-                (_ffi.IPP_GIVEN_OBSERVATION if given_observation else 0)
+                (_ffi.IPP_GIVEN_OBSERVATION if given_observation else 0) | (_ffi.IPP_UPDATE_PREV if update_prev else 0)
+        if update_prev and (predict_only or not isinstance(prev_actions, torch.Tensor) or p.data_ptr() != prev_actions.data_ptr()):
+            raise ValueError("update_prev needs prev_actions as a contiguous float64 device tensor and a committed step")
         _ffi.check(self._lib.ipp_step(self._h, self._ptr(ids), self._ptr(dst), n, self._ptr(a), self._ptr(p), self._ptr(nz),
                                       flags, self._ptr(reward), self._ptr(status), self.stream))
         self._keep = (a, p, ids, dst, nz)

@@ -84,9 +84,6 @@ class VecIPPEnv:
             ph = self.phase.cpu().numpy()
             self._reset_ids_host = [np.nonzero(ph == p)[0].astype(np.int32) for p in range(self.episode_steps)]
             self._reset_ids_by_phase = [torch.as_tensor(i, device=dev) for i in self._reset_ids_host]
-            # per-phase index tensors / rows for the single index_copy_ that returns the UAVs to init_action
-            self._reset_idl_by_phase = [i.long() for i in self._reset_ids_by_phase]
-            self._reset_prev_rows = [self.init_prev[i] for i in self._reset_idl_by_phase]
         self._white = torch.empty((B, cfg.n_cells), dtype=torch.float32, device=dev)
         # staggered runs prepare the next resets' ground truths on a side stream while the step kernels run
         # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
@@ -140,13 +137,12 @@ class VecIPPEnv:
             white_noise = white
         if prior_scale is None and self.shuffle_prior_cov:
             prior_scale = self._prior_scale(ids.cpu().numpy(), self.t)
-        self.engine.reset(env_ids=ids, prior_scale=prior_scale, gt=gt, white_noise=white_noise)
+        # the reset kernel also returns the UAVs to Mission.init_action (ipp_reset_episode)
+        self.engine.reset(env_ids=ids, prior_scale=prior_scale, gt=gt, white_noise=white_noise, prev=self.prev,
+                          init_action=INIT_ACTION)
         if _phase is not None:
-            self.prev.index_copy_(0, self._reset_idl_by_phase[_phase], self._reset_prev_rows[_phase])
             self.episode[self._reset_ids_host[_phase]] += 1
         else:
-            idl = ids.long()
-            self.prev.index_copy_(0, idl, self.init_prev[idl])
             if env_ids is None:
                 self.episode += 1
             elif not torch.is_tensor(env_ids):
@@ -208,11 +204,11 @@ class VecIPPEnv:
             self._noise_pos = (self._noise_pos + 1) % self.NOISE_RING
         else:
             nz = meas_noise
+        # full-batch steps let the kernel store the new previous waypoint (IPP_UPDATE_PREV): no copy launch
         self.engine.step(a, self.prev, env_ids=env_ids, meas_noise=nz, adaptive=self.adaptive,
-                         use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status)
-        if env_ids is None:
-            self.prev.copy_(a)
-        else:
+                         use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status,
+                         update_prev=env_ids is None)
+        if env_ids is not None:
             self.prev[torch.as_tensor(env_ids, device=self.device).long()] = a
         self.t += 1
         if after_step_hook is not None:

@@ -25,7 +25,7 @@ def engine(dim, window_rows, tile_threads=256, capacity=2):
 
 
 @pytest.mark.parametrize("name", ["episode_rf1_50_s0", "episode_mixed_50_s1"])
-@pytest.mark.parametrize("tile_threads", [64, 256])
+@pytest.mark.parametrize("tile_threads", [64, 128, 256])
 def test_window12_episode_vs_golden(golden, name, tile_threads):
     g = golden(name)
     dim = g["gt"].shape[0]
