@@ -78,7 +78,8 @@ typedef struct ipp_config {
     int32_t window_rows;      /* IPP_FACTOR: 0 = exact full columns; R > 0 = a new column of U is kept only on the
                                  grid rows within R of its footprint (|Wc| < 3e-8 beyond 12 rows for the example
                                  prior); streamed bytes shrink accordingly and are counted as such */
-    int32_t reserved0;
+    int32_t score_scratch;    /* 1 = reserve the scratch of ipp_score_actions in the arena: band of G = P M P
+                                 (N x 190 doubles) and, for IPP_FACTOR, one dense P (N x Npad floats) */
 } ipp_config;
 
 typedef struct ipp_info {
@@ -149,6 +150,22 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
  */
 int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
                       const float* white_noise, double* prev_action, const double* init_action, void* stream);
+
+/*
+ * Reward of n candidate actions from the CURRENT state of ONE env slot; nothing is written.  The call of
+ * greedy_search and of the rollout policy: simulate_prediction_step for every reachable action from the same
+ * state (planning/common/optimization.py:33-104, planning/mcts_mission.py:232-246).
+ * Same rewards as ipp_step(IPP_COV_ONLY | IPP_PREDICT_ONLY) with the env id repeated, but the state is read once
+ * instead of once per candidate: reward = tr(S^-1 H (P M P)[F,F] H^T) / (cost + 1), M = adaptive mask
+ * (csrc/k_score.h).  Needs ipp_config.score_scratch = 1.
+ *   actions     [dev]  double[n][3]
+ *   prev_action [host] double[3]      the one previous waypoint all candidates start from
+ *   flags              IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME
+ *   reward      [dev]  float[n]; status [dev] int32[n] or NULL (IPP_STATUS_BAD_FOOTPRINT: footprint above the
+ *                      compiled caps or wider than 10 cells, reward 0)
+ */
+int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32_t n, const double* prev_action,
+                      uint32_t flags, float* reward, int32_t* status, void* stream);
 
 /*
  * Ground-truth generation only: white noise [n][H][W] -> min-max normalised Gaussian random field into the

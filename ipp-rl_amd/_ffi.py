@@ -29,7 +29,7 @@ class IppConfig(C.Structure):
         ("value_threshold", C.c_double), ("interval_factor", C.c_double),
         ("cluster_radius", C.c_double),
         ("state_repr", C.c_int32), ("capacity", C.c_int32), ("rank_cap", C.c_int32), ("max_batch", C.c_int32),
-        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("reserved0", C.c_int32),
+        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("score_scratch", C.c_int32),
     ]
 
 
@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ipp_engine_info": (C.c_int, [_P, C.POINTER(IppInfo)]),
     "ipp_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
     "ipp_reset_episode": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "ipp_score_actions": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),

@@ -19,6 +19,7 @@
 #include "k_gain_wave.h"
 #include "k_misc.h"
 #include "k_grf_dft.h"
+#include "k_score.h"
 #include "k_prepare.h"
 
 using namespace ipp;
@@ -61,6 +62,8 @@ struct Engine {
     size_t prep_lds;
     size_t gain_lds;
     int q_chunk;
+    bool scoring = false;  // arena holds the ipp_score_actions scratch
+    ScoreView sv = {};
     bool grf_dft = false;  // even square grids up to 100: k_grf_dft instead of k_grf_conv + k_grf_norm
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
@@ -77,7 +80,7 @@ struct Engine {
 struct Layout {
     int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
-        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, total, cov_slot_floats;
+        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, total, cov_slot_floats;
 };
 
 uint64_t q_item_floats(const Layout& L) {
@@ -151,6 +154,14 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_grfg = o; o += up((uint64_t)(c.y_dim / 2 + 1) * c.x_dim * 8);    // g_k[d], k = 0 .. n/2 (k_grf_dft.h)
     L.off_grfraw = o; o += up(mb * np * 4);
     L.off_grfraw2 = o; o += up(mb * np * 4);
+    L.off_sc_hdr = L.off_sc_ext = L.off_sc_mask = L.off_sc_G = L.off_sc_P = o;
+    if (c.score_scratch) {  // ipp_score_actions (k_score.h)
+        L.off_sc_hdr = o; o += up(mb * sizeof(ScoreHdr));
+        L.off_sc_ext = o; o += up(64);
+        L.off_sc_mask = o; o += up(np * 4);
+        L.off_sc_G = o; o += up((uint64_t)L.N * kScoreBandCap * 8);
+        L.off_sc_P = o; o += (c.state_repr == IPP_FACTOR) ? up((uint64_t)L.N * np * 4) : 0;
+    }
     L.total = o;
     return 0;
 }
@@ -460,6 +471,15 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.grf_g = reinterpret_cast<double*>(base + L.off_grfg);
     v.grf_raw = reinterpret_cast<float*>(base + L.off_grfraw);
     v.grf_raw2 = reinterpret_cast<float*>(base + L.off_grfraw2);
+    e->scoring = cfg->score_scratch != 0;
+    if (e->scoring) {
+        e->sv.hdr = reinterpret_cast<ScoreHdr*>(base + L.off_sc_hdr);
+        e->sv.extent = reinterpret_cast<int*>(base + L.off_sc_ext);
+        e->sv.mask = reinterpret_cast<float*>(base + L.off_sc_mask);
+        e->sv.G = reinterpret_cast<double*>(base + L.off_sc_G);
+        e->sv.P = (cfg->state_repr == IPP_FACTOR) ? reinterpret_cast<float*>(base + L.off_sc_P) : nullptr;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_band), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    }
     e->n_bands = (L.N + kBandRows - 1) / kBandRows;
     e->prep_lds = prep_lds_bytes(L, *cfg);
     e->q_chunk = std::min(1024, (L.q_rows + 2 * kPipe - 1) / (2 * kPipe) * (2 * kPipe));
@@ -680,6 +700,36 @@ int ipp_set_adaptive(void* engine, double value_threshold, double interval_facto
     if (!e) return fail(-1, "null engine");
     e->v.thr = value_threshold;
     e->v.kf = interval_factor;
+    return 0;
+}
+
+int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32_t n, const double* prev_action,
+                      uint32_t flags, float* reward, int32_t* status, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !actions || !prev_action || !reward) return fail(-1, "null argument");
+    if (!e->scoring) return fail(-1, "ipp_score_actions needs ipp_config.score_scratch = 1");
+    if (int rc = check_env(e, env_id)) return rc;
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME)) return fail(-1, "unsupported flag bits 0x%x", flags);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const View& v = e->v;
+    const size_t band_lds = (size_t)2 * v.W * 65 * sizeof(float);
+    if (band_lds > 150 * 1024) return fail(-1, "grid rows of %d cells exceed the band kernel's LDS tiles", v.W);
+    ScoreView sv = e->sv;
+    if (v.mode == IPP_DENSE) sv.P = v.cov + (size_t)env_id * v.cov_slot;
+    PrevAction pa = {{prev_action[0], prev_action[1], prev_action[2]}};
+    HIP_TRY(hipMemsetAsync(sv.extent, 0, 8, s));
+    const int hdr_blocks = std::max((n + 255) / 256, std::min(64, (v.Npad + 255) / 256));
+    if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_hdr<9>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status);
+    else                 hipLaunchKernelGGL((k_score_hdr<25>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status);
+    if (v.mode == IPP_FACTOR)
+        hipLaunchKernelGGL(k_score_densify, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id);
+    hipLaunchKernelGGL(k_score_band, dim3(v.H, kScoreDCap + 1), dim3(256), band_lds, s, v, sv);
+    if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_eval<9>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
+    else                 hipLaunchKernelGGL((k_score_eval<25>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -70,7 +70,7 @@ class IPPEngine:
 
     def __init__(self, cfg: EngineConfig, capacity: int, state: str = "factor", rank_cap: int = 360,
                  max_batch: Optional[int] = None, device: str = "cuda:0", max_measurements: int = 9,
-                 tile_threads: int = 0, window_rows: int = 0):
+                 tile_threads: int = 0, window_rows: int = 0, score_scratch: bool = False):
         torch = _torch()
         self._lib = _ffi.load()
         if not torch.cuda.is_available():
@@ -97,6 +97,7 @@ class IPPEngine:
         c.capacity, c.rank_cap, c.max_batch = self.capacity, int(rank_cap), self.max_batch
         c.max_measurements, c.tile_threads = int(max_measurements), int(tile_threads)
         c.window_rows = int(window_rows)
+        c.score_scratch = 1 if score_scratch else 0
         self._c = c
         nbytes = C.c_uint64(0)
         _ffi.check(self._lib.ipp_engine_arena_bytes(C.byref(c), C.byref(nbytes)))
@@ -166,6 +167,22 @@ class IPPEngine:
             _ffi.check(self._lib.ipp_reset_episode(self._h, self._ptr(ids), n, self._ptr(ps), self._ptr(g), self._ptr(w),
                                                    self._ptr(prev), ia, self.stream))
         self._keep = (ids, ps, g, w)
+
+    def score_actions(self, env: int, actions, prev_action, *, adaptive=True, use_flight_time=True, reward_out=None,
+                      status_out=None):
+        """Reward of every candidate action from the current state of slot `env` (nothing is written): the state
+        is read once for all candidates (ipp_score_actions).  The engine needs score_scratch=True."""
+        torch = _torch()
+        a = self._dev(actions, torch.float64).reshape(-1, 3)
+        n = a.shape[0]
+        reward = reward_out if reward_out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        status = status_out if status_out is not None else torch.empty(n, dtype=torch.int32, device=self.device)
+        pv = (C.c_double * 3)(*[float(x) for x in np.asarray(prev_action, dtype=np.float64).ravel()[:3]])
+        flags = (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0)
+        _ffi.check(self._lib.ipp_score_actions(self._h, int(env), self._ptr(a), n, pv, flags, self._ptr(reward),
+                                               self._ptr(status), self.stream))
+        self._keep_score = a
+        return reward, status
 
     def generate_grf(self, white_noise, out=None, stream=None):
         """white noise [n, N] -> normalised GRF [n, N] in a caller tensor (no env slot touched)."""

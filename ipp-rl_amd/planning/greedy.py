@@ -4,7 +4,9 @@ planning/common/optimization.py:33-104 greedy_search and planning/greedy_mission
 
 The reference scores every reachable action by pickling the Mapping and its 50 MB covariance into a
 multiprocessing.Pool(4) and running simulate_prediction_step per candidate; here all candidates are scored by
-ONE predict-only batched ipp_step (env id repeated, nothing written), the winner is committed in place.
+ONE ipp_score_actions call that reads the state once (csrc/k_score.h), the winner is committed in place.
+``shared_pass=False`` scores through a predict-only batched ipp_step instead (env id repeated), which streams the
+state once per candidate.
 """
 from typing import Dict, List, Optional
 
@@ -19,14 +21,16 @@ INIT_ACTION = np.array([2.0, 2.0, 14.0])  # reference planning/missions.py:69
 class GreedyPlanner:
     def __init__(self, cfg: EngineConfig, min_altitude: float, max_altitude: float, altitude_spacing: float,
                  uav_specifications: Optional[Dict] = None, adaptive: bool = True, state: str = "dense",
-                 device: str = "cuda:0", max_candidates: Optional[int] = None):
+                 device: str = "cuda:0", max_candidates: Optional[int] = None, shared_pass: bool = True):
         levels = int((max_altitude - min_altitude) / altitude_spacing) + 1
         self.cfg = cfg
         self.min_altitude, self.max_altitude, self.altitude_spacing = min_altitude, max_altitude, altitude_spacing
         self.uav = uav_specifications
         self.adaptive = adaptive
         cap = max_candidates or cfg.n_cells * levels
-        self.engine = IPPEngine(cfg, capacity=2, state=state, rank_cap=9 * 128, max_batch=max(cap, 2), device=device)
+        self.shared_pass = shared_pass
+        self.engine = IPPEngine(cfg, capacity=2, state=state, rank_cap=9 * 128, max_batch=max(cap, 2), device=device,
+                                score_scratch=shared_pass)
         if uav_specifications is not None:
             self.engine.set_uav(uav_specifications["max_v"], uav_specifications["max_a"])
 
@@ -42,6 +46,10 @@ class GreedyPlanner:
     def score(self, previous_action, candidates) -> np.ndarray:
         """Reward of every candidate from the current state of slot 0 (nothing is written)."""
         acts = np.asarray(candidates, dtype=np.float64).reshape(-1, 3)
+        if self.shared_pass:
+            reward, _ = self.engine.score_actions(0, acts, previous_action, adaptive=self.adaptive,
+                                                  use_flight_time=self.uav is not None)
+            return reward.detach().cpu().numpy().astype(np.float64)
         prev = np.tile(np.asarray(previous_action, dtype=np.float64), (len(acts), 1))
         ids = np.zeros(len(acts), dtype=np.int32)
         reward, _ = self.engine.step(acts, prev, env_ids=ids, cov_only=True, predict_only=True, adaptive=self.adaptive,

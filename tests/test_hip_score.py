@@ -1,0 +1,95 @@
+"""
+GPU tests of ipp_score_actions (csrc/k_score.h): the reward of every candidate action from one state, computed
+from the band of G = P M P instead of one state stream per candidate.  Checked against
+  * the oracle's predict step (planning/common/optimization.py:14-30 restated) on sampled candidates,
+  * the golden per-candidate reward vectors recorded from the reference's greedy_search (tests/golden/greedy.npz),
+  * ipp_step(IPP_COV_ONLY | IPP_PREDICT_ONLY) with the env id repeated, for every candidate.
+"""
+import numpy as np
+import pytest
+
+from oracle import ipp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+UAV = {"max_v": 2.0, "max_a": 2.0}
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def all_candidates(cfg, alts):
+    xs = cfg.resolution * (np.arange(cfg.x_dim) + 0.5)
+    return np.array([(x, y, z) for z in alts for y in xs for x in xs])
+
+
+@pytest.mark.parametrize("state,window_rows", [("factor", 0), ("factor", 12), ("dense", 0)])
+@pytest.mark.parametrize("adaptive,flight_time", [(True, True), (False, False)])
+def test_score_matches_predict_step_and_oracle(state, window_rows, adaptive, flight_time):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    dim = 20
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim, resolution=cfg.resolution, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b)
+    cand = all_candidates(cfg, [5.0, 8.0, 10.0, 12.0, 14.0])
+    A = len(cand)
+    eng = IPPEngine(cfg, capacity=3, state=state, rank_cap=128, max_batch=A, window_rows=window_rows, score_scratch=True)
+    rs = np.random.RandomState(5)
+    white = rs.normal(size=(dim, dim))
+    eng.reset(env_ids=[1], white_noise=white[None])
+    st = orc.env_reset(ocfg, white)
+    prev = np.array([2.0, 2.0, 14.0])
+    for t in range(8):  # build a non-trivial state (mean moves the adaptive mask, P is no longer the prior)
+        a = cand[rs.randint(A)]
+        eps = rs.normal(size=9)
+        eng.step(a[None], prev[None], env_ids=[1], meas_noise=eps[None])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
+        orc.env_step(ocfg, st, a, eps[:m])
+        prev = a
+    reward, status = eng.score_actions(1, cand, prev, adaptive=adaptive, use_flight_time=flight_time)
+    assert int(status.abs().sum()) == 0
+    ids = np.ones(A, dtype=np.int32)
+    ref, _ = eng.step(cand, np.tile(prev, (A, 1)), env_ids=ids, cov_only=True, predict_only=True, adaptive=adaptive,
+                      use_flight_time=flight_time)
+    diff = float((reward - ref).abs().max())
+    print(f"[{state}, window {window_rows}, adaptive {adaptive}] {A} candidates, max |score - predict step| {diff:.2e}")
+    assert diff < TOL
+    info = {"mean": st.mean, "value_threshold": 0.4, "interval_factor": 0.0} if adaptive else None
+    for k in rs.choice(A, 24, replace=False):
+        want = orc.predict_step(ocfg, st.P, prev, cand[k], UAV if flight_time else None, info)[0]
+        assert abs(float(reward[k]) - want) < TOL, (k, cand[k], float(reward[k]), want)
+    # nothing was written
+    assert np.max(np.abs(host(eng.read_mean(1)) - st.mean)) < TOL
+
+
+def test_score_golden_greedy_candidates(golden):
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.planning.greedy import GreedyPlanner
+
+    g = golden("greedy")
+    for dim in (10, 20):
+        for state in ("dense", "factor"):
+            pl = GreedyPlanner(EngineConfig(x_dim=dim, y_dim=dim), 8, 14, 6, UAV, adaptive=True, state=state)
+            pl.reset()
+            r = pl.score(np.array([2.0, 2.0, 14.0]), g[f"candidates_{dim}"])
+            assert np.max(np.abs(r - g[f"rewards_{dim}"])) < TOL
+
+
+def test_score_bad_footprints_and_missing_scratch():
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd._ffi import IppError
+
+    cfg = EngineConfig(x_dim=20, y_dim=20)
+    eng = IPPEngine(cfg, capacity=2, state="factor", rank_cap=32, max_batch=8, score_scratch=True)
+    eng.reset()
+    acts = np.array([[10.0, 10.0, 8.0], [10.0, 10.0, 60.0], [np.nan, 1.0, 8.0], [78.0, 78.0, 14.0]])
+    reward, status = eng.score_actions(0, acts, [2.0, 2.0, 14.0])
+    st = host(status).astype(int)
+    assert st[0] == 0 and st[3] == 0 and st[1] == 4 and st[2] == 4  # IPP_STATUS_BAD_FOOTPRINT
+    r = host(reward)
+    assert r[0] > 0 and r[3] > 0 and r[1] == 0 and r[2] == 0
+    plain = IPPEngine(cfg, capacity=2, state="factor", rank_cap=32, max_batch=8)
+    plain.reset()
+    with pytest.raises(IppError):
+        plain.score_actions(0, acts, [2.0, 2.0, 14.0])
