@@ -159,7 +159,7 @@ int plan(const ipp_config& c, Layout& L) {
         L.off_sc_hdr = o; o += up(mb * sizeof(ScoreHdr));
         L.off_sc_ext = o; o += up(64);
         L.off_sc_mask = o; o += up(np * 4);
-        L.off_sc_G = o; o += up((uint64_t)L.N * kScoreBandCap * 8);
+        L.off_sc_G = o; o += up((uint64_t)kScoreSplit * L.N * kScoreBandCap * 8);
         L.off_sc_P = o; o += (c.state_repr == IPP_FACTOR) ? up((uint64_t)L.N * np * 4) : 0;
     }
     L.total = o;
@@ -715,7 +715,9 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
     const View& v = e->v;
-    const size_t band_lds = (size_t)2 * v.W * 65 * sizeof(float);
+    int band_kc = 64;  // columns k per LDS tile: 2 row blocks of W cells in fp64
+    while (band_kc > 8 && (size_t)2 * v.W * (band_kc + 1) * sizeof(double) > 64 * 1024) band_kc /= 2;
+    const size_t band_lds = (size_t)2 * v.W * (band_kc + 1) * sizeof(double);
     if (band_lds > 150 * 1024) return fail(-1, "grid rows of %d cells exceed the band kernel's LDS tiles", v.W);
     ScoreView sv = e->sv;
     if (v.mode == IPP_DENSE) sv.P = v.cov + (size_t)env_id * v.cov_slot;
@@ -726,7 +728,7 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
     else                 hipLaunchKernelGGL((k_score_hdr<25>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status);
     if (v.mode == IPP_FACTOR)
         hipLaunchKernelGGL(k_score_densify, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id);
-    hipLaunchKernelGGL(k_score_band, dim3(v.H, kScoreDCap + 1), dim3(256), band_lds, s, v, sv);
+    hipLaunchKernelGGL(k_score_band, dim3(v.H, kScoreDCap + 1, kScoreSplit), dim3(256), band_lds, s, v, sv, band_kc);
     if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_eval<9>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     else                 hipLaunchKernelGGL((k_score_eval<25>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     HIP_TRY(hipGetLastError());

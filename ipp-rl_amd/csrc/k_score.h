@@ -19,6 +19,7 @@ namespace ipp {
 
 constexpr int kScoreDCap = 9;                                      // footprints up to 10 x 10 cells
 constexpr int kScoreBandCap = (kScoreDCap + 1) * (2 * kScoreDCap + 1);  // doubles per cell
+constexpr int kScoreSplit = 4;                                     // k-range splits of the band kernel (partials summed in order)
 
 struct ScoreHdr {
     int xl, yu, w, h;
@@ -31,7 +32,7 @@ struct ScoreView {
     int* extent;        // [2] max (h - 1, w - 1) over the valid candidates
     float* mask;        // [Npad] 1 / 0
     float* P;           // [N][Npad] (scratch for factor engines, the env slot for dense engines)
-    double* G;          // [N][kScoreBandCap], entry (dy, dx) at dy * (2 Dx + 1) + dx + Dx, dy >= 0
+    double* G;          // [kScoreSplit][N][kScoreBandCap] partial sums over k ranges; entry (dy, dx) at dy * (2 Dx + 1) + dx + Dx, dy >= 0
 };
 
 struct PrevAction { double p[3]; };
@@ -158,20 +159,24 @@ __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int
 }
 
 // ---------------------------------------------------------------- G band: G[i][j] = sum_k mask_k P[i][k] P[j][k]
-// Workgroup (y, dy): cells i of grid row y against cells j of grid row y + dy, |col_i - col_j| <= Dx, fp64.
-// LDS: mask-weighted P rows of the i block and P rows of the j block for KC columns k at a time.
-__global__ __launch_bounds__(256) void k_score_band(View v, ScoreView sv) {
-    constexpr int KC = 64;
+// Workgroup (y, dy, z): cells i of grid row y against cells j of grid row y + dy, |col_i - col_j| <= Dx, over the
+// z-th quarter of the k range, fp64.  LDS: mask-weighted P rows of the i block and P rows of the j block, converted
+// to fp64 once, KC columns k at a time.  The kScoreSplit partial bands are added in order by k_score_eval.
+__global__ __launch_bounds__(256) void k_score_band(View v, ScoreView sv, int kc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_band[];
     const int W = v.W;
-    float* pi = reinterpret_cast<float*>(smem_band);   // [W][KC + 1]
-    float* pj = pi + (size_t)W * (KC + 1);             // [W][KC + 1]
+    const int ld = kc + 1;
+    double* pi = reinterpret_cast<double*>(smem_band);  // [W][kc + 1]
+    double* pj = pi + (size_t)W * ld;                    // [W][kc + 1]
     const int Dy = sv.extent[0], Dx = sv.extent[1];
-    const int y = blockIdx.x, dy = blockIdx.y;
+    const int y = blockIdx.x, dy = blockIdx.y, z = blockIdx.z;
     if (dy > Dy || y + dy >= v.H) return;
     const int nb = 2 * Dx + 1;
     const int n_out = W * nb;                          // (ci, dx) pairs
     const int tid = threadIdx.x;
+    const int k_per = ((v.N + kScoreSplit - 1) / kScoreSplit + kc - 1) / kc * kc;
+    const int k_lo = z * k_per, k_hi = min(v.N, k_lo + k_per);
+    double* Gz = sv.G + (size_t)z * v.N * kScoreBandCap;
     constexpr int OPT = 8;                             // outputs per thread and pass
     const float* Pi = sv.P + (size_t)(y * W) * v.Npad;
     const float* Pj = sv.P + (size_t)((y + dy) * W) * v.Npad;
@@ -188,24 +193,24 @@ __global__ __launch_bounds__(256) void k_score_band(View v, ScoreView sv) {
                 if (ci + dx >= 0 && ci + dx < W) { oci[o] = ci; ocj[o] = ci + dx; }
             }
         }
-        for (int k0 = 0; k0 < v.N; k0 += KC) {
+        for (int k0 = k_lo; k0 < k_hi; k0 += kc) {
             __syncthreads();
-            for (int idx = tid; idx < W * KC; idx += 256) {
-                const int c = idx / KC, kk = idx - c * KC;
+            for (int idx = tid; idx < W * kc; idx += 256) {
+                const int c = idx / kc, kk = idx - c * kc;
                 const int k = k0 + kk;
-                const float mk = (k < v.N) ? sv.mask[k] : 0.f;
-                pi[c * (KC + 1) + kk] = (k < v.N) ? mk * Pi[(size_t)c * v.Npad + k] : 0.f;
-                pj[c * (KC + 1) + kk] = (k < v.N) ? Pj[(size_t)c * v.Npad + k] : 0.f;
+                const bool in = k < k_hi;
+                pi[c * ld + kk] = in ? (double)(sv.mask[k] * Pi[(size_t)c * v.Npad + k]) : 0.0;
+                pj[c * ld + kk] = in ? (double)Pj[(size_t)c * v.Npad + k] : 0.0;
             }
             __syncthreads();
 #pragma unroll
             for (int o = 0; o < OPT; ++o) {
                 if (oci[o] < 0) continue;
-                const float* a = pi + oci[o] * (KC + 1);
-                const float* b = pj + ocj[o] * (KC + 1);
+                const double* a = pi + oci[o] * ld;
+                const double* b = pj + ocj[o] * ld;
                 double s = acc[o];
 #pragma unroll 8
-                for (int kk = 0; kk < KC; ++kk) s = fma((double)a[kk], (double)b[kk], s);
+                for (int kk = 0; kk < kc; ++kk) s = fma(a[kk], b[kk], s);
                 acc[o] = s;
             }
         }
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void k_score_band(View v, ScoreView sv) {
         for (int o = 0; o < OPT; ++o) {
             if (oci[o] < 0) continue;
             const int i = y * W + oci[o];
-            sv.G[(size_t)i * kScoreBandCap + dy * nb + (ocj[o] - oci[o]) + Dx] = acc[o];
+            Gz[(size_t)i * kScoreBandCap + dy * nb + (ocj[o] - oci[o]) + Dx] = acc[o];
         }
     }
 }
@@ -252,7 +257,9 @@ __global__ __launch_bounds__(256) void k_score_eval(View v, ScoreView sv, int A,
                 // band entry of the pair with the smaller row first (G is symmetric)
                 const bool swap = (yb < ya);
                 const int ci = swap ? cb : ca, ddy = swap ? ya - yb : yb - ya, ddx = swap ? xa - xb : xb - xa;
-                t += sv.G[(size_t)ci * kScoreBandCap + ddy * nb + ddx + Dx];
+                const size_t gi = (size_t)ci * kScoreBandCap + ddy * nb + ddx + Dx;
+#pragma unroll
+                for (int zz = 0; zz < kScoreSplit; ++zz) t += sv.G[(size_t)zz * v.N * kScoreBandCap + gi];
             }
         }
         const double wpq = bp.weight * bq.weight;
