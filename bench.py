@@ -126,6 +126,7 @@ def main():
     if args.print_args:
         print(json.dumps(workload_key(args)))
         return
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL)
     import torch
     import torch.distributed as dist
 
