@@ -168,6 +168,16 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
                       uint32_t flags, float* reward, int32_t* status, void* stream);
 
 /*
+ * NN input state plane of one env slot: the N x N covariance with the rows / columns outside the adaptive mask
+ * zeroed, min-max normalised (planning/common/features.py:91-101,74-81), fp32, row-major [N][N].
+ *   mean_for_mask [dev] float[N] = adaptive_info["mean"] (the reference masks every state of the history with the
+ *                 CURRENT map mean), or NULL = the slot's own mean; the diagonal is always the slot's
+ *   flags         IPP_ADAPTIVE (0 = no masking)
+ * IPP_FACTOR engines need ipp_config.score_scratch = 1 (the slot is densified into that scratch).
+ */
+int ipp_state_plane(void* engine, int32_t env_id, const float* mean_for_mask, uint32_t flags, float* out, void* stream);
+
+/*
  * Ground-truth generation only: white noise [n][H][W] -> min-max normalised Gaussian random field into the
  * caller buffer gt_out [n][H][W] (no env slot is touched).  Lets the host prepare the next episodes' ground
  * truths on a side stream while ipp_step runs, then install them with ipp_reset(gt = ...).

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ipp_reset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
     "ipp_reset_episode": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "ipp_score_actions": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
+    "ipp_state_plane": (C.c_int, [_P, C.c_int32, _P, C.c_uint32, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),

@@ -36,7 +36,7 @@ def compat_engine(cfg: EngineConfig) -> IPPEngine:
     eng = _ENGINES.get(key)
     if eng is None:
         m_cap = 9 if cfg.resolution >= 2 else 25
-        eng = IPPEngine(cfg, capacity=2, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap)
+        eng = IPPEngine(cfg, capacity=2, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap, score_scratch=True)
         _ENGINES[key] = eng
     return eng
 

@@ -20,6 +20,7 @@
 #include "k_misc.h"
 #include "k_grf_dft.h"
 #include "k_score.h"
+#include "k_plane.h"
 #include "k_prepare.h"
 
 using namespace ipp;
@@ -731,6 +732,27 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
     hipLaunchKernelGGL(k_score_band, dim3(v.H, kScoreDCap + 1, kScoreSplit), dim3(256), band_lds, s, v, sv, band_kc);
     if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_eval<9>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     else                 hipLaunchKernelGGL((k_score_eval<25>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_state_plane(void* engine, int32_t env_id, const float* mean_for_mask, uint32_t flags, float* out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (int rc = check_env(e, env_id)) return rc;
+    if (flags & ~IPP_ADAPTIVE) return fail(-1, "unsupported flag bits 0x%x", flags);
+    if (!e->scoring) return fail(-1, "ipp_state_plane needs ipp_config.score_scratch = 1");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const View& v = e->v;
+    ScoreView sv = e->sv;
+    if (v.mode == IPP_DENSE) sv.P = v.cov + (size_t)env_id * v.cov_slot;
+    hipLaunchKernelGGL(k_plane_mask, dim3((v.Npad + 255) / 256), dim3(256), 0, s, v, env_id, mean_for_mask, flags, sv.mask, sv.extent);
+    if (v.mode == IPP_FACTOR)
+        hipLaunchKernelGGL(k_score_densify, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id);
+    const int blocks = std::min(v.N, 1024);
+    hipLaunchKernelGGL(k_plane_minmax, dim3(blocks), dim3(256), 0, s, v, sv.P, sv.mask, sv.extent);
+    hipLaunchKernelGGL(k_plane_write, dim3(blocks), dim3(256), 0, s, v, sv.P, sv.mask, sv.extent, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -184,6 +184,20 @@ class IPPEngine:
         self._keep_score = a
         return reward, status
 
+    def state_plane(self, env: int, mean_for_mask=None, adaptive: bool = True, out=None):
+        """Masked, min-max normalised N x N covariance plane of slot `env` (features.py:91-101), device fp32 [N, N].
+        mean_for_mask: the map mean the mask is taken from (None: the slot's own).  Needs score_scratch=True."""
+        torch = _torch()
+        mu = self._dev(mean_for_mask, torch.float32)
+        if mu is not None:
+            mu = mu.reshape(-1)
+        if out is None:
+            out = torch.empty((self.n_cells, self.n_cells), dtype=torch.float32, device=self.device)
+        _ffi.check(self._lib.ipp_state_plane(self._h, int(env), self._ptr(mu), _ffi.IPP_ADAPTIVE if adaptive else 0,
+                                             self._ptr(out), self.stream))
+        self._keep_plane = mu
+        return out
+
     def generate_grf(self, white_noise, out=None, stream=None):
         """white noise [n, N] -> normalised GRF [n, N] in a caller tensor (no env slot touched)."""
         torch = _torch()

@@ -573,3 +573,58 @@ def metric_mll(gt, est, diag) -> float:
 def metric_wmll(gt, est, diag) -> float:
     """planning/evaluation_metrics.py:48-58."""
     return float(np.mean(_wrmse_weights(gt, est) * _log_loss(gt, est, diag)))
+
+
+# --------------------------------------------------------------------------- NN input feature planes ("next" row 3)
+def min_max_normalize(x: np.ndarray) -> np.ndarray:
+    """planning/common/features.py:74-81."""
+    lo, hi = np.min(x), np.max(x)
+    if lo == hi:
+        return x / hi
+    return (x - lo) / (hi - lo)
+
+
+def state_plane(state: np.ndarray, mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """Rows / columns outside the adaptive mask zeroed, then min-max normalised. features.py:91-101 (the reference
+    zeroes the caller's array in place; this restatement works on a copy)."""
+    st = np.array(state, dtype=np.float64, copy=True)
+    if mask is not None:
+        st[~mask, :] = 0
+        st[:, ~mask] = 0
+    return min_max_normalize(st)
+
+
+def costs_plane(cfg: OracleConfig, current_action, min_altitude: float, uav=None) -> np.ndarray:
+    """features.py:60-71: row i = cost from the current position (at min_altitude) to the action of index
+    i = x_dim * col + row (planning/common/actions.py:71-93), broadcast along the row, min-max normalised."""
+    cur = np.array(current_action, dtype=np.float64)
+    cur[-1] = min_altitude
+    n = cfg.n_cells
+    plane = np.zeros((n, n))
+    for row in range(cfg.y_dim):
+        for col in range(cfg.x_dim):
+            a = np.array([cfg.resolution * col + 0.5 * cfg.resolution, cfg.resolution * row + 0.5 * cfg.resolution, min_altitude])
+            plane[int(cfg.x_dim * col + row), :] = action_cost(cur, a, uav)
+    return min_max_normalize(plane)
+
+
+def input_feature_planes(cfg: OracleConfig, states, positions, budgets, max_history_length: int, min_altitude: float,
+                         max_altitude: float, adaptive_info: Optional[Dict] = None, uav: Optional[Dict] = None,
+                         use_action_costs_input: bool = False) -> np.ndarray:
+    """generate_input_feature_planes with altitude planes (features.py:83-151).  states[0] is the newest entry of the
+    history.  Per entry: [state, x, y, z, budget] planes of shape N x N; missing entries are zero planes."""
+    n = cfg.n_cells
+    ones = np.ones((n, n))
+    planes = []
+    for st, pos, budget in zip(states, positions, budgets):
+        mask = None
+        if adaptive_info is not None:
+            mask = adaptive_mask(adaptive_info["mean"], st, adaptive_info["value_threshold"], adaptive_info["interval_factor"])
+        extent = cfg.x_dim * cfg.resolution  # features.py:49-50 divides x and y by x_dim * resolution
+        planes.extend([state_plane(st, mask), pos[0] / extent * ones, pos[1] / extent * ones,
+                       (pos[2] - min_altitude) / (max_altitude - min_altitude) * ones, budget * ones])
+    for _ in range(max_history_length - len(states)):
+        planes.extend([np.zeros((n, n))] * 5)
+    if use_action_costs_input:
+        planes.append(costs_plane(cfg, positions[0], min_altitude, uav))
+    return np.array(planes)

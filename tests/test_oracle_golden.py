@@ -199,3 +199,27 @@ def test_smoke_values_from_survey():
         assert orc.project_fov(cfg, act) == fov
         _, Pn, _ = orc.update_grid_map(cfg, P0, None, np.array(act, float), cov_only=True)
         assert abs((np.trace(P0) - np.trace(Pn)) - red) < 1e-6
+
+
+def test_feature_planes_vs_reference(golden):
+    """planning/common/features.py:83-151 (masked, min-max normalised N x N state planes,
+    position / budget / cost planes, zero padding of a short history)."""
+    g = golden("features")
+    cfg = orc.OracleConfig(x_dim=10, y_dim=10)
+    uav = {"max_v": 2, "max_a": 2}
+    info = {"mean": g["mean"], "value_threshold": 0.4, "interval_factor": 0}
+    # the generator pushes states[0..k) oldest first, so the history's newest entry is states[k - 1]
+    def hist(k):
+        idx = list(range(k))[::-1]
+        return [g["states"][i] for i in idx], [g["positions"][i] for i in idx], [g["budgets"][i] for i in idx]
+
+    st, pos, bud = hist(3)
+    got = orc.input_feature_planes(cfg, st, pos, bud, 3, 8, 14, info, uav, use_action_costs_input=True)
+    assert got.shape == g["planes_full_adaptive_costs"].shape
+    assert np.max(np.abs(got - g["planes_full_adaptive_costs"])) < 1e-12
+    st, pos, bud = hist(2)
+    got = orc.input_feature_planes(cfg, st, pos, bud, 3, 8, 14, None, uav)
+    assert np.max(np.abs(got - g["planes_two_plain"])) < 1e-12
+    st, pos, bud = hist(1)
+    got = orc.input_feature_planes(cfg, st, pos, bud, 3, 8, 14, info, uav)
+    assert np.max(np.abs(got - g["planes_one_adaptive"])) < 1e-12

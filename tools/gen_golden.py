@@ -444,9 +444,48 @@ def gen_costs():
          t_vec=ref_actions.compute_flight_times(a, b[0], uav))
 
 
+# ----------------------------------------------------------------------------- NN input feature planes (8(f) rank 3)
+def gen_features():
+    """planning/common/features.py:83-151 on a 10x10 grid: history of covariance states -> masked, min-max
+    normalised N x N planes + position / budget / cost planes.  The reference masks the history's arrays IN PLACE
+    (features.py:98-99); copies are passed so that the recorded `states` are the unmasked inputs."""
+    from planning.common.features import EpisodeHistory, generate_input_feature_planes
+
+    dim = 10
+    params = load_params(dim, dim)
+    gm, sensor, sim, mapping = build(params, seed=4)
+    uav = {"max_v": 2, "max_a": 2}
+    acts = [np.array([2.0, 2.0, 14.0]), np.array([18.0, 22.0, 8.0]), np.array([30.0, 10.0, 9.0])]
+    budgets = [200.0, 171.5, 160.25]
+    states, means = [gm.cov_matrix.copy()], [gm.mean.copy()]
+    for a in acts[1:]:
+        z = sensor.take_measurement(a, verbose=False)  # rf = 1 altitudes: pinned
+        mapping.update_grid_map(a, z)
+        states.append(gm.cov_matrix.copy())
+        means.append(gm.mean.copy())
+    out = dict(states=np.array(states), positions=np.array(acts), budgets=np.array(budgets), mean=gm.mean.copy())
+
+    def planes(n_hist, adaptive, costs):
+        hist = EpisodeHistory(3)
+        for k in range(n_hist):  # push order: oldest first, so states[0] of the history is the newest
+            hist.push(states[k].copy(), acts[k].copy(), budgets[k])
+        info = {"mean": gm.mean.copy(), "value_threshold": 0.4, "interval_factor": 0} if adaptive else None
+        return generate_input_feature_planes(mapping, hist, 8, 14, info, uav, use_action_costs_input=costs)
+
+    out["planes_full_adaptive_costs"] = planes(3, True, True)
+    out["planes_two_plain"] = planes(2, False, False)
+    out["planes_one_adaptive"] = planes(1, True, False)
+    save("features", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("writing golden vectors to", OUT)
+    only = sys.argv[1:]
+    if only:  # e.g. `python tools/gen_golden.py features`: regenerate the named fixtures only
+        for name in only:
+            globals()["gen_" + name]()
+        return
     gen_footprints()
     gen_measurement_model()
     gen_priors()
@@ -456,6 +495,7 @@ def main():
     gen_fallback()
     gen_greedy()
     gen_costs()
+    gen_features()
     shapes = sorted(set(RESIZE_CALLS))
     print("cv2.resize stub was called with (src shape, dsize):", shapes)
 
