@@ -203,9 +203,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 
         // ---- stream the stored rows: acc += row_k[cells] * Q[k,:]  (Q carries the sign of the downdate)
         if (nact > 0 && !(IPP_GF_ABLATE & 4)) {
-            const int last = r - 1;
             typedef float rowv __attribute__((ext_vector_type(VEC)));
             auto col_of = [&](int a) -> int { return __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]); };
+            const int safe_k = col_of(0);  // nact > 0: the first column stored on this tile
             // Groups of KP rows, requested together and then consumed in order.  No row registers are carried
             // across the back edge: hipcc turns a carried (ping-pong) group into register copies at the loop end,
             // and each copy waits for its load, which empties the memory pipe once per iteration.  Overlap across
@@ -216,7 +216,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     kk[i] = col_of(a + i);
-                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)min(kk[i], last) * npad + cell0));
+                    // padding entries (kk == r, zero Q row) read a column that IS stored on this tile: a column that is
+                    // not stored here holds uninitialised memory, and NaN * 0 would poison the accumulators
+                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)(kk[i] < r ? kk[i] : safe_k) * npad + cell0));
                 }
                 __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
 #pragma unroll

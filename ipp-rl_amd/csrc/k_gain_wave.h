@@ -159,13 +159,15 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
 
         // ---- stream the stored rows: acc += row_k[cells] * Q[k,:]; Q row k is wave-uniform -> scalar loads
         if (nact > 0) {
-            const int last = r - 1;
             auto col_of = [&](int a) -> int { return __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]); };
+            const int safe_k = col_of(0);  // nact > 0: the first column stored on this tile
             // the row registers stay VEC-wide vector values so that the loop-carried group is one register tuple per
             // row (scalarised, the back edge needs copies, and every copy waits for its load)
             typedef float rowv __attribute__((ext_vector_type(VEC)));
             auto fetch = [&](int k) -> rowv {
-                return __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)min(k, last) * npad + cell0));
+                // padding entries (k == r, zero Q row) read a column that IS stored on this tile: a column that is not
+                // stored here holds uninitialised memory, and NaN * 0 would poison the accumulators
+                return __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)(k < r ? k : safe_k) * npad + cell0));
             };
             auto consume = [&](const rowv (&u)[KP], const int (&kq)[KP]) {
 #pragma unroll

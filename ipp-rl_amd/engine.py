@@ -9,6 +9,7 @@ GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -102,6 +103,8 @@ class IPPEngine:
         nbytes = C.c_uint64(0)
         _ffi.check(self._lib.ipp_engine_arena_bytes(C.byref(c), C.byref(nbytes)))
         self.arena = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+        if os.environ.get("IPP_POISON_ARENA"):  # tests: every float the engine does not initialise reads as NaN
+            self.arena.fill_(0xFF)
         base = (self.arena.data_ptr() + 255) // 256 * 256
         handle = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
