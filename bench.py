@@ -191,6 +191,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
     bad = int((env.status != 0).sum().item())
+    bad_rewards = int((~torch.isfinite(env.reward)).sum().item())
 
     # ---- roofline leg: same steps again with HIP events around the streaming kernel (rank 0 reports)
     eng.profile(True)
@@ -252,7 +253,7 @@ def main():
                 "envs_per_gpu": B, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,
                 "episode_steps": T, "episode_phase": "staggered (stationary rank mix)",
                 "mean_rank_after_step": mean_rank_after, "tile_threads": int(eng.info.tile_threads), "window_rows": int(eng.info.window_rows),
-                "items_with_nonzero_status": bad, "rng": "device Philox4x32-10",
+                "items_with_nonzero_status": bad, "non_finite_rewards": bad_rewards, "rng": "device Philox4x32-10",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
