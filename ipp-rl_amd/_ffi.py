@@ -109,7 +109,12 @@ def load():
         )
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        try:
+            fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        except AttributeError:
+            if os.environ.get("IPP_AB_OLD_LIB"):  # tools/ab_kernels.py timing an older build of the same ABI version
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     if lib.ipp_abi_version() != ABI_VERSION:

@@ -41,6 +41,25 @@ struct ItemHdr {
     double cost_d, nv_d;
 };
 
+// The item header is the same for every lane, but it reaches the streaming kernels through vector loads (LDS or
+// global), so the compiler keeps its ~30 words in VGPRs for the whole tile loop.  readfirstlane moves them to SGPRs.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double uni(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ ItemHdr uniform_hdr(const ItemHdr& h) {
+    ItemHdr o;
+    o.env = uni(h.env); o.dst = uni(h.dst); o.rank = uni(h.rank); o.status = uni(h.status);
+    o.xl = uni(h.xl); o.xr = uni(h.xr); o.yu = uni(h.yu); o.yd = uni(h.yd);
+    o.w = uni(h.w); o.h = uni(h.h); o.nx = uni(h.nx); o.ny = uni(h.ny);
+    o.rf = uni(h.rf); o.m = uni(h.m); o.f = uni(h.f); o.rows = uni(h.rows);
+    o.fallback = uni(h.fallback); o.commit = uni(h.commit); o.t_lo = uni(h.t_lo); o.t_hi = uni(h.t_hi);
+    o.cost = uni(h.cost); o.sv = uni(h.sv); o.ls = uni(h.ls); o.nv = uni(h.nv);
+    o.cost_d = uni(h.cost_d); o.nv_d = uni(h.nv_d);
+    return o;
+}
+
 // Everything the kernels need, passed by value.
 struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x, T = blockDim.x;
-    const ItemHdr h = v.hdr[item];
+    const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int r = h.rank;
     if (h.m == 0 || h.status == IPP_STATUS_NOT_PD) {
         if (tid == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int lane = threadIdx.x;
-    const ItemHdr h = v.hdr[item];
+    const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int m = h.m, r = h.rank;
     if (m == 0 || h.status == IPP_STATUS_NOT_PD) {
         if (lane == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;

@@ -191,6 +191,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         h.rows = (MODE == IPP_FACTOR) ? h.rank : h.f;
         if (h.status == IPP_STATUS_BAD_FOOTPRINT) { h.m = 0; h.f = 0; h.rows = 0; h.commit = 0; }
     }
+    h = uniform_hdr(h);  // every thread computed the same values: keep them in SGPRs from here on
     if (tid == 0) {
         *hs = h;
         okflag[0] = 1;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true>(
         v, item, env_ids, nullptr, action, prev_action, meas_noise, flags, status_out, nullptr, nullptr, nullptr, lds.small,
         lds.work, 1, QS, nullptr, lds.Ls, nullptr, lds.ys, nullptr, lds.span_s, mid);
-    const ItemHdr h = *hs;  // (every path of the prologue ends with a barrier)
+    const ItemHdr h = uniform_hdr(*hs);  // (every path of the prologue ends with a barrier)
     IPP_TICK_DECL(tick);
     if (h.m == 0) {
         if (tid == 0) reward_out[item] = 0.f;
