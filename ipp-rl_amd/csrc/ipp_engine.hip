@@ -68,6 +68,7 @@ struct Engine {
     bool grf_dft = false;  // even square grids up to 100: k_grf_dft instead of k_grf_conv + k_grf_norm
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
+    int lut_rows = 0;  // workgroup-per-item factor kernels: rows |drow| of the prior table kept in LDS
     bool profile = false;
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
@@ -270,7 +271,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
         ProfScope ps(e, 0, s);
         hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, v.q, env_ids, n, action, prev,
-                           noise, flags, e->lut_cap, status, reward);
+                           noise, flags, e->lut_rows, status, reward);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
     }
@@ -290,7 +291,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
         if (v.mode == IPP_FACTOR && v.window_rows > 0 && v.T == kWave)
             hipLaunchKernelGGL((k_gain_wave<MC, VEC>), dim3(n), dim3(kWave), e->gain_lds, s, v, v.q, n, flags, reward);
         else if (v.mode == IPP_FACTOR && v.window_rows > 0)
-            hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_cap, reward);
+            hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_rows, reward);
         else if (v.mode == IPP_FACTOR)
             hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
         else
@@ -493,12 +494,18 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         e->fused = (v.T == kStepThreads);
         if (const char* fu = getenv("IPP_FUSED")) e->fused = e->fused && atoi(fu) != 0;  // A/B experiments
         const int waves = v.T / 64;
+        // prior table rows: a tile that holds new columns lies within window_rows of the footprint, so
+        // |drow| <= window_rows + rows a tile spans + footprint height; farther rows (tall footprints) use sqrt / exp
+        const int tile_rows = (v.tile_cells + v.W - 1) / v.W + 1;
+        e->lut_rows = std::min(v.H, v.window_rows + tile_rows + 6);
+        while (e->lut_rows > 0 && (size_t)e->lut_rows * v.W > 12288) --e->lut_rows;  // <= 48 KiB
+        const int lutf = e->lut_rows * v.W;
         if (v.meas_cap == 9)
-            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), e->lut_cap, step_small_floats<9>(), waves)
-                                   : GainLds<9>::bytes(v.rank_cap, 0, e->lut_cap, 0, waves);
+            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves)
+                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves);
         else
-            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), e->lut_cap, step_small_floats<25>(), waves)
-                                   : GainLds<25>::bytes(v.rank_cap, 0, e->lut_cap, 0, waves);
+            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves)
+                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves);
         if (v.T == kWave)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;

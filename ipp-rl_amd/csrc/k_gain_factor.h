@@ -43,15 +43,15 @@ struct GainLds {
     static constexpr int QS = (MC + 3) & ~3;
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
-    int* solve_flag; int* span_s; int* fb_yx; float* fb_w; unsigned short* ridx_all;
+    int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all;
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
-        b += (size_t)rank_cap * 4 + (size_t)8 * MC * 4 + (size_t)waves * (rank_cap + 8) * 2;
+        b += (size_t)((rank_cap + 3) & ~3) * 4 + (size_t)8 * MC * 4 + (size_t)waves * kWave * 8 * 4 + (size_t)waves * (rank_cap + 8) * 2;
         return (b + 15) & ~(size_t)15;
     }
     // work: HT staging rows of the fused prologue (0 floats for the stand-alone kernel); lut: prior table;
     // small: the fused prologue's fp64 scratch (0 floats for the stand-alone kernel)
-    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats) {
+    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats, int waves) {
         Ls = reinterpret_cast<float*>(base);
         ys = Ls + MC * MC;
         work = Ls + LQ;
@@ -62,9 +62,12 @@ struct GainLds {
         done_waves = next_tile + 1;
         solve_flag = reinterpret_cast<int*>(red + 14);  // fused kernel: 0 = L^-1 / y pending, 1 = ready, 2 = S not PD
         span_s = reinterpret_cast<int*>(red + 16);
-        fb_yx = span_s + rank_cap;                         // [MC][4] footprint cell (row << 16 | col) of block b
+        fb_yx = span_s + ((rank_cap + 3) & ~3);            // [MC][4] footprint cell (row << 16 | col) of block b
         fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);   // [MC][4] weight of that cell (0 for padding)
-        ridx_all = reinterpret_cast<unsigned short*>(fb_w + 4 * MC);
+        // [waves][2][64 lanes][4]: mean / diag of the wave's current tile, parked here across the stream loop
+        // (typed pointer arithmetic only: an integer round trip would turn the LDS pointer into a flat one)
+        stage = fb_w + 4 * MC;
+        ridx_all = reinterpret_cast<unsigned short*>(stage + (size_t)waves * kWave * 8);
     }
 };
 
@@ -83,7 +86,8 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
     }
 }
 
-// Tile loop + per-item results; expects Ls / ys, the block tables, the prior table (when use_lut), span_s[0..r)
+// Tile loop + per-item results; expects Ls / ys, the block tables, the prior table P0(|drow| < lut_rows, |dcol|)
+// (row distances beyond it fall back to sqrt / exp), span_s[0..r)
 // and the two counters (zeroed) in LDS, visible to the whole workgroup.
 // qrows: the item's Q rows [k][QS] in global scratch, followed by >= 8 zero rows.  It must be a pointer the
 // compiler can prove read-only (a `const float* __restrict__` kernel argument): only then are the wave-uniform row
@@ -93,7 +97,7 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // per cell) once lds.solve_flag says wave 0 has finished the m x m algebra.  The stream therefore starts right
 // after the gather instead of after S / Cholesky / L^-1 / Q.
 template <int MC, int VEC, int KP, bool PRE>
-__device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, bool use_lut,
+__device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out) {
     constexpr int kWaveTile = VEC * kWave;  // cells per wave tile
@@ -109,6 +113,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
     unsigned short* ridx = lds.ridx_all + (size_t)wave * (v.rank_cap + 8);
+    float* stage_w = lds.stage + (size_t)wave * kWave * 8;  // (VEC <= 4)
     const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
     const size_t npad = (size_t)v.Npad;
     double wave_part = 0.0;
@@ -125,9 +130,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile > h.t_hi) break;
         const int cell0 = tile * kWaveTile + VEC * lane;
-        float mean_in[VEC], diag_in[VEC];  // requested now, consumed in the tile's epilogue
-        load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, mean_in);
-        load_vec<VEC>(v.diag + (size_t)h.env * npad + cell0, diag_in);
+        // mean / diag of the tile: requested now, parked in LDS after the base term (the loads have landed by then),
+        // read back in the epilogue.  Kept in registers across the stream loop they were spilled to scratch, which
+        // cost 10 % of the kernel (A/B with the loads ablated).
+        float md_in[2][VEC];
+        load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, md_in[0]);
+        load_vec<VEC>(v.diag + (size_t)h.env * npad + cell0, md_in[1]);
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
         int nact = 0;
@@ -161,6 +169,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
+            // the table covers |drow| < lut_rows: decided per tile (wave-uniform) from the farthest tile / footprint rows
+            const int trow0 = (tile * kWaveTile) / v.W, trow1 = min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
+            const int dmax = max(max(abs(trow0 - h.yu), abs(trow0 - h.yd)), max(abs(trow1 - h.yu), abs(trow1 - h.yd)));
+            const bool tile_lut = dmax < lut_rows;
             auto block_term = [&](int b, float (&cb)[VEC]) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
@@ -172,7 +184,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) {
                         const int dr = abs(crow[c] - fy), dc = abs(ccol[c] - fx);
-                        const float p0 = use_lut ? lut[dr * v.W + dc] : matern_f(dr, dc, s3, h.sv);
+                        const float p0 = tile_lut ? lut[dr * v.W + dc] : matern_f(dr, dc, s3, h.sv);
                         cb[c] = fmaf(wa, p0, cb[c]);
                     }
                 }
@@ -199,6 +211,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     }
                 }
             }
+        }
+
+        {
+            float* st = stage_w + lane * VEC;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { st[c] = md_in[0][c]; st[kWave * VEC + c] = md_in[1][c]; }
         }
 
         // ---- stream the stored rows: acc += row_k[cells] * Q[k,:]  (Q carries the sign of the downdate)
@@ -265,6 +283,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
         }
         const bool commit = h.commit && !dead;
+        float mean_in[VEC], diag_in[VEC];
+        {
+            const float* st = stage_w + lane * VEC;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { mean_in[c] = st[c]; diag_in[c] = st[kWave * VEC + c]; }
+        }
 
         // ---- epilogue for this tile
         float dred[VEC], dmean[VEC];
@@ -344,11 +368,11 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 // q_all == v.q, passed separately so that it is a read-only kernel argument (scalar loads of the Q rows).
 template <int MC, int VEC>
 __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, const float* __restrict__ q_all, int n_items,
-                                                                   unsigned flags, int lut_cap,
+                                                                   unsigned flags, int lut_rows,
                                                                    float* __restrict__ reward_out) {
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_cap, 0);
+    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave);
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -363,16 +387,15 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; }
     for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
     fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
-    const bool use_lut = v.N <= lut_cap;
-    if (use_lut) {
+    {
         const float s3 = (float)(kSqrt3 * v.res) / h.ls;
-        for (int i = tid; i < v.N; i += T) {
+        for (int i = tid; i < lut_rows * v.W; i += T) {
             const int dr = i / v.W, dc = i - dr * v.W;
             lds.lut[i] = matern_f(dr, dc, s3, h.sv);
         }
     }
     __syncthreads();
-    gain_tiles<MC, VEC, IPP_GF_PIPE, false>(v, h, item, flags, use_lut, lds, blk + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_GF_PIPE, false>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
 }
 
 }  // namespace ipp

@@ -39,27 +39,25 @@ template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     View v, const float* __restrict__ q_ro, const int* __restrict__ env_ids, int n_items,
     const double* __restrict__ action, const double* __restrict__ prev_action, const float* __restrict__ meas_noise,
-    unsigned flags, int lut_cap, int* __restrict__ status_out, float* __restrict__ reward_out) {
+    unsigned flags, int lut_rows, int* __restrict__ status_out, float* __restrict__ reward_out) {
     constexpr int QS = (MC + 3) & ~3;
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
-    const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_cap, step_small_floats<MC>());
+    const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
+                          kStepThreads / kWave);
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x;
-    const bool use_lut = v.N <= lut_cap;
 
     // ---- phase A: header, observation, gather of HT(i,k) = work[k*QS + i].  While the footprint-dependent loads are
     // in flight the workgroup builds the prior table and the block tables (pure arithmetic on the header).
     auto mid = [&](const ItemHdr& hh) {
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
-        if (use_lut) {
-            const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
-            for (int i = tid; i < v.N; i += kStepThreads) {
-                const int dr = i / v.W, dc = i - dr * v.W;
-                lds.lut[i] = matern_f(dr, dc, s3, hh.sv);
-            }
+        const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
+        for (int i = tid; i < lut_rows * v.W; i += kStepThreads) {
+            const int dr = i / v.W, dc = i - dr * v.W;
+            lds.lut[i] = matern_f(dr, dc, s3, hh.sv);
         }
     };
     ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true>(
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true>(v, h, item, flags, use_lut, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_SF_PIPE, true>(v, h, item, flags, lut_rows, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
 }
 
 }  // namespace ipp
