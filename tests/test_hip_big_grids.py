@@ -33,6 +33,7 @@ def make(dim, window_rows, tile_threads, capacity):
 @pytest.mark.parametrize("dim,window_rows,tile_threads", [
     (64, 12, 256), (64, 12, 128), (64, 12, 64), (64, 0, 0),
     (120, 12, 256), (120, 12, 128), (120, 12, 64), (120, 0, 0), (120, 1000, 256),
+    (200, 12, 256), (200, 0, 0),  # BASELINE configs[4] grid size
 ])
 def test_factor_step_vs_oracle_factor_form(dim, window_rows, tile_threads):
     """B envs x 6 steps with clustered revisits (so that stored columns are streamed on the footprint tiles),
