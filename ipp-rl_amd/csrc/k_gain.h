@@ -33,9 +33,9 @@ namespace ipp {
 #define IPP_NT_LOADS 1  // +6..10 % on MI355X: rows are streamed once, Q / headers stay in L2
 #endif
 #ifndef IPP_GAIN_GROUP
-#define IPP_GAIN_GROUP 4  // rows per request group; 0 = carried ping-pong groups (A/B on MI355X: 1.5% slower)
+#define IPP_GAIN_GROUP 4  // rows per request group (a carried 2 x 4 ping-pong measured 1.5 % slower, groups of 8 spill)
 #endif
-constexpr int kPipe = IPP_KPIPE;  // row loads per ping-pong group (2 groups in flight per wave)
+constexpr int kPipe = IPP_KPIPE;  // zero Q rows kept behind a staged chunk: 2 * kPipe (>= IPP_GAIN_GROUP); row pipeline of k_downdate
 
 template <int VEC> struct VecIO;
 template <> struct VecIO<4> {
@@ -97,23 +97,6 @@ __device__ __forceinline__ void stream_rows(const float* __restrict__ cov_src,
         const int kc = min(k, last_row);  // rows past the end re-read the last row against a zero Q row
         return (size_t)__builtin_amdgcn_readfirstlane(rowidx[kc]) * npad;
     };
-    // ping-pong register buffers: while one group of kPipe rows is consumed the next is in flight
-    auto consume = [&](const float (&u)[kPipe][VEC], int kbase) {
-#pragma unroll
-        for (int i = 0; i < kPipe; ++i) {
-            float qv[QS];
-#pragma unroll
-            for (int t4 = 0; t4 < QS / 4; ++t4) {
-                const float4 q4 = *reinterpret_cast<const float4*>(&Qs[(kbase + i) * QS + 4 * t4]);
-                qv[4 * t4 + 0] = q4.x; qv[4 * t4 + 1] = q4.y; qv[4 * t4 + 2] = q4.z; qv[4 * t4 + 3] = q4.w;
-            }
-#pragma unroll
-            for (int j = 0; j < MC; ++j)
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(u[i][c], qv[j], acc[c][j]);
-        }
-    };
-#if IPP_GAIN_GROUP
     // groups of G rows requested together, then consumed; nothing loaded is carried over the back edge
     // (hipcc turns a carried group into register copies that each wait for their load, see k_gain_wave.h)
     constexpr int G = IPP_GAIN_GROUP;
@@ -140,19 +123,6 @@ __device__ __forceinline__ void stream_rows(const float* __restrict__ cov_src,
             if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most two Q rows in registers
         }
     }
-#else
-    float ua[kPipe][VEC], ub[kPipe][VEC];
-#pragma unroll
-    for (int i = 0; i < kPipe; ++i) load_stream<VEC>(cov_src + row_base(k0 + i) + cell0, ua[i]);
-    for (int kk = 0; kk < cnt; kk += 2 * kPipe) {
-#pragma unroll
-        for (int i = 0; i < kPipe; ++i) load_stream<VEC>(cov_src + row_base(k0 + kk + kPipe + i) + cell0, ub[i]);
-        consume(ua, kk);
-#pragma unroll
-        for (int i = 0; i < kPipe; ++i) load_stream<VEC>(cov_src + row_base(k0 + kk + 2 * kPipe + i) + cell0, ua[i]);
-        consume(ub, kk + kPipe);
-    }
-#endif
 }
 
 template <int MC, int VEC, int MODE>

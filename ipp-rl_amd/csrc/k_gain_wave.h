@@ -18,11 +18,8 @@
 #include "ipp_common.h"
 #include "k_gain.h"
 
-#ifndef IPP_GW_PINGPONG
-#define IPP_GW_PINGPONG 0
-#endif
 #ifndef IPP_GW_PIPE
-#define IPP_GW_PIPE (IPP_GW_PINGPONG ? 4 : 12)  // rows of U requested per group (A/B on MI355X: 4: 0.46 ms, 8: 0.42, 12: 0.40)
+#define IPP_GW_PIPE 12  // rows of U requested per group (A/B on MI355X: 4: 0.46 ms, 8: 0.42, 12: 0.40; ping-pong 2 x 4: 0.44)
 #endif
 #ifndef IPP_GW_ABLATE
 #define IPP_GW_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no Q loads
@@ -182,29 +179,6 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
                         for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(u[i][c], qv[j], acc[c][j]);
                 }
             };
-#if IPP_GW_PINGPONG
-            rowv ua[KP], ub[KP];
-            int ka[KP], kb[KP];
-#pragma unroll
-            for (int i = 0; i < KP; ++i) {
-                ka[i] = col_of(i);
-                ua[i] = fetch(ka[i]);
-            }
-            for (int a = 0; a < nact; a += 2 * KP) {
-#pragma unroll
-                for (int i = 0; i < KP; ++i) {
-                    kb[i] = col_of(a + KP + i);
-                    ub[i] = fetch(kb[i]);
-                }
-                consume(ua, ka);
-#pragma unroll
-                for (int i = 0; i < KP; ++i) {
-                    ka[i] = col_of(a + 2 * KP + i);
-                    ua[i] = fetch(ka[i]);
-                }
-                consume(ub, kb);
-            }
-#else
             // Groups of KP rows, requested together and then consumed in order.  No row registers are carried
             // across the back edge: hipcc turns a carried (ping-pong) group into register copies at the loop end,
             // and each copy waits for its load, which empties the memory pipe once per iteration.  Overlap across
@@ -220,7 +194,6 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
                 __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
                 consume(u, kk);
             }
-#endif
         }
 
         // ---- epilogue for this tile
