@@ -106,18 +106,20 @@ def pmc_traffic(kernel_name, args):
     (tools/pmc_run.sh -> tools/pmc_summary.py -> profiles/*_pmc_summary.json): FETCH_SIZE x 2 (gfx950 correction,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB.  None when no matching summary is committed:
     counters cannot be collected from inside the timed process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
-    try:
-        with open(path) as fh:
-            summary = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    want = summary.get("_bench_args")
-    if want != workload_key(args):
-        return None
-    for name, counters in summary.items():
-        if name.startswith("ipp::" + kernel_name + "<") and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-            return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+    import glob
+
+    want = workload_key(args)
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary*.json"))):
+        try:
+            with open(path) as fh:
+                summary = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if summary.get("_bench_args") != want:
+            continue
+        for name, counters in summary.items():
+            if name.startswith("ipp::" + kernel_name + "<") and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+                return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
     return None
 
 

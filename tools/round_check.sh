@@ -10,7 +10,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o kt -- python3 bench.py --no-cpu-baseline > $O/trace.log 2>&1
 find $O/trace -name "*kernel_stats.csv" | head -2
 bash tools/pmc_run.sh $O/pmc > $O/pmc_run.log 2>&1
-python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 300 $O/pmc_summary.json
+python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json
+# the other bench variants (exact factor mode, one-wave kernel, dense state): FETCH / WRITE passes only
+for variant in "exact --window-rows 0" "wave --tile-threads 64" "dense --state dense --envs 256"; do
+  set -- $variant; name=$1; shift
+  PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_$name "$@" > $O/pmc_run_$name.log 2>&1
+  python tools/pmc_summary.py $O/pmc_$name 40 > $O/pmc_summary_$name.json 2>>$O/pmc_summary.err
+done
 # keep the merge-back small: drop raw per-dispatch csvs except stats
-find $O/pmc -name "*.csv" -size +2M -delete; find $O/trace -name "*kernel_trace.csv" -size +2M -delete
+find $O -path "*pmc*" -name "*.csv" -size +1M -delete; find $O/trace -name "*kernel_trace.csv" -size +2M -delete
 du -sh $O
