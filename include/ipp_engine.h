@@ -77,7 +77,9 @@ typedef struct ipp_config {
     int32_t tile_threads;     /* 0 = auto; threads per streaming workgroup (multiple of 64, <= 640) */
     int32_t window_rows;      /* IPP_FACTOR: 0 = exact full columns; R > 0 = a new column of U is kept only on the
                                  grid rows within R of its footprint (|Wc| < 3e-8 beyond 12 rows for the example
-                                 prior); streamed bytes shrink accordingly and are counted as such */
+                                 prior); streamed bytes shrink accordingly and are counted as such.
+                                 The dropped entries scale like exp(-sqrt(3) R resolution / length_scale): choose R
+                                 from the prior (12 = 13 length scales for the example config), 0 when in doubt */
     int32_t score_scratch;    /* 1 = reserve the scratch of ipp_score_actions in the arena: band of G = P M P
                                  (N x 190 doubles) and, for IPP_FACTOR, one dense P (N x Npad floats) */
 } ipp_config;

@@ -125,6 +125,15 @@ int plan(const ipp_config& c, Layout& L) {
     L.n_tiles = (n4 + L.T - 1) / L.T;
     L.Npad = L.n_tiles * L.T * L.VEC;
     if (c.state_repr == IPP_FACTOR && c.window_rows > 0) {
+        // the columns are cut where the prior covariance to the footprint has decayed: refuse windows that are too
+        // narrow for this prior (length scale up to 1.2 x nominal under shuffle_prior_cov, mappings.py:238-240)
+        const double d = (double)c.window_rows * c.resolution, ls = 1.2 * c.length_scale;
+        const double a = std::sqrt(3.0) * d / ls;
+        const double bound = c.signal_variance * (1.0 + a) * std::exp(-a);
+        if (c.window_rows < std::max(c.x_dim, c.y_dim) && bound > 1e-6)
+            return fail(-1, "window_rows = %d drops prior covariances up to %.1e (> 1e-6) for length_scale %.3g m at %.3g m cells: "
+                            "use window_rows >= %d, or 0 for exact columns", c.window_rows, bound, c.length_scale, c.resolution,
+                        (int)std::ceil(19.0 * ls / (std::sqrt(3.0) * c.resolution)));
         // windowed factor state: one workgroup per item, wave-granular tiles of 64 * VEC cells (k_gain_factor.h);
         // tile_threads is the workgroup size (waves share the item's Q block and prior table in LDS)
         L.T = (c.tile_threads > 0) ? c.tile_threads : 256;  // 256: fused workgroup kernel (k_step_factor.h), 64: one wave per item (k_gain_wave.h)

@@ -103,3 +103,46 @@ def test_window_batch_vs_oracle_with_clustered_revisits():
         assert np.max(np.abs(host(eng.read_mean(b)) - envs[b].mean)) < TOL
         assert np.max(np.abs(host(eng.read_diag(b)) - np.diag(envs[b].P))) < TOL
     assert np.max(np.abs(host(eng.read_cov(0)) - envs[0].P)) < TOL
+
+
+@pytest.mark.parametrize("tile_threads", [64, 128, 256])
+def test_window_resolution_one_m25(tile_threads):
+    """1 m cells: 5 x 5 footprints at rf = 1 -> m = 25, the MC = 25 / VEC = 2 instantiations of every windowed kernel."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    dim = 24
+    # length scale 0.9175 m at 1 m cells = the example config's 3.67 m at 4 m cells: the dropped entries scale like
+    # exp(-sqrt(3) * window_rows * resolution / length_scale), so window 12 is as accurate as in the default config
+    cfg = EngineConfig(x_dim=dim, y_dim=dim, resolution=1.0, length_scale=0.9175)
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim, resolution=1.0, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b,
+                            length_scale=0.9175)
+    eng = IPPEngine(cfg, capacity=2, state="factor", rank_cap=256, max_measurements=25, window_rows=12,
+                    tile_threads=tile_threads)
+    rs = np.random.RandomState(17)
+    gt = rs.uniform(size=(dim, dim))
+    eng.reset(env_ids=[1], gt=gt[None])
+    st = orc.EnvState(mean=0.5 * np.ones((dim, dim)), P=orc.matern_prior(ocfg), gt=gt, prev=np.array([0.5, 0.5, 5.0]))
+    prev = st.prev.copy()
+    for t in range(8):
+        a = np.array([rs.randint(8, 16) + 0.5, rs.randint(8, 16) + 0.5, [5.0, 4.0, 3.0, 2.0][t % 4]])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), 1)
+        eps = rs.normal(size=25)
+        reward, status = eng.step(a[None], prev[None], env_ids=[1], meas_noise=eps[None])
+        out = orc.env_step(ocfg, st, a, eps[:m])
+        assert int(status[0]) == 0 and abs(float(reward[0]) - out["reward"]) < TOL, (t, float(reward[0]), out["reward"])
+        prev = a
+    assert np.max(np.abs(host(eng.read_mean(1)) - st.mean)) < TOL
+    assert np.max(np.abs(host(eng.read_diag(1)).ravel() - np.diag(st.P))) < TOL
+    assert np.max(np.abs(host(eng.read_cov(1)) - st.P)) < TOL
+
+
+def test_window_too_narrow_for_the_prior_is_refused():
+    """12 rows of 1 m cells are 3 length scales of the example prior: the engine refuses instead of silently truncating."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd._ffi import IppError
+
+    cfg = EngineConfig(x_dim=40, y_dim=40, resolution=1.0)
+    with pytest.raises(IppError, match="window_rows"):
+        IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, max_measurements=25, window_rows=12)
+    IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, max_measurements=25, window_rows=0).close()
+    IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, max_measurements=25, window_rows=100).close()  # >= grid: exact
