@@ -94,10 +94,18 @@ def cpu_baseline(cfg, args):
     t0 = time.perf_counter()
     c_oracle.run_batch(ocfg, P, mean, gts, acts, np.array([2.0, 2.0, 14.0]), eps=eps, threads=threads)
     dt = time.perf_counter() - t0
+    # single-thread rate ("(i) 1 thread; (ii) all cores") on a few env-steps of the same workload
+    B1, T1 = 2, min(T, 10)
+    P1 = np.ascontiguousarray(np.broadcast_to(P0, (B1, n, n)))
+    t1 = time.perf_counter()
+    c_oracle.run_batch(ocfg, P1, 0.5 * np.ones((B1, n)), np.ascontiguousarray(gts[:B1]), np.ascontiguousarray(acts[:T1, :B1]),
+                       np.array([2.0, 2.0, 14.0]), eps=np.ascontiguousarray(eps[:T1, :B1]), threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": B * T / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+        "value_1_thread": B1 * T1 / dt1,
         "sample": f"{B} envs x {T} steps, {cfg.x_dim}x{cfg.y_dim} grid, dense fp64 state (reference representation), "
-                  f"{T}-step episodes, OpenMP over envs ({threads} threads), {dt:.1f} s",
+                  f"{T}-step episodes, OpenMP over envs ({threads} threads), {dt:.1f} s; 1 thread: {B1} envs x {T1} steps, {dt1:.1f} s",
     }
 
 
