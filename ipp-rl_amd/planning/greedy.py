@@ -43,18 +43,39 @@ class GreedyPlanner:
         return get_actions(previous_action, remaining_budget, self._Grid(self.cfg), self.min_altitude, self.max_altitude,
                            self.altitude_spacing, self.uav)
 
-    def score(self, previous_action, candidates) -> np.ndarray:
-        """Reward of every candidate from the current state of slot 0 (nothing is written)."""
+    def score(self, previous_action, candidates, env: int = 0) -> np.ndarray:
+        """Reward of every candidate from the current state of slot `env` (nothing is written)."""
         acts = np.asarray(candidates, dtype=np.float64).reshape(-1, 3)
         if self.shared_pass:
-            reward, _ = self.engine.score_actions(0, acts, previous_action, adaptive=self.adaptive,
+            reward, _ = self.engine.score_actions(env, acts, previous_action, adaptive=self.adaptive,
                                                   use_flight_time=self.uav is not None)
             return reward.detach().cpu().numpy().astype(np.float64)
         prev = np.tile(np.asarray(previous_action, dtype=np.float64), (len(acts), 1))
-        ids = np.zeros(len(acts), dtype=np.int32)
+        ids = np.full(len(acts), env, dtype=np.int32)
         reward, _ = self.engine.step(acts, prev, env_ids=ids, cov_only=True, predict_only=True, adaptive=self.adaptive,
                                      use_flight_time=self.uav is not None)
         return reward.detach().cpu().numpy().astype(np.float64)
+
+    def search(self, previous_action, remaining_budget: float, episode_horizon: int) -> List[np.ndarray]:
+        """greedy_search (planning/common/optimization.py:33-104): `episode_horizon` waypoints, each the first
+        maximiser of the predicted reward from the look-ahead state; the look-ahead runs on scratch slot 1
+        (covariance-only commits, the map mean and the adaptive mask's mean stay those of slot 0)."""
+        prev = np.asarray(previous_action, dtype=np.float64)
+        budget = float(remaining_budget)
+        self.engine.fork([0], [1])
+        waypoints = []
+        for _ in range(episode_horizon):
+            cands = self.candidates(prev, budget)
+            if len(cands) == 0:
+                break
+            r = self.score(prev, cands, env=1)
+            best = np.asarray(cands[int(np.argmax(r))])
+            self.engine.step(best[None], prev[None], env_ids=[1], cov_only=True, adaptive=self.adaptive,
+                             use_flight_time=self.uav is not None)
+            budget -= action_costs(best, prev, self.uav)
+            prev = best
+            waypoints.append(best)
+        return waypoints
 
     def reset(self, white_noise=None, gt=None, prior_scale=None):
         self.engine.reset(env_ids=[0], white_noise=None if white_noise is None else np.asarray(white_noise)[None],

@@ -124,3 +124,18 @@ def test_score_resolution_one_m25():
     for k in rs.choice(A, 16, replace=False):
         want = orc.predict_step(ocfg, st.P, prev, cand[k], UAV, info)[0]
         assert abs(float(reward[k]) - want) < TOL, (k, cand[k], float(reward[k]), want)
+
+
+@pytest.mark.parametrize("state", ["dense", "factor"])
+def test_greedy_search_horizon_three_vs_reference(golden, state):
+    """greedy_search(prev, 200, P0, horizon 3, ...) of the reference: same three waypoints (first maximiser per level,
+    look-ahead on covariance-only predicted states)."""
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.planning.greedy import GreedyPlanner
+
+    g = golden("greedy")
+    for dim in (10, 20):
+        pl = GreedyPlanner(EngineConfig(x_dim=dim, y_dim=dim), 8, 14, 6, UAV, adaptive=True, state=state)
+        pl.reset()
+        wps = pl.search(np.array([2.0, 2.0, 14.0]), 200, 3)
+        assert np.array_equal(np.array(wps), g[f"waypoints_{dim}"]), (dim, wps, g[f"waypoints_{dim}"])
