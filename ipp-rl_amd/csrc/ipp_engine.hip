@@ -390,13 +390,19 @@ void grf_dft_tables_host(int n, double c, std::vector<double>& cs, std::vector<d
 int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
     const View& v = e->v;
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
-    if (e->grf_dft) {  // even n <= 100: half-spectrum DFT, normalisation fused (k_grf_dft.h)
-        const int rows = (v.W + (kGrfThreads / v.W) - 1) / (kGrfThreads / v.W);
-        const size_t lds = grf_dft_lds_bytes(v.W, e->grf_kc);
-        if (rows <= 10)
-            hipLaunchKernelGGL((k_grf_dft<10>), dim3(n), dim3(kGrfThreads), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+    if (e->grf_dft) {  // even n <= 256: half-spectrum DFT, normalisation fused (k_grf_dft.h)
+        const bool small = v.W <= 100;
+        const int nt = small ? 256 : 1024;
+        const int rows = (v.W + (nt / v.W) - 1) / (nt / v.W);
+        const size_t lds = grf_dft_lds_bytes(v.W, e->grf_kc, small);
+        if (small && rows <= 10)
+            hipLaunchKernelGGL((k_grf_dft<10, 256, true>), dim3(n), dim3(256), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+        else if (small)
+            hipLaunchKernelGGL((k_grf_dft<50, 256, true>), dim3(n), dim3(256), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+        else if (rows <= 44)
+            hipLaunchKernelGGL((k_grf_dft<44, 1024, false>), dim3(n), dim3(1024), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
         else
-            hipLaunchKernelGGL((k_grf_dft<50>), dim3(n), dim3(kGrfThreads), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+            hipLaunchKernelGGL((k_grf_dft<64, 1024, false>), dim3(n), dim3(1024), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -555,7 +561,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         grf_kernel_host(cfg->y_dim, cfg->x_dim, cfg->cluster_radius, h);
         HIP_TRY(hipMemcpy(v.grf_h, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
         const int n = cfg->x_dim;
-        e->grf_dft = (n % 2 == 0) && n >= 4 && n <= 100;  // odd n: the reference's amp is not even (ground_truths.py:8-11)
+        e->grf_dft = (n % 2 == 0) && n >= 4 && n <= 256;  // odd n: the reference's amp is not even (ground_truths.py:8-11)
         if (const char* gc = getenv("IPP_GRF_CONV")) e->grf_dft = e->grf_dft && atoi(gc) == 0;  // A/B experiments
         if (e->grf_dft) {
             std::vector<double> cs, g;
@@ -563,7 +569,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
             HIP_TRY(hipMemcpy(v.grf_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(v.grf_g, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
             const long budget = (n <= 64) ? 32768 : 65536;
-            const long fixed = (long)n * n * 4 + (long)n * 16 + 64;
+            const long fixed = (n <= 100 ? (long)n * n * 4 : 0) + (long)n * 16 + 256;
             e->grf_kc = (int)std::max(1L, std::min((long)(n / 2 + 1), (budget - fixed) / ((long)n * 40)));
         }
     }

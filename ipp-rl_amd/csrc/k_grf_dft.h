@@ -9,8 +9,9 @@
 // 17x fewer at n = 50, 33x at n = 100.  The constant 1/n of the row inverse is dropped: the field is min-max
 // normalised right after.  cs[j] = (cos, sin)(2 pi j / n) and g come from the host in fp64.
 //
-// One 256-thread workgroup per env.  LDS: the white noise (fp32), cs, and one chunk of KC spectrum rows
-// (A, D complex fp64, g real) -- 25 KB at n = 50 -- so several fields run per CU beside the step kernel.
+// One workgroup per env (256 threads up to n = 100, 1024 threads up to n = 256).  LDS: the white noise (fp32; read
+// from global memory instead when it would not fit, n > 100), cs, and one chunk of KC spectrum rows (A, D complex
+// fp64, g real) -- 25 KB at n = 50 -- so several fields run per CU beside the step kernel.
 // Stage 3 keeps the outputs in registers: thread (x, yg) owns rows y = yg, yg + R, ... of column x, so D[k][x] is
 // read once per k and the phase (k y mod n) advances by y per k without a multiply.  The normalisation is fused
 // (workgroup min / max), the field goes straight to the env slot or the caller's buffer.
@@ -19,14 +20,14 @@
 
 namespace ipp {
 
-constexpr int kGrfThreads = 256;
-
-__host__ __device__ inline size_t grf_dft_lds_bytes(int n, int kc) {
-    return (size_t)n * n * 4 + (size_t)n * 16 + (size_t)kc * n * (16 + 16 + 8) + 64;
+__host__ __device__ inline size_t grf_dft_lds_bytes(int n, int kc, bool w_in_lds) {
+    return (w_in_lds ? (size_t)n * n * 4 : 0) + (size_t)n * 16 + (size_t)kc * n * (16 + 16 + 8) + 2 * 16 * 8;
 }
 
-template <int OPT>  // rows of one column a thread owns in stage 3: ceil(n / (256 / n)) <= OPT
-__global__ __launch_bounds__(kGrfThreads) void k_grf_dft(View v, const int* __restrict__ env_ids, int n_items,
+// OPT: rows of one column a thread owns in stage 3, ceil(n / (NT / n)) <= OPT;  NT: workgroup size;
+// WLDS: white noise staged in LDS
+template <int OPT, int NT, bool WLDS>
+__global__ __launch_bounds__(NT) void k_grf_dft(View v, const int* __restrict__ env_ids, int n_items,
                                                          const float* __restrict__ white, const double2* __restrict__ cs,
                                                          const double* __restrict__ g, int kc,
                                                          float* __restrict__ gt_out) {
@@ -40,11 +41,14 @@ __global__ __launch_bounds__(kGrfThreads) void k_grf_dft(View v, const int* __re
     double2* A = cs_s + n;
     double2* D = A + (size_t)kc * n;
     double* gs = reinterpret_cast<double*>(D + (size_t)kc * n);
+    constexpr int kGrfThreads = NT;
     float* ws = reinterpret_cast<float*>(gs + (size_t)kc * n);
-    double* red = reinterpret_cast<double*>(ws + N);  // [8] min / max per wave (N is even)
+    double* red = reinterpret_cast<double*>(ws + (WLDS ? N : 0));  // [2 * waves] min / max per wave (N is even)
     const int tid = threadIdx.x;
     const float* __restrict__ wn = white + (size_t)item * N;
-    for (int i = tid; i < N; i += kGrfThreads) ws[i] = wn[i];
+    if (WLDS)
+        for (int i = tid; i < N; i += kGrfThreads) ws[i] = wn[i];
+    const float* __restrict__ wsrc = WLDS ? ws : wn;
     for (int i = tid; i < n; i += kGrfThreads) cs_s[i] = cs[i];
 
     // stage-3 ownership: column x, rows yg + j R
@@ -52,9 +56,9 @@ __global__ __launch_bounds__(kGrfThreads) void k_grf_dft(View v, const int* __re
     const int x3 = tid % n, yg = tid / n;
     const bool own = tid < R * n;
     double acc[OPT];
-    int ph[OPT];
 #pragma unroll
-    for (int j = 0; j < OPT; ++j) { acc[j] = 0.0; ph[j] = 0; }
+    for (int j = 0; j < OPT; ++j) acc[j] = 0.0;
+    const int stepR = R % n;  // (row y advances by R per j: its phase k y mod n advances by k R mod n)
 
     const int n_k = n / 2 + 1;
     for (int k0 = 0; k0 < n_k; k0 += kc) {
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(kGrfThreads) void k_grf_dft(View v, const int* __re
             double re = 0.0, im = 0.0;
             int p = 0;
             for (int y = 0; y < n; ++y) {
-                const double wv = (double)ws[y * n + x];
+                const double wv = (double)wsrc[y * n + x];
                 const double2 c = cs_s[p];
                 re = fma(wv, c.x, re);
                 im = fma(-wv, c.y, im);
@@ -94,23 +98,22 @@ __global__ __launch_bounds__(kGrfThreads) void k_grf_dft(View v, const int* __re
             D[idx] = make_double2(re, im);
         }
         __syncthreads();
-        // ---- stage 3: f[y][x] += Re(D[k][x] (cos + i sin)(2 pi k y / n)); the phase of row y advances by y per k
+        // ---- stage 3: f[y][x] += Re(D[k][x] (cos + i sin)(2 pi k y / n)).  Row y = yg + j R of this thread has
+        // phase (k yg + j (k R)) mod n: two running values per k instead of a table of OPT phases
         if (own) {
-            if (k0 == 0) {
-#pragma unroll
-                for (int j = 0; j < OPT; ++j) ph[j] = 0;  // k = 0
-            }
             for (int kk = 0; kk < kn; ++kk) {
+                const int k = k0 + kk;
                 const double2 d = D[(size_t)kk * n + x3];
+                int p = (int)(((long)k * yg) % n);
+                const int dp = (int)(((long)k * stepR) % n);
 #pragma unroll
                 for (int j = 0; j < OPT; ++j) {
-                    const int y = yg + j * R;
-                    if (y < n) {
-                        const double2 c = cs_s[ph[j]];
+                    if (yg + j * R < n) {
+                        const double2 c = cs_s[p];
                         acc[j] = fma(d.x, c.x, fma(-d.y, c.y, acc[j]));
-                        ph[j] += y;
-                        ph[j] -= (ph[j] >= n) ? n : 0;
                     }
+                    p += dp;
+                    p -= (p >= n) ? n : 0;
                 }
             }
         }
@@ -128,10 +131,13 @@ __global__ __launch_bounds__(kGrfThreads) void k_grf_dft(View v, const int* __re
         lo = fmin(lo, __shfl_xor(lo, off));
         hi = fmax(hi, __shfl_xor(hi, off));
     }
-    if ((tid & (kWave - 1)) == 0) { red[tid / kWave] = lo; red[4 + tid / kWave] = hi; }
+    constexpr int NW = NT / kWave;
+    if ((tid & (kWave - 1)) == 0) { red[tid / kWave] = lo; red[NW + tid / kWave] = hi; }
     __syncthreads();
-    const double dlo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-    const double span = fmax(fmax(red[4], red[5]), fmax(red[6], red[7])) - dlo;
+    double dlo = red[0], dhi = red[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[NW + w]); }
+    const double span = dhi - dlo;
     if (gt_out) {
         float* gt = gt_out + (size_t)item * N;
         if (own) {
