@@ -65,7 +65,7 @@ struct Engine {
     int q_chunk;
     bool scoring = false;  // arena holds the ipp_score_actions scratch
     ScoreView sv = {};
-    bool grf_dft = false;  // even square grids up to 100: k_grf_dft instead of k_grf_conv + k_grf_norm
+    bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
     int lut_rows = 0;  // workgroup-per-item factor kernels: rows |drow| of the prior table kept in LDS
