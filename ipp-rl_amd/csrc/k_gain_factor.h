@@ -43,15 +43,19 @@ struct GainLds {
     static constexpr int QS = (MC + 3) & ~3;
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
-    int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all;
-    __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves) {
+    int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
+    __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
+                                            int mask_bytes = 0) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
-        b += (size_t)((rank_cap + 3) & ~3) * 4 + (size_t)8 * MC * 4 + (size_t)waves * kWave * 8 * 4 + (size_t)waves * (rank_cap + 8) * 2;
+        b += (size_t)((rank_cap + 3) & ~3) * 4 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
+        b = ((b + 15) & ~(size_t)15) + (size_t)mask_bytes;
         return (b + 15) & ~(size_t)15;
     }
     // work: HT staging rows of the fused prologue (0 floats for the stand-alone kernel); lut: prior table;
     // small: the fused prologue's fp64 scratch (0 floats for the stand-alone kernel)
-    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats, int waves) {
+    // mask_bytes > 0 (fused kernel): no mean / diag staging area, the env's mask bytes instead
+    __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
+                                       int mask_bytes = 0) {
         Ls = reinterpret_cast<float*>(base);
         ys = Ls + MC * MC;
         work = Ls + LQ;
@@ -67,7 +71,9 @@ struct GainLds {
         // [waves][2][64 lanes][4]: mean / diag of the wave's current tile, parked here across the stream loop
         // (typed pointer arithmetic only: an integer round trip would turn the LDS pointer into a flat one)
         stage = fb_w + 4 * MC;
-        ridx_all = reinterpret_cast<unsigned short*>(stage + (size_t)waves * kWave * 8);
+        ridx_all = reinterpret_cast<unsigned short*>(stage + (mask_bytes ? 0 : (size_t)waves * kWave * 8));
+        // adaptive-mask bits of the whole env, one byte per VEC cells (fused kernel), behind the per-wave index lists
+        mask4 = reinterpret_cast<unsigned char*>(ridx_all + (((size_t)waves * (rank_cap + 8) + 7) & ~(size_t)7));
     }
 };
 
@@ -96,7 +102,10 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // the accumulators hold Wc L = P[:,F] H_F^T per cell, and the tile epilogue applies L^-1 (upper triangular, 45 FMAs
 // per cell) once lds.solve_flag says wave 0 has finished the m x m algebra.  The stream therefore starts right
 // after the gather instead of after S / Cholesky / L^-1 / Q.
-template <int MC, int VEC, int KP, bool PRE>
+// LMASK (fused kernel): the adaptive mask of the whole env was put into lds.mask4 by phase A and mean / diag are
+// updated with no-return float atomics (one add per cell, bit-identical to load + add + store): the tile loop has no
+// mean / diag loads, whose latency sat in front of every tile's stream.
+template <int MC, int VEC, int KP, bool PRE, bool LMASK>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out) {
@@ -134,8 +143,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         // read back in the epilogue.  Kept in registers across the stream loop they were spilled to scratch, which
         // cost 10 % of the kernel (A/B with the loads ablated).
         float md_in[2][VEC];
-        load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, md_in[0]);
-        load_vec<VEC>(v.diag + (size_t)h.env * npad + cell0, md_in[1]);
+        if (!LMASK) {
+            load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, md_in[0]);
+            load_vec<VEC>(v.diag + (size_t)h.env * npad + cell0, md_in[1]);
+        }
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
         int nact = 0;
@@ -213,7 +224,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
         }
 
-        {
+        if (!LMASK) {
             float* st = stage_w + lane * VEC;
 #pragma unroll
             for (int c = 0; c < VEC; ++c) { st[c] = md_in[0][c]; st[kWave * VEC + c] = md_in[1][c]; }
@@ -284,7 +295,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         }
         const bool commit = h.commit && !dead;
         float mean_in[VEC], diag_in[VEC];
-        {
+        unsigned mbits = 0xffu;
+        if (LMASK) {
+            mbits = lds.mask4[tile * kWave + lane];
+        } else {
             const float* st = stage_w + lane * VEC;
 #pragma unroll
             for (int c = 0; c < VEC; ++c) { mean_in[c] = st[c]; diag_in[c] = st[kWave * VEC + c]; }
@@ -309,21 +323,35 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             dred[c] = w2;
             dmean[c] = dm;
             // rewards.py:11 mask from the pre-step mean and pre-step diag(P); rewards.py:23-30 trace reduction
-            const bool in_mask = !adaptive || ((double)mean_in[c] + v.kf * (double)diag_in[c] >= v.thr);
+            const bool in_mask = LMASK ? ((mbits >> c) & 1u) != 0u
+                                       : (!adaptive || ((double)mean_in[c] + v.kf * (double)diag_in[c] >= v.thr));
             if (valid && in_mask) part += (double)w2;
         }
         wave_part += wave_sum(part);
         const int valid_cells = max(0, min(kWaveTile, v.N - tile * kWaveTile));
-        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * valid_cells;
+        // LMASK: phase A read mean / diag of this tile for the mask (2), the atomics read and write them again (4)
+        units += (unsigned long long)(nact + (commit ? m + (LMASK ? 6 : 4) : 2)) * valid_cells;
         if (commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
+            if (LMASK) {
+                // in place (dst == env): diag -= |Wc_i|^2, mean += Wc_i y as read-modify-writes at L2
+                float* dg = v.diag + (size_t)h.dst * npad + cell0;
+                float* mu = v.mean + (size_t)h.dst * npad + cell0;
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
-            store_vec<VEC>(v.diag + (size_t)h.dst * npad + cell0, outv);
-            if (!(flags & IPP_COV_ONLY)) {
+                for (int c = 0; c < VEC; ++c)
+                    if (cell0 + c < v.N) {
+                        unsafeAtomicAdd(dg + c, -dred[c]);
+                        if (!(flags & IPP_COV_ONLY)) unsafeAtomicAdd(mu + c, dmean[c]);
+                    }
+            } else {
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) outv[c] = mean_in[c] + dmean[c];
-                store_vec<VEC>(v.mean + (size_t)h.dst * npad + cell0, outv);
+                for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
+                store_vec<VEC>(v.diag + (size_t)h.dst * npad + cell0, outv);
+                if (!(flags & IPP_COV_ONLY)) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) outv[c] = mean_in[c] + dmean[c];
+                    store_vec<VEC>(v.mean + (size_t)h.dst * npad + cell0, outv);
+                }
             }
 #pragma unroll
             for (int j = 0; j < MC; ++j)
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
         }
     }
     __syncthreads();
-    gain_tiles<MC, VEC, IPP_GF_PIPE, false>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_GF_PIPE, false, false>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
 }
 
 }  // namespace ipp

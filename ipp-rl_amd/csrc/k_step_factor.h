@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
     const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave);
+                          kStepThreads / kWave, v.Npad / VEC);
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int tid = threadIdx.x;
@@ -54,6 +54,35 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     auto mid = [&](const ItemHdr& hh) {
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
+        // adaptive mask of the whole env (rewards.py:11: pre-step mean and pre-step diag), one byte per VEC cells: the
+        // tile loop then needs neither mean nor diag (their updates are no-return atomics)
+        typedef float cellv __attribute__((ext_vector_type(VEC)));
+        const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
+        const cellv* diag_v = reinterpret_cast<const cellv*>(v.diag + (size_t)hh.env * v.Npad);
+        const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
+        constexpr int kMaskPerThread = 4;  // groups in flight per thread and pass
+        // only the tiles this step touches: [t_lo, t_hi] (the span of the appended columns)
+        const int q_lo = hh.t_lo * kWave, q_hi = (hh.t_hi + 1) * kWave;  // groups of VEC cells
+        for (int q0 = q_lo + tid; q0 < q_hi; q0 += kMaskPerThread * kStepThreads) {
+            cellv mu[kMaskPerThread], dg[kMaskPerThread];
+#pragma unroll
+            for (int u = 0; u < kMaskPerThread; ++u) {
+                const int q = q0 + u * kStepThreads;
+                if (adaptive && q < q_hi) { mu[u] = mean_v[q]; dg[u] = diag_v[q]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kMaskPerThread; ++u) {
+                const int q = q0 + u * kStepThreads;
+                if (q >= q_hi) continue;
+                unsigned bits = 0;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    const bool in = !adaptive || ((double)mu[u][c] + v.kf * (double)dg[u][c] >= v.thr);
+                    bits |= (in ? 1u : 0u) << c;
+                }
+                lds.mask4[q] = (unsigned char)bits;
+            }
+        }
         const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
         for (int i = tid; i < lut_rows * v.W; i += kStepThreads) {
             const int dr = i / v.W, dc = i - dr * v.W;
@@ -87,7 +116,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true>(v, h, item, flags, lut_rows, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true>(v, h, item, flags, lut_rows, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
 }
 
 }  // namespace ipp
