@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 3
+#define IPP_ABI_VERSION 4
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -82,6 +82,8 @@ typedef struct ipp_config {
                                  from the prior (12 = 13 length scales for the example config), 0 when in doubt */
     int32_t score_scratch;    /* 1 = reserve the scratch of ipp_score_actions in the arena: band of G = P M P
                                  (N x 190 doubles) and, for IPP_FACTOR, one dense P (N x Npad floats) */
+    int32_t node_capacity;    /* tree nodes of ipp_tree_step (each (max_measurements + 1) x Npad floats); 0 = none */
+    int32_t reserved0;
 } ipp_config;
 
 typedef struct ipp_info {
@@ -168,6 +170,27 @@ int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const dou
  */
 int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32_t n, const double* prev_action,
                       uint32_t flags, float* reward, int32_t* status, void* stream);
+
+#define IPP_TREE_DEPTH 6 /* nodes on a path of ipp_tree_step */
+
+/*
+ * Tree-search step on path-local factor columns: item i starts from the state of env slot root_ids[i] followed
+ * by the covariance-only steps recorded in the nodes path_ids[i][0..5] (root side first, -1 = unused), takes
+ * the covariance-only predict step for action[i] and returns its reward -- simulate_prediction_step at a tree node
+ * (planning/mcts_zero/mcts.py:166-265, planning/mcts_mission.py:167-246).  With new_ids[i] >= 0 the step is also
+ * recorded as node new_ids[i] (a child of the last path node): the node keeps only the <= max_measurements columns
+ * the step appended and the state's diagonal -- the reference stores a whole N x N covariance per node
+ * (mcts.py:16-21).  The root env slot is never written; the map mean (adaptive mask) is the root's.
+ * Needs IPP_FACTOR with window_rows > 0, default tile_threads, node_capacity > 0; root rank + path columns +
+ * new columns <= rank_cap (else IPP_STATUS_RANK_FULL: reward valid, no node written).
+ *   root_ids [dev] int32[n]; path_ids [dev] int32[n][IPP_TREE_DEPTH]; new_ids [dev] int32[n] or NULL
+ *   flags    IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_PREDICT_ONLY (ignore new_ids)
+ */
+int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
+                  const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
+                  void* stream);
+/* diag of a node's state, float[N] */
+int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream);
 
 /*
  * NN input state plane of one env slot: the N x N covariance with the rows / columns outside the adaptive mask

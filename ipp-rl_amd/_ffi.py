@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class IppConfig(C.Structure):
@@ -29,7 +29,7 @@ class IppConfig(C.Structure):
         ("value_threshold", C.c_double), ("interval_factor", C.c_double),
         ("cluster_radius", C.c_double),
         ("state_repr", C.c_int32), ("capacity", C.c_int32), ("rank_cap", C.c_int32), ("max_batch", C.c_int32),
-        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("score_scratch", C.c_int32),
+        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("score_scratch", C.c_int32), ("node_capacity", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -67,6 +67,8 @@ PROTOTYPES = {
     "ipp_reset_episode": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "ipp_score_actions": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
     "ipp_state_plane": (C.c_int, [_P, C.c_int32, _P, C.c_uint32, _P, _P]),
+    "ipp_tree_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P]),
+    "ipp_tree_read_diag": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),

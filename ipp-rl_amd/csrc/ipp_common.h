@@ -60,6 +60,35 @@ __device__ __forceinline__ ItemHdr uniform_hdr(const ItemHdr& h) {
     return o;
 }
 
+// Where the columns of an item's factor state live when it is a TREE state (ipp_tree_step): the root env's slab
+// followed by the column blocks of the nodes on the path from the root (each node holds the <= MC columns its own
+// step appended, at stride Npad, plus their tile span).  Plain env steps read one slab and do not use this.
+constexpr int kTreeDepth = 6;  // nodes on a path (episode_horizon of the tree searches is <= 5)
+struct ChainCols {
+    const float* root;        // root slab: columns 0 .. r_root-1
+    const int* root_spans;    // tile spans of the root's columns
+    int r_root, depth;
+    const float* node[kTreeDepth];  // column block of path node j
+    int off[kTreeDepth];            // index of its first column in the chained state
+    int nspan[kTreeDepth];          // its tile span (lo | hi << 16)
+    size_t npad;
+    __device__ __forceinline__ const float* row(int k) const {
+        const float* b = root;
+        int kk = k;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < depth && k >= off[j]) { b = node[j]; kk = k - off[j]; }
+        return b + (size_t)kk * npad;
+    }
+    __device__ __forceinline__ int span(int k) const {
+        int s = (r_root > 0) ? root_spans[min(k, r_root - 1)] : 0;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < depth && k >= off[j]) s = nspan[j];
+        return s;
+    }
+};
+
 // Everything the kernels need, passed by value.
 struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL

@@ -21,6 +21,7 @@
 #include "k_grf_dft.h"
 #include "k_score.h"
 #include "k_plane.h"
+#include "k_tree.h"
 #include "k_prepare.h"
 
 using namespace ipp;
@@ -63,6 +64,7 @@ struct Engine {
     size_t prep_lds;
     size_t gain_lds;
     int q_chunk;
+    TreeView tv = {};      // node pool of ipp_tree_step (node_cap == 0: none)
     bool scoring = false;  // arena holds the ipp_score_actions scratch
     ScoreView sv = {};
     bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
@@ -82,7 +84,7 @@ struct Engine {
 struct Layout {
     int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
-        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, total, cov_slot_floats;
+        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, total, cov_slot_floats;
 };
 
 uint64_t q_item_floats(const Layout& L) {
@@ -172,6 +174,14 @@ int plan(const ipp_config& c, Layout& L) {
         L.off_sc_mask = o; o += up(np * 4);
         L.off_sc_G = o; o += up((uint64_t)kScoreSplit * L.N * kScoreBandCap * 8);
         L.off_sc_P = o; o += (c.state_repr == IPP_FACTOR) ? up((uint64_t)L.N * np * 4) : 0;
+    }
+    L.off_tr_cov = L.off_tr_diag = L.off_tr_meta = o;
+    if (c.node_capacity > 0) {  // ipp_tree_step (k_tree.h)
+        if (c.state_repr != IPP_FACTOR) return fail(-1, "node_capacity needs IPP_FACTOR");
+        const uint64_t nc = c.node_capacity;
+        L.off_tr_cov = o; o += up(nc * L.MC * np * 4);
+        L.off_tr_diag = o; o += up(nc * np * 4);
+        L.off_tr_meta = o; o += up(nc * 2 * 4);
     }
     L.total = o;
     return 0;
@@ -488,6 +498,12 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.grf_g = reinterpret_cast<double*>(base + L.off_grfg);
     v.grf_raw = reinterpret_cast<float*>(base + L.off_grfraw);
     v.grf_raw2 = reinterpret_cast<float*>(base + L.off_grfraw2);
+    e->tv.node_cap = std::max(0, cfg->node_capacity);
+    if (e->tv.node_cap > 0) {
+        e->tv.node_cov = reinterpret_cast<float*>(base + L.off_tr_cov);
+        e->tv.node_diag = reinterpret_cast<float*>(base + L.off_tr_diag);
+        e->tv.node_meta = reinterpret_cast<int*>(base + L.off_tr_meta);
+    }
     e->scoring = cfg->score_scratch != 0;
     if (e->scoring) {
         e->sv.hdr = reinterpret_cast<ScoreHdr*>(base + L.off_sc_hdr);
@@ -548,6 +564,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -755,6 +773,40 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
     if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_eval<9>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     else                 hipLaunchKernelGGL((k_score_eval<25>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
+                  const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
+                  void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !root_ids || !path_ids || !action || !prev_action || !reward) return fail(-1, "null argument");
+    if (e->tv.node_cap <= 0) return fail(-1, "ipp_tree_step needs ipp_config.node_capacity > 0");
+    if (!e->fused) return fail(-1, "ipp_tree_step needs IPP_FACTOR with window_rows > 0 and the default tile_threads");
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME)) return fail(-1, "unsupported flag bits 0x%x", flags);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    e->last_n = n;
+    const View& v = e->v;
+    if (v.meas_cap == 9)
+        hipLaunchKernelGGL((k_tree_step<9, 4>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, v.q, root_ids, path_ids, new_ids, n,
+                           action, prev_action, flags, e->lut_rows, status, reward);
+    else
+        hipLaunchKernelGGL((k_tree_step<25, 2>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, v.q, root_ids, path_ids, new_ids, n,
+                           action, prev_action, flags, e->lut_rows, status, reward);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (node_id < 0 || node_id >= e->tv.node_cap) return fail(-1, "node_id %d outside [0, %d)", node_id, e->tv.node_cap);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(out, e->tv.node_diag + (size_t)node_id * e->v.Npad, (size_t)e->v.N * 4, hipMemcpyDeviceToDevice,
+                           reinterpret_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -105,10 +105,14 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // LMASK (fused kernel): the adaptive mask of the whole env was put into lds.mask4 by phase A and mean / diag are
 // updated with no-return float atomics (one add per cell, bit-identical to load + add + store): the tile loop has no
 // mean / diag loads, whose latency sat in front of every tile's stream.
-template <int MC, int VEC, int KP, bool PRE, bool LMASK>
+// CHAIN (ipp_tree_step): the streamed columns come from a chained tree state (cc), the m new columns go to the new
+// node's block, diag_rw is the new node's diagonal (initialised as a copy of its parent's), and instead of the env's
+// rank / spans the node's (m, span) record is written; nothing of the root env slot is modified.
+template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
-                                           float* __restrict__ reward_out) {
+                                           float* __restrict__ reward_out, const ChainCols* cc = nullptr,
+                                           float* new_cols = nullptr, float* diag_rw = nullptr, int* node_meta = nullptr) {
     constexpr int kWaveTile = VEC * kWave;  // cells per wave tile
     constexpr int QS = (MC + 3) & ~3;
     const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut; double* red = lds.red;
@@ -247,7 +251,8 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     kk[i] = col_of(a + i);
                     // padding entries (kk == r, zero Q row) read a column that IS stored on this tile: a column that is
                     // not stored here holds uninitialised memory, and NaN * 0 would poison the accumulators
-                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)(kk[i] < r ? kk[i] : safe_k) * npad + cell0));
+                    const int ku = kk[i] < r ? kk[i] : safe_k;
+                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>((CHAIN ? cc->row(ku) : cov_src + (size_t)ku * npad) + cell0));
                 }
                 __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
 #pragma unroll
@@ -335,7 +340,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             float outv[VEC];
             if (LMASK) {
                 // in place (dst == env): diag -= |Wc_i|^2, mean += Wc_i y as read-modify-writes at L2
-                float* dg = v.diag + (size_t)h.dst * npad + cell0;
+                float* dg = (CHAIN ? diag_rw : v.diag + (size_t)h.dst * npad) + cell0;
                 float* mu = v.mean + (size_t)h.dst * npad + cell0;
 #pragma unroll
                 for (int c = 0; c < VEC; ++c)
@@ -358,7 +363,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 if (j < m) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
-                    store_stream<VEC>(cov_dst + (size_t)(r + j) * npad + cell0, outv);
+                    store_stream<VEC>((CHAIN ? new_cols + (size_t)j * npad : cov_dst + (size_t)(r + j) * npad) + cell0, outv);
                 }
         }
         __builtin_amdgcn_wave_barrier();
@@ -387,9 +392,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         double tot = 0.0;
         for (int w = 0; w < nw; ++w) tot += red[w];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
-        if (commit_item) v.rank[h.dst] = r + m;
+        if (commit_item && !CHAIN) v.rank[h.dst] = r + m;
+        if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); }
     }
-    if (commit_item && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+    if (commit_item && !CHAIN && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
 }
 
 // Stand-alone gain kernel (after k_prepare): stages L^-1 | y, the spans and the prior table, then gain_tiles.

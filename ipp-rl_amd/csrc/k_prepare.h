@@ -80,7 +80,9 @@ struct NoMidWork { __device__ __forceinline__ void operator()(const ItemHdr&) co
 //   FRONT_ONLY   stop after the gather (HT / P_FF staged in `big`, z and the innovation in the scratch): the fused
 //                kernel lets one wave finish the m x m algebra (solve_wave) while the others already stream
 //   mid_work     called once between issuing the footprint-dependent loads and consuming them (free compute slot)
-template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid>
+//   CHAIN / cc   factor columns come from a chained tree state (ChainCols) instead of the env's own slab; rank_chain
+//                is then the state's column count
+template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid, bool CHAIN = false>
 __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int item, const int* __restrict__ env_ids,
                                                     const int* __restrict__ dst_ids, const double* __restrict__ action,
                                                     const double* __restrict__ prev_action,
@@ -89,7 +91,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                                                     int* __restrict__ obs_m, int* __restrict__ obs_shape,
                                                     unsigned char* small, float* big, int si, int sk, float* q_out,
                                                     float* linv_f, float* linv_f2, float* y_f, float* y_f2, int* span_s,
-                                                    Mid mid_work) {
+                                                    Mid mid_work, const ChainCols* cc = nullptr, int rank_chain = 0) {
     constexpr int kPrepThreads = NT;
     constexpr int FC = 4 * MC;
     constexpr int LD = MC + 1;
@@ -116,7 +118,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     const int envc = slots_ok ? env0 : 0;  // speculative loads stay in bounds
     const double ax = action[3 * item + 0], ay = action[3 * item + 1], az = action[3 * item + 2];
     const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
-    const int rank_ld = (MODE == IPP_FACTOR) ? v.rank[envc] : 0;
+    const int rank_ld = CHAIN ? rank_chain : ((MODE == IPP_FACTOR) ? v.rank[envc] : 0);
     const double sv = v.prior[2 * envc + 0], ls = v.prior[2 * envc + 1];
     const float eps_ld = (meas_noise && tid < MC) ? meas_noise[(size_t)item * MC + tid] : 0.f;
     const int* __restrict__ span = v.colspan + (size_t)envc * v.rank_cap;
@@ -124,7 +126,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int k = tid / MP + u * KS;
-        sp_pre[u] = (MODE == IPP_FACTOR && k < v.rank_cap) ? span[k] : 0;
+        sp_pre[u] = CHAIN ? cc->span(min(k, max(rank_chain - 1, 0))) : ((MODE == IPP_FACTOR && k < v.rank_cap) ? span[k] : 0);
     }
 
     // ------------------------------------------------------------------ header (every thread, fp64 like NumPy)
@@ -257,7 +259,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = min(k0 + u * KS, r - 1);
-            const float* row = cov_env + (size_t)k * v.Npad;
+            const float* row = CHAIN ? cc->row(k) : cov_env + (size_t)k * v.Npad;
             const int lo = sp[u] & 0xffff, hi = sp[u] >> 16;
             float t = (gtile[0] >= lo && gtile[0] <= hi) ? row[gc[0]] : 0.f;
             if (gcnt > 1) t += (gtile[1] >= lo && gtile[1] <= hi) ? row[gc[1]] : 0.f;
@@ -355,7 +357,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         ht_ld = (r + 3) & ~3;
         const int SI = (si > 0) ? si : ht_ld, SK = (si > 0) ? sk : 1;
         if (span_s)
-            for (int k = tid; k < r; k += kPrepThreads) span_s[k] = span[k];
+            for (int k = tid; k < r; k += kPrepThreads) span_s[k] = CHAIN ? cc->span(k) : span[k];
         if (gather_on) {
             const int k00 = tid / MP;
 #pragma unroll
@@ -364,7 +366,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
             for (int k0 = k00 + UN * KS; k0 < r; k0 += UN * KS) {  // further passes (rank > UN * KS)
                 int sp[UN];
 #pragma unroll
-                for (int u = 0; u < UN; ++u) sp[u] = span[min(k0 + u * KS, r - 1)];
+                for (int u = 0; u < UN; ++u) sp[u] = CHAIN ? cc->span(min(k0 + u * KS, r - 1)) : span[min(k0 + u * KS, r - 1)];
                 float sacc[UN];
                 gather_rows(k0, sp, sacc);
 #pragma unroll

@@ -71,7 +71,7 @@ class IPPEngine:
 
     def __init__(self, cfg: EngineConfig, capacity: int, state: str = "factor", rank_cap: int = 360,
                  max_batch: Optional[int] = None, device: str = "cuda:0", max_measurements: int = 9,
-                 tile_threads: int = 0, window_rows: int = 0, score_scratch: bool = False):
+                 tile_threads: int = 0, window_rows: int = 0, score_scratch: bool = False, node_capacity: int = 0):
         torch = _torch()
         self._lib = _ffi.load()
         if not torch.cuda.is_available():
@@ -99,6 +99,7 @@ class IPPEngine:
         c.max_measurements, c.tile_threads = int(max_measurements), int(tile_threads)
         c.window_rows = int(window_rows)
         c.score_scratch = 1 if score_scratch else 0
+        c.node_capacity = int(node_capacity)
         self._c = c
         nbytes = C.c_uint64(0)
         _ffi.check(self._lib.ipp_engine_arena_bytes(C.byref(c), C.byref(nbytes)))
@@ -186,6 +187,34 @@ class IPPEngine:
                                                self._ptr(status), self.stream))
         self._keep_score = a
         return reward, status
+
+    TREE_DEPTH = 6
+
+    def tree_step(self, root_ids, path_ids, actions, prev_actions, new_ids=None, *, adaptive=True, use_flight_time=True,
+                  reward_out=None, status_out=None):
+        """Covariance-only predict steps at tree nodes (ipp_tree_step): item i starts from env slot root_ids[i] plus
+        the nodes path_ids[i] (root side first, -1 padded to TREE_DEPTH); new_ids[i] >= 0 records the step as that node."""
+        torch = _torch()
+        roots = self._dev(root_ids, torch.int32)
+        n = int(roots.numel())
+        paths = self._dev(path_ids, torch.int32).reshape(n, self.TREE_DEPTH)
+        new = self._dev(new_ids, torch.int32)
+        a = self._dev(actions, torch.float64).reshape(n, 3)
+        p = self._dev(prev_actions, torch.float64).reshape(n, 3)
+        reward = reward_out if reward_out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        status = status_out if status_out is not None else torch.empty(n, dtype=torch.int32, device=self.device)
+        flags = (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0) | \
+                (_ffi.IPP_PREDICT_ONLY if new is None else 0)
+        _ffi.check(self._lib.ipp_tree_step(self._h, self._ptr(roots), self._ptr(paths), self._ptr(new), n, self._ptr(a),
+                                           self._ptr(p), flags, self._ptr(reward), self._ptr(status), self.stream))
+        self._keep = (roots, paths, new, a, p)
+        return reward, status
+
+    def tree_diag(self, node: int):
+        torch = _torch()
+        out = torch.empty(self.n_cells, dtype=torch.float32, device=self.device)
+        _ffi.check(self._lib.ipp_tree_read_diag(self._h, int(node), self._ptr(out), self.stream))
+        return out
 
     def state_plane(self, env: int, mean_for_mask=None, adaptive: bool = True, out=None):
         """Masked, min-max normalised N x N covariance plane of slot `env` (features.py:91-101), device fp32 [N, N].

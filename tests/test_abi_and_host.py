@@ -48,7 +48,7 @@ def test_struct_layouts_match_header_order():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"(?:int32_t|double)\s+([a-z_0-9]+);", body)
     assert fields == [f[0] for f in _ffi.IppConfig._fields_]
-    assert ctypes.sizeof(_ffi.IppConfig) == 8 + 13 * 8 + 8 * 4
+    assert ctypes.sizeof(_ffi.IppConfig) == 8 + 13 * 8 + 10 * 4
 
 
 def test_arena_sizing_and_validation_without_gpu():

@@ -1,0 +1,104 @@
+"""
+GPU tests of ipp_tree_step (csrc/k_tree.h): covariance-only predict steps at tree nodes whose
+states are the root env's factor columns plus path-local column blocks.  Oracle: the dense restatement of
+simulate_prediction_step chained along every path (planning/common/optimization.py:14-30; the tree searches keep
+`next_state` as the child's state, planning/mcts_zero/mcts.py:166-265).
+"""
+import numpy as np
+import pytest
+
+from oracle import ipp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+UAV = {"max_v": 2.0, "max_a": 2.0}
+D = 6
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def pad(path):
+    return list(path) + [-1] * (D - len(path))
+
+
+@pytest.mark.parametrize("dim,window_rows", [(20, 12), (50, 12), (20, 1000)])
+def test_tree_steps_vs_chained_oracle_predictions(dim, window_rows):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim, resolution=cfg.resolution, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b)
+    eng = IPPEngine(cfg, capacity=3, state="factor", rank_cap=128, window_rows=window_rows, node_capacity=32, max_batch=16)
+    rs = np.random.RandomState(dim)
+    white = rs.normal(size=(dim, dim))
+    eng.reset(env_ids=[2], white_noise=white[None])
+    st = orc.env_reset(ocfg, white)
+    prev = np.array([2.0, 2.0, 14.0])
+    centre = np.array([dim // 2, dim // 2])
+
+    def random_action():
+        c = np.clip(centre + rs.randint(-3, 4, size=2), 0, dim - 1)
+        return np.array([4.0 * c[0] + 2.0, 4.0 * c[1] + 2.0, float(rs.choice([6.0, 8.0, 12.0, 14.0]))])
+
+    for _ in range(4):  # the root: a few executed steps (mean moves, so the adaptive mask is not trivial)
+        a = random_action()
+        eps = rs.normal(size=9)
+        eng.step(a[None], prev[None], env_ids=[2], meas_noise=eps[None])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
+        orc.env_step(ocfg, st, a, eps[:m])
+        prev = a
+    root_rank, root_diag, root_cov = eng.rank(2), host(eng.read_diag(2)), host(eng.read_cov(2))
+    info = {"mean": st.mean, "value_threshold": 0.4, "interval_factor": 0.0}
+
+    # tree: node id -> (parent id or None, action); states of the oracle per node
+    P_of = {None: st.P}
+    prev_of = {None: prev}
+    path_of = {None: []}
+    plan = [(0, None), (1, None), (2, 0), (3, 0), (4, 2), (5, 4), (6, 1), (7, 5), (8, 7)]  # node 8 sits at depth 6
+    depth_of = {None: 0}
+    for nid, par in plan:
+        depth_of[nid] = depth_of[par] + 1
+    for level in range(1, 7):  # nodes of one depth are expanded in ONE call (they only depend on shallower nodes)
+        batch = [(nid, par) for nid, par in plan if depth_of[nid] == level]
+        if not batch:
+            continue
+        acts = np.array([random_action() for _ in batch])
+        prevs = np.array([prev_of[par] for _, par in batch])
+        reward, status = eng.tree_step([2] * len(batch), [pad(path_of[par]) for _, par in batch], acts, prevs,
+                                       new_ids=[nid for nid, _ in batch])
+        assert int(status.abs().sum()) == 0
+        for k, (nid, par) in enumerate(batch):
+            want, P_new, _, _ = orc.predict_step(ocfg, P_of[par], prevs[k], acts[k], UAV, info)
+            assert abs(float(reward[k]) - want) < TOL, (level, nid, float(reward[k]), want)
+            P_of[nid], prev_of[nid], path_of[nid] = P_new, acts[k], path_of[par] + [nid]
+    for nid in (0, 3, 5, 8):
+        assert np.max(np.abs(host(eng.tree_diag(nid)) - np.diag(P_of[nid]))) < TOL
+
+    # predict-only queries at several nodes in one call, nothing recorded
+    nodes = [None, 1, 3, 5, 7]
+    acts = np.array([random_action() for _ in nodes])
+    prevs = np.array([prev_of[nid] for nid in nodes])
+    reward, status = eng.tree_step([2] * len(nodes), [pad(path_of[nid]) for nid in nodes], acts, prevs)
+    for k, nid in enumerate(nodes):
+        want = orc.predict_step(ocfg, P_of[nid], prevs[k], acts[k], UAV, info)[0]
+        assert abs(float(reward[k]) - want) < TOL
+    # the root env slot is untouched
+    assert eng.rank(2) == root_rank and np.array_equal(host(eng.read_diag(2)), root_diag)
+    assert np.array_equal(host(eng.read_cov(2)), root_cov)
+    assert np.max(np.abs(host(eng.tree_diag(8)) - np.diag(P_of[8]))) < TOL  # and so are the recorded nodes
+
+
+def test_tree_step_needs_nodes_and_fused_configuration():
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd._ffi import IppError
+
+    cfg = EngineConfig(x_dim=20, y_dim=20)
+    plain = IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, window_rows=12)
+    plain.reset()
+    with pytest.raises(IppError, match="node_capacity"):
+        plain.tree_step([0], [pad([])], np.array([[10.0, 10.0, 8.0]]), np.array([[2.0, 2.0, 14.0]]))
+    exact = IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, window_rows=0, node_capacity=4)
+    exact.reset()
+    with pytest.raises(IppError, match="window_rows"):
+        exact.tree_step([0], [pad([])], np.array([[10.0, 10.0, 8.0]]), np.array([[2.0, 2.0, 14.0]]))
