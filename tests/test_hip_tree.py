@@ -102,3 +102,26 @@ def test_tree_step_needs_nodes_and_fused_configuration():
     exact.reset()
     with pytest.raises(IppError, match="window_rows"):
         exact.tree_step([0], [pad([])], np.array([[10.0, 10.0, 8.0]]), np.array([[2.0, 2.0, 14.0]]))
+
+
+def test_tree_steps_resolution_one_m25():
+    """1 m cells (length scale scaled accordingly): the MC = 25 / VEC = 2 instantiation of the tree kernel."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    dim = 24
+    cfg = EngineConfig(x_dim=dim, y_dim=dim, resolution=1.0, length_scale=0.9175)
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim, resolution=1.0, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b, length_scale=0.9175)
+    eng = IPPEngine(cfg, capacity=2, state="factor", rank_cap=160, max_measurements=25, window_rows=12, node_capacity=8, max_batch=4)
+    eng.reset()
+    P = orc.matern_prior(ocfg)
+    mean = 0.5 * np.ones((dim, dim))
+    info = {"mean": mean, "value_threshold": 0.4, "interval_factor": 0.0}
+    rs = np.random.RandomState(1)
+    prev, path = np.array([0.5, 0.5, 5.0]), []
+    for nid in range(4):
+        a = np.array([rs.randint(8, 16) + 0.5, rs.randint(8, 16) + 0.5, [5.0, 3.0, 4.0, 2.0][nid]])
+        reward, status = eng.tree_step([0], [pad(path)], a[None], prev[None], new_ids=[nid])
+        want, P, _, _ = orc.predict_step(ocfg, P, prev, a, UAV, info)
+        assert int(status[0]) == 0 and abs(float(reward[0]) - want) < TOL, (nid, float(reward[0]), want)
+        prev, path = a, path + [nid]
+    assert np.max(np.abs(host(eng.tree_diag(3)) - np.diag(P))) < TOL
