@@ -125,3 +125,27 @@ def test_tree_steps_resolution_one_m25():
         assert int(status[0]) == 0 and abs(float(reward[0]) - want) < TOL, (nid, float(reward[0]), want)
         prev, path = a, path + [nid]
     assert np.max(np.abs(host(eng.tree_diag(3)) - np.diag(P))) < TOL
+
+
+def test_tree_node_pool_bookkeeping():
+    """TreeNodePool: ids, parents, padded paths; predict from a node equals the expansion that follows it."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.tree import TreeNodePool
+
+    cfg = EngineConfig(x_dim=20, y_dim=20)
+    eng = IPPEngine(cfg, capacity=2, state="factor", rank_cap=96, window_rows=12, node_capacity=16, max_batch=8)
+    eng.reset()
+    pool = TreeNodePool(eng, 16)
+    start = np.array([2.0, 2.0, 14.0])
+    a0 = np.array([[38.0, 42.0, 8.0], [10.0, 14.0, 14.0]])
+    _, _, kids = pool.expand([0, 0], [None, None], a0, np.tile(start, (2, 1)))
+    assert list(kids) == [0, 1] and pool.path(1) == [1, -1, -1, -1, -1, -1]
+    a1 = np.array([[42.0, 42.0, 12.0]])
+    r_pred, _ = pool.predict([0], [0], a1, a0[:1])
+    r_exp, _, grandkid = pool.expand([0], [0], a1, a0[:1])
+    assert abs(float(r_pred[0]) - float(r_exp[0])) < 1e-7 and pool.path(int(grandkid[0])) == [0, 2, -1, -1, -1, -1]
+    assert int(pool.depth[2]) == 2 and int(pool.parent[2]) == 0 and len(pool) == 3
+    # the same action from the sibling's state gives a different reward (different state), from the root yet another
+    r_sib, _ = pool.predict([0], [1], a1, a0[1:])
+    r_root, _ = pool.predict([0], [None], a1, start[None])
+    assert abs(float(r_sib[0]) - float(r_exp[0])) > 1e-4 and abs(float(r_root[0]) - float(r_exp[0])) > 1e-4
