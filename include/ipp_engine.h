@@ -189,6 +189,12 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
 int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
                   const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
                   void* stream);
+/*
+ * ipp_score_actions from the state of a tree node: root env slot + path (host int32[IPP_TREE_DEPTH], -1 padded) --
+ * the rollout policy's "score every reachable action" at a search node (planning/mcts_mission.py:232-246).
+ */
+int ipp_tree_score_actions(void* engine, int32_t root_id, const int32_t* path_ids, const double* actions, int32_t n,
+                           const double* prev_action, uint32_t flags, float* reward, int32_t* status, void* stream);
 /* diag of a node's state, float[N] */
 int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream);
 

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "ipp_state_plane": (C.c_int, [_P, C.c_int32, _P, C.c_uint32, _P, _P]),
     "ipp_tree_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_tree_read_diag": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_tree_score_actions": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),

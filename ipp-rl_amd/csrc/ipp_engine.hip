@@ -744,8 +744,8 @@ int ipp_set_adaptive(void* engine, double value_threshold, double interval_facto
     return 0;
 }
 
-int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32_t n, const double* prev_action,
-                      uint32_t flags, float* reward, int32_t* status, void* stream) {
+static int score_actions_impl(void* engine, int32_t env_id, const ScorePath& path, const float* node_diag, const double* actions,
+                              int32_t n, const double* prev_action, uint32_t flags, float* reward, int32_t* status, void* stream) {
     Engine* e = as_engine(engine);
     if (!e || !actions || !prev_action || !reward) return fail(-1, "null argument");
     if (!e->scoring) return fail(-1, "ipp_score_actions needs ipp_config.score_scratch = 1");
@@ -765,10 +765,12 @@ int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32
     PrevAction pa = {{prev_action[0], prev_action[1], prev_action[2]}};
     HIP_TRY(hipMemsetAsync(sv.extent, 0, 8, s));
     const int hdr_blocks = std::max((n + 255) / 256, std::min(64, (v.Npad + 255) / 256));
-    if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_hdr<9>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status);
-    else                 hipLaunchKernelGGL((k_score_hdr<25>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status);
-    if (v.mode == IPP_FACTOR)
-        hipLaunchKernelGGL(k_score_densify, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id);
+    if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_hdr<9>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status, node_diag);
+    else                 hipLaunchKernelGGL((k_score_hdr<25>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status, node_diag);
+    if (v.mode == IPP_FACTOR && path.depth > 0)
+        hipLaunchKernelGGL(k_score_densify<true>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, path, e->tv.node_cov, e->tv.node_meta);
+    else if (v.mode == IPP_FACTOR)
+        hipLaunchKernelGGL(k_score_densify<false>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, path, nullptr, nullptr);
     hipLaunchKernelGGL(k_score_band, dim3(v.H, kScoreDCap + 1, kScoreSplit), dim3(256), band_lds, s, v, sv, band_kc);
     if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_eval<9>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     else                 hipLaunchKernelGGL((k_score_eval<25>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
@@ -823,12 +825,33 @@ int ipp_state_plane(void* engine, int32_t env_id, const float* mean_for_mask, ui
     if (v.mode == IPP_DENSE) sv.P = v.cov + (size_t)env_id * v.cov_slot;
     hipLaunchKernelGGL(k_plane_mask, dim3((v.Npad + 255) / 256), dim3(256), 0, s, v, env_id, mean_for_mask, flags, sv.mask, sv.extent);
     if (v.mode == IPP_FACTOR)
-        hipLaunchKernelGGL(k_score_densify, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id);
+        hipLaunchKernelGGL(k_score_densify<false>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, ScorePath{}, nullptr, nullptr);
     const int blocks = std::min(v.N, 1024);
     hipLaunchKernelGGL(k_plane_minmax, dim3(blocks), dim3(256), 0, s, v, sv.P, sv.mask, sv.extent);
     hipLaunchKernelGGL(k_plane_write, dim3(blocks), dim3(256), 0, s, v, sv.P, sv.mask, sv.extent, out);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int ipp_score_actions(void* engine, int32_t env_id, const double* actions, int32_t n, const double* prev_action,
+                      uint32_t flags, float* reward, int32_t* status, void* stream) {
+    return score_actions_impl(engine, env_id, ScorePath{}, nullptr, actions, n, prev_action, flags, reward, status, stream);
+}
+
+int ipp_tree_score_actions(void* engine, int32_t root_id, const int32_t* path_ids, const double* actions, int32_t n,
+                           const double* prev_action, uint32_t flags, float* reward, int32_t* status, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !path_ids) return fail(-1, "null argument");
+    if (e->tv.node_cap <= 0 || e->v.mode != IPP_FACTOR) return fail(-1, "ipp_tree_score_actions needs IPP_FACTOR and node_capacity > 0");
+    ScorePath path{};
+    for (int j = 0; j < kTreeDepth; ++j) {
+        const int id = path_ids[j];
+        if (id < 0) continue;
+        if (id >= e->tv.node_cap) return fail(-1, "node id %d outside [0, %d)", id, e->tv.node_cap);
+        path.ids[path.depth++] = id;
+    }
+    const float* node_diag = path.depth ? e->tv.node_diag + (size_t)path.ids[path.depth - 1] * e->v.Npad : nullptr;
+    return score_actions_impl(engine, root_id, path, node_diag, actions, n, prev_action, flags, reward, status, stream);
 }
 
 int ipp_fork(void* engine, const int32_t* src_ids, const int32_t* dst_ids, int32_t n, void* stream) {

@@ -41,7 +41,7 @@ struct PrevAction { double p[3]; };
 template <int MC>
 __global__ __launch_bounds__(256) void k_score_hdr(View v, ScoreView sv, int env, const double* __restrict__ actions, int A,
                                                    PrevAction prev, unsigned flags, float* __restrict__ reward,
-                                                   int* __restrict__ status_out) {
+                                                   int* __restrict__ status_out, const float* __restrict__ diag_src) {
     constexpr int FC = 4 * MC;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     // adaptive mask of the state (planning/common/rewards.py:8-12), one pass by the first blocks
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_score_hdr(View v, ScoreView sv, int env
         float mk = 0.f;
         if (i < v.N)
             mk = (!(flags & IPP_ADAPTIVE) ||
-                  ((double)v.mean[(size_t)env * v.Npad + i] + v.kf * (double)v.diag[(size_t)env * v.Npad + i] >= v.thr)) ? 1.f : 0.f;
+                  ((double)v.mean[(size_t)env * v.Npad + i] + v.kf * (double)(diag_src ? diag_src[i] : v.diag[(size_t)env * v.Npad + i]) >= v.thr)) ? 1.f : 0.f;
         sv.mask[i] = mk;
     }
     if (a >= A) return;
@@ -96,14 +96,35 @@ __global__ __launch_bounds__(256) void k_score_hdr(View v, ScoreView sv, int env
 
 // ---------------------------------------------------------------- factor state -> dense P (fp32), 64 x 64 tiles
 // P[i][j] = P0(i, j) - sum_k U[k][i] U[k][j] over the columns stored on both cells' tiles.
-__global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int env) {
+// CHAIN: the state of a tree node (k_tree.h): the root env's columns followed by the column blocks of the path.
+struct ScorePath { int depth; int ids[kTreeDepth]; };
+
+template <bool CHAIN>
+__global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int env, ScorePath path, const float* __restrict__ node_cov,
+                                                       const int* __restrict__ node_meta) {
     constexpr int TB = 64, KC = 32;
     __shared__ float ui[KC][TB + 1], uj[KC][TB + 1];
     const int i0 = blockIdx.y * TB, j0 = blockIdx.x * TB;
     const int tid = threadIdx.x, ti = tid / 16, tj = tid % 16;  // thread owns rows ti*4.., cols tj*4..
     const float* U = v.cov + (size_t)env * v.cov_slot;
-    const int r = v.rank[env];
+    int r = v.rank[env];
     const int* span = v.colspan + (size_t)env * v.rank_cap;
+    ChainCols cc;
+    if (CHAIN) {
+        cc.root = U; cc.root_spans = span; cc.r_root = r; cc.depth = 0; cc.npad = (size_t)v.Npad;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j) { cc.node[j] = U; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < path.depth) {
+                const int id = path.ids[j];
+                cc.node[j] = node_cov + (size_t)id * v.meas_cap * v.Npad;
+                cc.off[j] = r;
+                cc.nspan[j] = node_meta[2 * id + 1];
+                r += node_meta[2 * id];
+            }
+        cc.depth = path.depth;
+    }
     const int tile_i = i0 / v.tile_cells, tile_j = j0 / v.tile_cells;  // 64 divides tile_cells: a block sits on one tile
     float acc[4][4];
 #pragma unroll
@@ -117,9 +138,10 @@ __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int
             const int k = k0 + kk;
             float a = 0.f, b = 0.f;
             if (k < r) {
-                const int sp = span[k], lo = sp & 0xffff, hi = sp >> 16;
-                if (tile_i >= lo && tile_i <= hi && i0 + c < v.N) a = U[(size_t)k * v.Npad + i0 + c];
-                if (tile_j >= lo && tile_j <= hi && j0 + c < v.N) b = U[(size_t)k * v.Npad + j0 + c];
+                const int sp = CHAIN ? cc.span(k) : span[k], lo = sp & 0xffff, hi = sp >> 16;
+                const float* rowk = CHAIN ? cc.row(k) : U + (size_t)k * v.Npad;
+                if (tile_i >= lo && tile_i <= hi && i0 + c < v.N) a = rowk[i0 + c];
+                if (tile_j >= lo && tile_j <= hi && j0 + c < v.N) b = rowk[j0 + c];
             }
             ui[kk][c] = a;
             uj[kk][c] = b;

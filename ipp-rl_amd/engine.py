@@ -210,6 +210,21 @@ class IPPEngine:
         self._keep = (roots, paths, new, a, p)
         return reward, status
 
+    def tree_score_actions(self, root: int, path, actions, prev_action, *, adaptive=True, use_flight_time=True):
+        """score_actions from the state of a tree node (root env slot + node path, host list padded with -1)."""
+        torch = _torch()
+        a = self._dev(actions, torch.float64).reshape(-1, 3)
+        n = a.shape[0]
+        reward = torch.empty(n, dtype=torch.float32, device=self.device)
+        status = torch.empty(n, dtype=torch.int32, device=self.device)
+        ids = (C.c_int32 * self.TREE_DEPTH)(*[int(x) for x in (list(path) + [-1] * self.TREE_DEPTH)[: self.TREE_DEPTH]])
+        pv = (C.c_double * 3)(*[float(x) for x in np.asarray(prev_action, dtype=np.float64).ravel()[:3]])
+        flags = (_ffi.IPP_ADAPTIVE if adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if use_flight_time else 0)
+        _ffi.check(self._lib.ipp_tree_score_actions(self._h, int(root), ids, self._ptr(a), n, pv, flags, self._ptr(reward),
+                                                    self._ptr(status), self.stream))
+        self._keep_score = a
+        return reward, status
+
     def tree_diag(self, node: int):
         torch = _torch()
         out = torch.empty(self.n_cells, dtype=torch.float32, device=self.device)

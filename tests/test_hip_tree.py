@@ -29,7 +29,8 @@ def test_tree_steps_vs_chained_oracle_predictions(dim, window_rows):
 
     cfg = EngineConfig(x_dim=dim, y_dim=dim)
     ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim, resolution=cfg.resolution, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b)
-    eng = IPPEngine(cfg, capacity=3, state="factor", rank_cap=128, window_rows=window_rows, node_capacity=32, max_batch=16)
+    eng = IPPEngine(cfg, capacity=3, state="factor", rank_cap=128, window_rows=window_rows, node_capacity=32, max_batch=64,
+                    score_scratch=True)
     rs = np.random.RandomState(dim)
     white = rs.normal(size=(dim, dim))
     eng.reset(env_ids=[2], white_noise=white[None])
@@ -83,6 +84,13 @@ def test_tree_steps_vs_chained_oracle_predictions(dim, window_rows):
     for k, nid in enumerate(nodes):
         want = orc.predict_step(ocfg, P_of[nid], prevs[k], acts[k], UAV, info)[0]
         assert abs(float(reward[k]) - want) < TOL
+    # all-candidate scoring from a node state (ipp_tree_score_actions) == per-candidate tree steps == oracle
+    cand = np.array([random_action() for _ in range(48)])
+    r_all, st_all = eng.tree_score_actions(2, path_of[5], cand, prev_of[5])
+    r_each, _ = eng.tree_step([2] * len(cand), [pad(path_of[5])] * len(cand), cand, np.tile(prev_of[5], (len(cand), 1)))
+    assert int(st_all.abs().sum()) == 0 and float((r_all - r_each).abs().max()) < TOL
+    for k in (0, 7, 23, 47):
+        assert abs(float(r_all[k]) - orc.predict_step(ocfg, P_of[5], prev_of[5], cand[k], UAV, info)[0]) < TOL
     # the root env slot is untouched
     assert eng.rank(2) == root_rank and np.array_equal(host(eng.read_diag(2)), root_diag)
     assert np.array_equal(host(eng.read_cov(2)), root_cov)
