@@ -54,4 +54,8 @@ def engine_config_from(grid_map, sensor, signal_variance: float, length_scale: f
 
 
 def to_host64(t) -> np.ndarray:
-    return t.detach().cpu().numpy().astype(np.float64)
+    """fp64 host copy of a device tensor; large tensors are widened on the device (cheaper than numpy's astype)."""
+    t = t.detach()
+    if t.numel() >= (1 << 16):
+        return t.double().cpu().numpy()
+    return t.cpu().numpy().astype(np.float64)

@@ -142,7 +142,13 @@ class IPPEngine:
         if isinstance(x, torch.Tensor):
             t = x.to(device=self.device, dtype=dtype).contiguous()
         else:
-            t = torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=self.device)
+            arr = np.ascontiguousarray(x)
+            if arr.size >= (1 << 16) and arr.dtype == np.float64 and dtype == torch.float32:
+                # large fp64 host arrays (dense covariances of the drop-in classes): copy as they are and convert on
+                # the device -- numpy's single-threaded astype costs more than the extra PCIe bytes
+                t = torch.from_numpy(arr).to(self.device).to(dtype)
+            else:
+                t = torch.as_tensor(arr, dtype=dtype, device=self.device)
         if shape is not None:
             t = t.reshape(shape)
         return t
