@@ -150,10 +150,10 @@ def test_not_positive_definite_paths():
     assert int(s[0]) == _ffi.STATUS_NOT_PD and np.isnan(float(r[0])) and factor.rank(0) == 0
 
 
-@pytest.mark.parametrize("state", ["dense", "factor"])
-def test_out_of_place_fork_and_predict_only(state):
+@pytest.mark.parametrize("state,window_rows", [("dense", 0), ("factor", 0), ("factor", 12)])
+def test_out_of_place_fork_and_predict_only(state, window_rows):
     dim = 14
-    eng, ocfg = make(dim, state=state, capacity=6)
+    eng, ocfg = make(dim, state=state, capacity=6, window_rows=window_rows)
     rs = np.random.RandomState(3)
     eng.reset(white_noise=rs.normal(size=(6, dim, dim)))
     prev = np.tile([2.0, 2.0, 14.0], (6, 1))
