@@ -319,3 +319,43 @@ def test_metrics_kernel_vs_oracle():
                      orc.metric_uncertainty(diag, msk), orc.metric_uncertainty_difference(diag, msk)])
     got = host(eng.metrics(env_ids=[0]))[0]
     assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-4
+
+
+def test_vec_env_shuffled_priors_vs_oracle():
+    """shuffle_prior_cov (mapping/mappings.py:238-240): every episode of every env draws its own (sigma^2, l) in
+    [0.8, 1.2] x nominal; the batched driver passes them per reset and the step uses them (checked env by env)."""
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+
+    dim, B, T = 20, 6, 4
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    env = VecIPPEnv(cfg, B, state="factor", episode_steps=T, seed=5, stagger=True, shuffle_prior_cov=True, window_rows=12)
+    env.reset()
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim, resolution=cfg.resolution, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b)
+    for t in range(7):
+        acts = cell_centre_actions(cfg, t, 0, B, B, [6.0, 9.0, 14.0])
+        _, status = env.step(acts)
+        assert int(status.abs().sum()) == 0
+    # after 7 steps every env has been reset at least once with a shuffled prior: diag of a just-reset env == its sigma^2
+    scales = set()
+    for e in range(B):
+        steps_in_episode = (7 + int(env.phase[e])) % T
+        d = host(env.diag(e))
+        if steps_in_episode == 0:
+            sv = float(d.max())
+            assert abs(float(d.min()) - sv) < 1e-6 and 0.8 * cfg.signal_variance - 1e-6 <= sv <= 1.2 * cfg.signal_variance + 1e-6
+            scales.add(round(sv, 6))
+        else:
+            assert float(d.max()) <= 1.2 * cfg.signal_variance + 1e-6 and float(d.min()) < float(d.max())
+    assert len(scales) >= 1
+    # one env step by step against the oracle with that env's drawn prior
+    e = 0
+    env.reset()
+    sv, ls = env._prior_scale(np.array([e]), env.t)[0]
+    P = orc.matern_prior(ocfg, sv, ls)
+    prev = np.array([2.0, 2.0, 14.0])
+    info = {"mean": 0.5 * np.ones((dim, dim)), "value_threshold": 0.4, "interval_factor": 0.0}
+    acts = cell_centre_actions(cfg, 50, 0, B, B, [6.0, 9.0, 14.0])
+    reward, _ = env.step(acts, auto_reset=False)
+    want = orc.predict_step(ocfg, P, prev, acts[e], {"max_v": 2.0, "max_a": 2.0}, info)[0]
+    assert abs(float(reward[e]) - want) < TOL
