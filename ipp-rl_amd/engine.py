@@ -10,7 +10,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import math
 from dataclasses import dataclass
 from typing import Dict, Optional
 

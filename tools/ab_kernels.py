@@ -8,7 +8,6 @@ engines' own HIP-event profiling and the median wall time per step.
 usage: python tools/ab_kernels.py [--envs 4096] [--rounds 60] name=path/to/lib.so[:tile_threads] ...
 """
 import argparse
-import ctypes as C
 import os
 import sys
 import time

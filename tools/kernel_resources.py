@@ -2,7 +2,6 @@
 """Print VGPR / scratch / occupancy / LDS per kernel from hipcc's -Rpass-analysis=kernel-resource-usage."""
 import re
 import subprocess
-import sys
 import os
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
