@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
     int item, tile;
     if (!decode_block(blockIdx.x, n_items, v.n_tiles, item, tile)) return;
     const int tid = threadIdx.x;
-    const ItemHdr h = v.hdr[item];
+    const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int m = h.m;
     const int T = blockDim.x;
 
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kMaxTileThreads, 4) void k_downdate(View v, int n_i
     __shared__ float Ss[MC * MC];
     int item, part;
     if (!decode_block(blockIdx.x, n_items, n_bands * v.n_tiles, item, part)) return;
-    const ItemHdr h = v.hdr[item];
+    const ItemHdr h = uniform_hdr(v.hdr[item]);
     if (!h.commit || h.m == 0) return;
     const int band = part / v.n_tiles, tile = part - band * v.n_tiles;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -397,59 +397,61 @@ __global__ __launch_bounds__(kMaxTileThreads, 4) void k_downdate(View v, int n_i
     if (h.fallback)
         for (int i = tid; i < MC * MC; i += T) Ss[i] = v.linv[(size_t)item * MC * MC + i];
 
+    // this thread's cells of Wc (normal path) or of Z = Y S^-1 (fallback, mappings.py:206: accumulated row by row so
+    // that no second m-vector per cell is live -- the unrolled Y -> Z transform used to cost 38 spilled registers)
     float wj[VEC][MC];
-#pragma unroll
-    for (int j = 0; j < MC; ++j) {
-        float t[VEC];
-        load_vec<VEC>(wc + (size_t)j * v.Npad + cell0, t);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) wj[c][j] = t[c];
-    }
-    __syncthreads();
     if (h.fallback) {
+        __syncthreads();  // Ss staged
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            float zj[MC];
+        for (int c = 0; c < VEC; ++c)
+#pragma unroll
+            for (int j = 0; j < MC; ++j) wj[c][j] = 0.f;
+        for (int i = 0; i < MC; ++i) {
+            float t[VEC];
+            load_vec<VEC>(wc + (size_t)i * v.Npad + cell0, t);
 #pragma unroll
             for (int j = 0; j < MC; ++j) {
-                float s = 0.f;
+                const float sij = Ss[i * MC + j];
 #pragma unroll
-                for (int i = 0; i < MC; ++i) s = fmaf(wj[c][i], Ss[i * MC + j], s);
-                zj[j] = s;
+                for (int c = 0; c < VEC; ++c) wj[c][j] = fmaf(t[c], sij, wj[c][j]);
             }
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < MC; ++j) wj[c][j] = zj[j];
+        for (int j = 0; j < MC; ++j) {
+            float t[VEC];
+            load_vec<VEC>(wc + (size_t)j * v.Npad + cell0, t);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) wj[c][j] = t[c];
         }
     }
+    __syncthreads();
     const float* psrc = v.cov + (size_t)h.env * v.cov_slot + (size_t)row0 * v.Npad + cell0;
     float* pdst = v.cov + (size_t)h.dst * v.cov_slot + (size_t)row0 * v.Npad + cell0;
     const int last = nrows - 1;
-    auto apply = [&](float (&p)[kPipe][VEC], int rbase) {
+    // groups of G rows requested together, downdated and written back; nothing loaded is carried over the back edge
+    // (a carried ping-pong group compiles to register copies that each wait for their load, see k_gain_wave.h)
+    constexpr int G = 8;
+    static_assert(G <= 2 * kPipe, "wi holds 2 * kPipe zero rows behind the band");
+    for (int rr = 0; rr < nrows; rr += G) {
+        float p[G][VEC];
 #pragma unroll
-        for (int i = 0; i < kPipe; ++i) {
+        for (int i = 0; i < G; ++i) load_vec<VEC>(psrc + (size_t)min(rr + i, last) * v.Npad, p[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
             float a[QS];
 #pragma unroll
             for (int t4 = 0; t4 < QS / 4; ++t4) {
-                const float4 q4 = *reinterpret_cast<const float4*>(&wi[(rbase + i) * QS + 4 * t4]);
+                const float4 q4 = *reinterpret_cast<const float4*>(&wi[(rr + i) * QS + 4 * t4]);
                 a[4 * t4 + 0] = q4.x; a[4 * t4 + 1] = q4.y; a[4 * t4 + 2] = q4.z; a[4 * t4 + 3] = q4.w;
             }
 #pragma unroll
             for (int j = 0; j < MC; ++j)
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) p[i][c] = fmaf(a[j], wj[c][j], p[i][c]);
-            if (rbase + i < nrows) store_vec<VEC>(pdst + (size_t)(rbase + i) * v.Npad, p[i]);
+            if (rr + i < nrows) store_vec<VEC>(pdst + (size_t)(rr + i) * v.Npad, p[i]);
         }
-    };
-    float pa[kPipe][VEC], pb[kPipe][VEC];
-#pragma unroll
-    for (int i = 0; i < kPipe; ++i) load_vec<VEC>(psrc + (size_t)min(i, last) * v.Npad, pa[i]);
-    for (int rr = 0; rr < nrows; rr += 2 * kPipe) {
-#pragma unroll
-        for (int i = 0; i < kPipe; ++i) load_vec<VEC>(psrc + (size_t)min(rr + kPipe + i, last) * v.Npad, pb[i]);
-        apply(pa, rr);
-#pragma unroll
-        for (int i = 0; i < kPipe; ++i) load_vec<VEC>(psrc + (size_t)min(rr + 2 * kPipe + i, last) * v.Npad, pa[i]);
-        apply(pb, rr + kPipe);
     }
 }
 
