@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kMaxTileThreads, 4) void k_downdate(View v, int n_i
     for (int rr = 0; rr < nrows; rr += G) {
         float p[G][VEC];
 #pragma unroll
-        for (int i = 0; i < G; ++i) load_vec<VEC>(psrc + (size_t)min(rr + i, last) * v.Npad, p[i]);
+        for (int i = 0; i < G; ++i) load_stream<VEC>(psrc + (size_t)min(rr + i, last) * v.Npad, p[i]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kMaxTileThreads, 4) void k_downdate(View v, int n_i
             for (int j = 0; j < MC; ++j)
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) p[i][c] = fmaf(a[j], wj[c][j], p[i][c]);
-            if (rr + i < nrows) store_vec<VEC>(pdst + (size_t)(rr + i) * v.Npad, p[i]);
+            if (rr + i < nrows) store_stream<VEC>(pdst + (size_t)(rr + i) * v.Npad, p[i]);
         }
     }
 }
