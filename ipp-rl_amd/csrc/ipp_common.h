@@ -17,6 +17,19 @@
 #define IPP_TICK_DECL(t) ((void)0)
 #define IPP_TICK(v, k, t) ((void)0)
 #endif
+// -DIPP_TIMELINE=1: timeline of the last fused step launch: per item the wall clock at workgroup start, at the end
+// of phase A and at the last wave's exit (three stores per workgroup; IPP_TIMELINE_FILE=<path> makes
+// ipp_streamed_bytes dump it, tools/timeline.py prints the occupancy over time).
+#ifndef IPP_TIMELINE
+#define IPP_TIMELINE 0
+#endif
+#if IPP_TIMELINE
+constexpr int kTimelineItems = 65536;
+__device__ unsigned long long g_timeline[4 * kTimelineItems];
+#define IPP_MARK(item, k) do { if ((item) < kTimelineItems) g_timeline[4 * (item) + (k)] = wall_clock64(); } while (0)
+#else
+#define IPP_MARK(item, k) ((void)0)
+#endif
 
 namespace ipp {
 
@@ -172,13 +185,25 @@ __device__ __forceinline__ Block block_of(int i, int nx, int rf, int w, int h) {
     return b;
 }
 
-// XCD-aware block -> (item, part) map: blocks b, b+8, b+16.. run on one XCD (observed b % 8), so the
-// parts of one item are laid out on consecutive slots of the same XCD and share its L2 (Q, Wc, header).
+// XCD-aware block -> item map.  Blocks b, b+8, b+16.. run on one XCD (observed b % 8) and every XCD works through
+// its own list independently, so item = b gives XCD x the items with index = x mod 8.  Any workload whose cost has
+// a period sharing a factor with 8 then loads the XCDs unevenly (staggered 40-step episodes, rank ~ phase: the
+// heaviest XCD started its last workgroup 60 us after the lightest one, 15 % of the step kernel).  Here XCD x takes
+// the contiguous range [x n/8, (x+1) n/8) instead: every XCD sees the whole cycle.
+__device__ __forceinline__ int xcd_item(int b, int n_items) {
+    const int xcd = b & 7, slot = b >> 3;
+    const int base = n_items >> 3, rem = n_items & 7;
+    return xcd * base + min(xcd, rem) + slot;  // slot < base + (xcd < rem) for every b < n_items
+}
+// (item, part) for kernels with several blocks per item: the parts of one item sit on consecutive slots of the same
+// XCD and share its L2 (Q, Wc, header).  Grid = grid_for(n_items, parts).
 __device__ __forceinline__ bool decode_block(int b, int n_items, int parts, int& item, int& part) {
     const int xcd = b & 7, slot = b >> 3;
-    item = (slot / parts) * 8 + xcd;
-    part = slot - (slot / parts) * parts;
-    return item < n_items;
+    const int base = n_items >> 3, rem = n_items & 7;
+    const int j = slot / parts;
+    item = xcd * base + min(xcd, rem) + j;
+    part = slot - j * parts;
+    return j < base + (xcd < rem ? 1 : 0);
 }
 inline int grid_for(int n_items, int parts) { return ((n_items + 7) / 8) * 8 * parts; }
 

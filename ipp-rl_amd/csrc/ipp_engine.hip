@@ -289,7 +289,9 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                   hipEvent_t prep_done) {
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
         ProfScope ps(e, 0, s);
-        hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, v.q, env_ids, n, action, prev,
+        // persistent grid: no more workgroups than the GPU holds at once, the rest of the items through tickets
+        // persistent grid: no more workgroups than the GPU holds at once, the rest of the items through tickets
+        hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev,
                            noise, flags, e->lut_rows, status, reward);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
@@ -793,10 +795,10 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     e->last_n = n;
     const View& v = e->v;
     if (v.meas_cap == 9)
-        hipLaunchKernelGGL((k_tree_step<9, 4>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, v.q, root_ids, path_ids, new_ids, n,
+        hipLaunchKernelGGL((k_tree_step<9, 4>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                            action, prev_action, flags, e->lut_rows, status, reward);
     else
-        hipLaunchKernelGGL((k_tree_step<25, 2>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, v.q, root_ids, path_ids, new_ids, n,
+        hipLaunchKernelGGL((k_tree_step<25, 2>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                            action, prev_action, flags, e->lut_rows, status, reward);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1009,6 +1011,14 @@ int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* strea
         unsigned long long c[8];
         HIP_TRY(hipMemcpy(c, e->v.counters, 64, hipMemcpyDeviceToHost));
         fprintf(stderr, "[phase timing, 10 ns ticks summed over workgroups] c1 hdr %llu c2 obs %llu c3 gather %llu c4 %llu c5 %llu c6 %llu c7 %llu\n", c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    }
+#endif
+#if IPP_TIMELINE
+    if (const char* path = getenv("IPP_TIMELINE_FILE")) {
+        const size_t n = (size_t)4 * std::min((int)e->v.max_batch, kTimelineItems);
+        std::vector<unsigned long long> tl(n);
+        HIP_TRY(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_timeline), n * 8));
+        if (FILE* f = fopen(path, "wb")) { fwrite(tl.data(), 8, n, f); fclose(f); }
     }
 #endif
     if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 64, s));

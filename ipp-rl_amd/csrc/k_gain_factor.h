@@ -95,9 +95,9 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // Tile loop + per-item results; expects Ls / ys, the block tables, the prior table P0(|drow| < lut_rows, |dcol|)
 // (row distances beyond it fall back to sqrt / exp), span_s[0..r)
 // and the two counters (zeroed) in LDS, visible to the whole workgroup.
-// qrows: the item's Q rows [k][QS] in global scratch, followed by >= 8 zero rows.  It must be a pointer the
-// compiler can prove read-only (a `const float* __restrict__` kernel argument): only then are the wave-uniform row
-// reads emitted as scalar loads.
+// qrows: the item's Q rows [k][QS] in global scratch, followed by >= 8 zero rows.  The wave-uniform row reads are
+// emitted as scalar loads only if the compiler can prove the rows read-only (a `const float* __restrict__` kernel
+// argument, stand-alone kernel) or is told so (QCONST, fused kernels).
 // PRE (fused kernel): qrows holds the rows of -HT (HT = H_F U[F,:]^T, m values per column) instead of Q = -HT L^-1,
 // the accumulators hold Wc L = P[:,F] H_F^T per cell, and the tile epilogue applies L^-1 (upper triangular, 45 FMAs
 // per cell) once lds.solve_flag says wave 0 has finished the m x m algebra.  The stream therefore starts right
@@ -108,7 +108,9 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // CHAIN (ipp_tree_step): the streamed columns come from a chained tree state (cc), the m new columns go to the new
 // node's block, diag_rw is the new node's diagonal (initialised as a copy of its parent's), and instead of the env's
 // rank / spans the node's (m, span) record is written; nothing of the root env slot is modified.
-template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false>
+// QCONST: qrows is read through the constant address space (scalar loads whatever the compiler can prove about
+// aliasing); the caller guarantees the rows are complete and visible before the call and unchanged during it.
+template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out, const ChainCols* cc = nullptr,
@@ -122,6 +124,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const int lane = tid & (kWave - 1), wave = tid / kWave, nw = T / kWave;
     const int m = h.m, r = h.rank;
     const float s3 = (float)(kSqrt3 * v.res) / h.ls;
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    cfloat_p qrows_c = (cfloat_p)(const void*)qrows;
+    if (QCONST) asm volatile("" : "+s"(qrows_c));  // defined here: no load through it can move above the caller's barrier
 
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
@@ -258,9 +263,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     const float* __restrict__ qr = qrows + (size_t)kk[i] * QS;  // wave-uniform -> s_load
+                    cfloat_p qc = qrows_c + (size_t)kk[i] * QS;
                     float qv[MC];
 #pragma unroll
-                    for (int j = 0; j < MC; ++j) qv[j] = qr[j];
+                    for (int j = 0; j < MC; ++j) qv[j] = QCONST ? qc[j] : qr[j];
 #pragma unroll
                     for (int j = 0; j < MC; ++j)
 #pragma unroll
@@ -389,6 +395,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     if (PRE) dead = __hip_atomic_load(lds.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without tiles never looked)
     const bool commit_item = h.commit && !dead;
     if (lane == 0) {
+        if (PRE && !CHAIN) IPP_MARK(item, 2);
         double tot = 0.0;
         for (int w = 0; w < nw; ++w) tot += red[w];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
@@ -407,8 +414,8 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
     const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave);
-    const int item = blockIdx.x;
-    if (item >= n_items) return;
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;
     const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int r = h.rank;

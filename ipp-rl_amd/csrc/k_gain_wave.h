@@ -46,8 +46,8 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
     float* fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);               // [MC][4] weight of that cell (0 for padding)
     unsigned short* ridx = reinterpret_cast<unsigned short*>(fb_w + 4 * MC);
 
-    const int item = blockIdx.x;
-    if (item >= n_items) return;
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
     const int lane = threadIdx.x;
     const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int m = h.m, r = h.rank;

@@ -29,15 +29,15 @@ __host__ __device__ constexpr int step_small_floats() {
     return (int)((prep_small_bytes<MC>() + 15) / 16 * 4);
 }
 
-// q_ro == v.q.  Phase A writes the item's -HT rows through v.q (vector stores, complete at the workgroup barrier
-// below: __syncthreads waits for vmcnt(0) and the stores are write-through to L2), the tile loop reads them
-// through q_ro, which the compiler may treat as read-only and therefore fetches with scalar loads.  The two never
-// overlap in time within a workgroup, no other workgroup touches this item's block, blocks are 64-byte aligned
-// (no scalar-cache line shared between items) and the scalar cache is invalidated at every kernel launch, so it
-// cannot hold lines of a previous step.
+// Phase A writes the item's -HT rows to its block of v.q (vector stores, complete at the workgroup barrier below:
+// __syncthreads waits for vmcnt(0) and the stores are write-through to L2); the tile loop reads them back through
+// the constant address space (gain_tiles<QCONST>), i.e. with scalar loads.  The two never overlap in time within a
+// workgroup, no other workgroup touches this item's block, blocks are 64-byte aligned (no scalar-cache line shared
+// between items) and the scalar cache is invalidated at every kernel launch, so it cannot hold lines of a previous
+// step.
 template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
-    View v, const float* __restrict__ q_ro, const int* __restrict__ env_ids, int n_items,
+    View v, const int* __restrict__ env_ids, int n_items,
     const double* __restrict__ action, const double* __restrict__ prev_action, const float* __restrict__ meas_noise,
     unsigned flags, int lut_rows, int* __restrict__ status_out, float* __restrict__ reward_out) {
     constexpr int QS = (MC + 3) & ~3;
@@ -45,9 +45,10 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
     const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
                           kStepThreads / kWave, v.Npad / VEC);
-    const int item = blockIdx.x;
-    if (item >= n_items) return;
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
+    if (tid == 0) IPP_MARK(item, 0);
 
     // ---- phase A: header, observation, gather of HT(i,k) = work[k*QS + i].  While the footprint-dependent loads are
     // in flight the workgroup builds the prior table and the block tables (pure arithmetic on the header).
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
     __syncthreads();
     IPP_TICK(v, 4, tick);
+    if (tid == 0) IPP_MARK(item, 1);
 
     // ---- wave 0 finishes the m x m algebra while waves 1..3 already stream (they need L^-1 only in a tile epilogue)
     if (tid < kWave) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true>(v, h, item, flags, lut_rows, lds, q_ro + (size_t)item * v.q_item + LQ, reward_out);
+    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, false, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out);
 }
 
 }  // namespace ipp

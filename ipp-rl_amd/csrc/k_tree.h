@@ -21,7 +21,7 @@ struct TreeView {
 
 template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
-    View v, TreeView tv, const float* __restrict__ q_ro, const int* __restrict__ root_ids, const int* __restrict__ path_ids,
+    View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids,
     const int* __restrict__ new_ids, int n_items, const double* __restrict__ action, const double* __restrict__ prev_action,
     unsigned flags, int lut_rows, int* __restrict__ status_out, float* __restrict__ reward_out) {
     constexpr int QS = (MC + 3) & ~3;
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tr[];
     const GainLds<MC> lds(smem_tr, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
                           kStepThreads / kWave, v.Npad / VEC);
-    const int item = blockIdx.x;
-    if (item >= n_items) return;
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
 
     // ---- the chained state of this item (every thread builds the same, wave-uniform description)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, true>(v, h, item, flags_eff, lut_rows, lds, q_ro + (size_t)item * v.q_item + LQ,
+    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
                                                          reward_out, &cc, new_cols, new_diag, new_meta);
 }
 

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=60)
     ap.add_argument("--window-rows", type=int, default=12)
+    ap.add_argument("--order", default="natural", help="comma list per variant: natural | desc | asc (items sorted by rank)")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
     cfg = EngineConfig(x_dim=50, y_dim=50)
@@ -59,11 +60,37 @@ def main():
     flags = _ffi.IPP_ADAPTIVE | _ffi.IPP_USE_FLIGHT_TIME
     wall = {n: [] for n, _, _ in engines}
 
+    orders = (args.order.split(",") * len(engines))[: len(engines)]
+    order_of = {n: o for (n, _, _), o in zip(engines, orders)}
+
     def one(eng, prev, t, timed_name=None):
+        ids_sorted = a_t = p_t = n_t = None
+        mode = order_of[timed_name] if timed_name else "natural"
+        if mode != "natural":  # item i works on env perm[i]; inputs are per item
+            perm = torch.argsort(eng.ranks(), descending=(mode != "asc"), stable=True)
+            if mode == "zigzag":  # heaviest, lightest, 2nd heaviest, 2nd lightest, ...: mixed load, medium items last
+                half = (B + 1) // 2
+                z = torch.empty_like(perm)
+                z[0::2] = perm[:half]
+                z[1::2] = perm.flip(0)[: B - half]
+                perm = z
+            elif mode.startswith("head"):  # "head<k>[tail<j>]": heaviest 1/k first, lightest 1/j last, the rest natural
+                k, _, j = mode[4:].partition("tail")
+                head = perm[: B // int(k)]
+                tail = perm[B - B // int(j):].flip(0) if j else perm[:0]
+                keep = torch.ones(B, dtype=torch.bool, device=perm.device)
+                keep[head] = False
+                keep[tail] = False
+                perm = torch.cat([head, torch.nonzero(keep).flatten(), tail])
+            ids_sorted = perm.to(torch.int32)
+            a_t, p_t, n_t = acts[t][perm].contiguous(), prev[perm].contiguous(), noise[t][perm].contiguous()
         if timed_name:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        eng.step_raw(B, acts[t], prev, noise[t], flags, reward, status)
+        if mode == "natural":
+            eng.step_raw(B, acts[t], prev, noise[t], flags, reward, status)
+        else:
+            eng.step_raw(B, a_t, p_t, n_t, flags, reward, status, env_ids=ids_sorted)
         if timed_name:
             torch.cuda.synchronize()
             wall[timed_name].append(time.perf_counter() - t0)
@@ -83,6 +110,8 @@ def main():
         for name, eng, prev in order:
             one(eng, prev, T + r, timed_name=name)
     torch.cuda.synchronize()
+    if os.environ.get("IPP_TIMELINE_FILE"):  # timing builds dump the last launch's timeline here
+        engines[0][1].streamed_bytes()
     base = None
     for name, eng, _ in engines:
         g_ms, g_n = eng.profile_read(0)
@@ -91,7 +120,7 @@ def main():
         ranks = eng.ranks().double().mean().item()
         base = base or g_ms
         print(f"{name:14s} T={eng.info.tile_threads:3d} gain {g_ms:.4f} ms ({g_ms / base:5.3f}x)  prepare {p_ms:.4f} ms  "
-              f"step wall median {w:.4f} ms  mean rank {ranks:.1f}")
+              f"step wall median {w:.4f} ms  mean rank {ranks:.1f}  order {order_of[name]}")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""
+Occupancy timeline of the last fused step launch of a -DIPP_PHASE_TIMING=1 build (tools/probes/libipp_timing.so):
+reads the dump made through IPP_TIMELINE_FILE (per item: workgroup start, end of phase A, last wave's exit; 100 MHz
+wall clock) and prints how many workgroups were resident / streaming over time.
+
+usage: python tools/timeline.py dump.bin [n_items] [bucket_us]
+"""
+import sys
+
+import numpy as np
+
+
+def main():
+    path = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    bucket = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
+    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)[:n].astype(np.float64)
+    t0 = t[:, 0].min()
+    start, mid, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0  # us
+    ok = t[:, 2] > 0
+    print(f"items {n} (with marks: {int(ok.sum())}), kernel span {end[ok].max():.1f} us")
+    print(f"phase A  mean {np.mean(mid[ok] - start[ok]):.1f} us   p10 {np.percentile(mid[ok] - start[ok], 10):.1f}  p90 {np.percentile(mid[ok] - start[ok], 90):.1f}")
+    print(f"phase B  mean {np.mean(end[ok] - mid[ok]):.1f} us   p10 {np.percentile(end[ok] - mid[ok], 10):.1f}  p90 {np.percentile(end[ok] - mid[ok], 90):.1f}  max {np.max(end[ok] - mid[ok]):.1f}")
+    print(f"last workgroup start at {start[ok].max():.1f} us")
+    edges = np.arange(0.0, end[ok].max() + bucket, bucket)
+    print(" window[us]  resident  in phase A  streaming")
+    for a, b in zip(edges[:-1], edges[1:]):
+        c = 0.5 * (a + b)
+        res = np.sum((start <= c) & (end > c) & ok)
+        pa = np.sum((start <= c) & (mid > c) & ok)
+        print(f" {a:6.0f}-{b:<6.0f} {res:8d} {pa:10d} {res - pa:10d}")
+
+
+if __name__ == "__main__":
+    main()
