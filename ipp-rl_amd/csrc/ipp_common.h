@@ -188,22 +188,28 @@ __device__ __forceinline__ Block block_of(int i, int nx, int rf, int w, int h) {
 // XCD-aware block -> item map.  Blocks b, b+8, b+16.. run on one XCD (observed b % 8) and every XCD works through
 // its own list independently, so item = b gives XCD x the items with index = x mod 8.  Any workload whose cost has
 // a period sharing a factor with 8 then loads the XCDs unevenly (staggered 40-step episodes, rank ~ phase: the
-// heaviest XCD started its last workgroup 60 us after the lightest one, 15 % of the step kernel).  Here XCD x takes
-// the contiguous range [x n/8, (x+1) n/8) instead: every XCD sees the whole cycle.
+// heaviest XCD started its last workgroup 60 us after the lightest one, 15 % of the step kernel).
+// Here the item list is cut into 16 contiguous ranges and XCD x works through range x, then range 15 - x: a range
+// covers many cycles of any short period, and a list sorted by cost (or any trend along the list) is balanced by
+// the mirrored second range, which one contiguous range per XCD would not be (+55 % on the last XCD for a cost
+// rising 0.3 -> 1.3 along the list).  Left over: cost periods of more than n/16 items (10 % at n = 4096, period 500).
 __device__ __forceinline__ int xcd_item(int b, int n_items) {
-    const int xcd = b & 7, slot = b >> 3;
-    const int base = n_items >> 3, rem = n_items & 7;
-    return xcd * base + min(xcd, rem) + slot;  // slot < base + (xcd < rem) for every b < n_items
+    const int len = n_items >> 4, full = len << 4;  // 16 ranges of len items, then the ragged end
+    if (b >= full) return b;
+    const int xcd = b & 7, slot = b >> 3;            // slot in [0, 2 len)
+    const bool second = slot >= len;
+    return (second ? 15 - xcd : xcd) * len + (second ? slot - len : slot);
 }
 // (item, part) for kernels with several blocks per item: the parts of one item sit on consecutive slots of the same
 // XCD and share its L2 (Q, Wc, header).  Grid = grid_for(n_items, parts).
 __device__ __forceinline__ bool decode_block(int b, int n_items, int parts, int& item, int& part) {
     const int xcd = b & 7, slot = b >> 3;
-    const int base = n_items >> 3, rem = n_items & 7;
     const int j = slot / parts;
-    item = xcd * base + min(xcd, rem) + j;
+    const int vb = j * 8 + xcd;  // the block index a one-block-per-item launch would have on this XCD
     part = slot - j * parts;
-    return j < base + (xcd < rem ? 1 : 0);
+    if (vb >= n_items) { item = 0; return false; }
+    item = xcd_item(vb, n_items);
+    return true;
 }
 inline int grid_for(int n_items, int parts) { return ((n_items + 7) / 8) * 8 * parts; }
 
