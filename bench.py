@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--predict-only", action="store_true", help="time the predict-only rate (tree-search call)")
+    ap.add_argument("--fused-resets", action="store_true",
+                    help="A/B: scheduled episode resets inside the step launch (ipp_step_autoreset) instead of their own launch")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
     return ap.parse_args()
 
@@ -157,7 +159,8 @@ def main():
     total_envs = B * world
     lo, hi = rank * B, (rank + 1) * B  # contiguous env-id range per GPU, no exchange between shards
     env = VecIPPEnv(cfg, B, state=args.state, episode_steps=T, device=device, seed=1234, env_id_offset=lo,
-                    stagger=True, tile_threads=args.tile_threads, window_rows=args.window_rows)
+                    stagger=True, tile_threads=args.tile_threads, window_rows=args.window_rows,
+                    fused_reset=args.fused_resets)
     eng = env.engine
     n_total = T + args.warmup + 2 * args.steps
     # synthetic inputs resident in HBM before the timed region

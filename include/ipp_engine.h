@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 4
+#define IPP_ABI_VERSION 5
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -154,6 +154,23 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
  */
 int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const double* prior_scale, const float* gt,
                       const float* white_noise, double* prev_action, const double* init_action, void* stream);
+
+/*
+ * ipp_step (in place, factor engines) with the episode resets that fall on this step folded into the same launch:
+ * item i steps its env and, when reset_src[i] >= 0, then resets it exactly like ipp_reset_episode with
+ * gt = reset_gt[reset_src[i]], the engine's default prior and prev_action[env] <- init_action.  The batched driver's
+ * auto-reset: what Mission.execute's episode loop (planning/missions.py:69-118) does between two episodes, without a
+ * launch between two step kernels.  The windowed 256-thread engine resets inside the step kernel, the other factor
+ * paths by a second launch behind it; results are the same as ipp_step followed by ipp_reset_episode.
+ *   prev_action [dev] double[..][3]: read per ITEM by the step (and written with IPP_UPDATE_PREV), written per ENV by
+ *               the reset: use it with env_ids == NULL (item == env) unless the two index spaces agree
+ *   reset_src   [dev] int32[n]: index into reset_gt, or -1 (no reset); NULL: plain ipp_step
+ *   reset_gt    [dev] float[..][H][W] ground-truth fields (e.g. from ipp_generate_grf)
+ *   init_action [host] double[3]
+ */
+int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const double* action, double* prev_action,
+                       const float* meas_noise, uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src,
+                       const float* reset_gt, const double* init_action, void* stream);
 
 /*
  * Reward of n candidate actions from the CURRENT state of ONE env slot; nothing is written.  The call of

@@ -135,6 +135,38 @@ struct View {
     float* grf_raw2; // [max_batch][Npad] un-normalised field (ipp_generate_grf, may run on a side stream)
 };
 
+// Episode reset folded into a step launch (ipp_step_autoreset): item i resets its env after its step when
+// src[i] >= 0, taking ground truth gt[src[i]] ([N] floats).  Mission.init_action by value.
+struct AutoReset {
+    const int* src;     // [n] or NULL (no resets in this launch)
+    const float* gt;    // [..][N]
+    double* prev;       // [capacity][3] indexed by env id, or NULL
+    double init[3];
+};
+
+// One wave resets env `env` (mapping/mappings.py:235-240,259-261: mean 0.5, P = prior; factor state: rank 0) and
+// installs ground truth field k.  The caller guarantees that every earlier store / atomic to the env's planes
+// has completed.
+__device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& ar, int env, int k, int lane) {
+    const float sv = (float)v.sv0;
+    float* mean = v.mean + (size_t)env * v.Npad;
+    float* diag = v.diag + (size_t)env * v.Npad;
+    float* gt = v.gt + (size_t)env * v.Npad;
+    const float* src = ar.gt + (size_t)k * v.N;
+    for (int c = lane; c < v.Npad; c += kWave) {
+        const bool valid = c < v.N;
+        mean[c] = valid ? 0.5f : 0.f;
+        diag[c] = valid ? sv : 0.f;
+        gt[c] = valid ? src[c] : 0.f;
+    }
+    if (lane == 0) {
+        v.rank[env] = 0;
+        v.prior[2 * env + 0] = v.sv0;
+        v.prior[2 * env + 1] = v.ls0;
+    }
+    if (ar.prev && lane < 3) ar.prev[3 * env + lane] = ar.init[lane];
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);

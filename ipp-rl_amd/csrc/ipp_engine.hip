@@ -286,13 +286,13 @@ size_t gain_lds_bytes(const View& v, int q_chunk, int lut_cap) {
 template <int MC, int VEC>
 void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
                   const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
-                  hipEvent_t prep_done) {
+                  hipEvent_t prep_done, const AutoReset& ar) {
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
         ProfScope ps(e, 0, s);
         // persistent grid: no more workgroups than the GPU holds at once, the rest of the items through tickets
         // persistent grid: no more workgroups than the GPU holds at once, the rest of the items through tickets
         hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev,
-                           noise, flags, e->lut_rows, status, reward);
+                           noise, flags, e->lut_rows, status, reward, ar);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
     }
@@ -332,13 +332,14 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
 // kernel.  Chunks touch disjoint items and (for committed steps) disjoint env slots.
 template <int MC, int VEC>
 int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
-                const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s) {
+                const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
+                const AutoReset& ar) {
     int chunks = e->step_chunks;
     if (chunks <= 0) chunks = 1;  // measured on MI355X: no gain from 2 chunks, slower from 4; opt in with IPP_STEP_CHUNKS
     if (e->profile) chunks = 1;  // kernels are timed alone (bench.py roofline leg)
     chunks = std::min(chunks, kMaxChunks);
     if (chunks <= 1 || !e->side) {
-        launch_chunk<MC, VEC>(e, e->v, env_ids, dst_ids, n, action, prev, noise, flags, reward, status, s, nullptr);
+        launch_chunk<MC, VEC>(e, e->v, env_ids, dst_ids, n, action, prev, noise, flags, reward, status, s, nullptr, ar);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -359,9 +360,11 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
         v.partial += (size_t)off * v.n_tiles;
         v.dbg += (size_t)off * (2 * v.meas_cap * v.meas_cap + 2 * v.meas_cap);
         if (c > 0) HIP_TRY(hipStreamWaitEvent(st, e->ev_prep[c - 1], 0));
+        AutoReset arc = ar;
+        if (arc.src) arc.src += off;
         launch_chunk<MC, VEC>(e, v, env_ids ? env_ids + off : nullptr, dst_ids ? dst_ids + off : nullptr, nc,
                               action + 3 * (size_t)off, prev + 3 * (size_t)off, noise ? noise + (size_t)off * MC : nullptr,
-                              flags, reward + off, status ? status + off : nullptr, st, e->ev_prep[c]);
+                              flags, reward + off, status ? status + off : nullptr, st, e->ev_prep[c], arc);
         used = c + 1;
     }
     (void)used;
@@ -669,9 +672,9 @@ int ipp_reset(void* engine, const int32_t* env_ids, int32_t n, const double* pri
     return ipp_reset_episode(engine, env_ids, n, prior_scale, gt, white_noise, nullptr, nullptr, stream);
 }
 
-int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
-             const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
-             void* stream) {
+static int step_impl(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
+                     const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
+                     void* stream, const AutoReset& ar) {
     Engine* e = as_engine(engine);
     if (!e) return fail(-1, "null engine");
     if (!action || !prev_action || !reward) return fail(-1, "action, prev_action and reward are required");
@@ -690,9 +693,39 @@ int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32
         env_ids = dst_ids;
         dst_ids = nullptr;
     }
+    // the fused kernel resets the flagged envs itself; every other path gets a separate launch behind the step
+    const bool in_kernel = e->fused;
+    const AutoReset none = {nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
+    int rc;
     if (e->v.meas_cap == 9)
-        return launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
-    return launch_step<25, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s);
+        rc = launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none);
+    else
+        rc = launch_step<25, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none);
+    if (rc == 0 && ar.src && !in_kernel) {
+        hipLaunchKernelGGL(k_reset_flagged, dim3((e->v.Npad + 255) / 256, n), dim3(256), 0, s, e->v, env_ids, n, ar);
+        HIP_TRY(hipGetLastError());
+    }
+    return rc;
+}
+
+int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
+             const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
+             void* stream) {
+    const AutoReset none = {nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
+    return step_impl(engine, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, stream, none);
+}
+
+int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const double* action, double* prev_action,
+                       const float* meas_noise, uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src,
+                       const float* reset_gt, const double* init_action, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (e->v.mode != IPP_FACTOR) return fail(-1, "ipp_step_autoreset: factor state only (dense engines: ipp_step + ipp_reset_episode)");
+    if (flags & IPP_PREDICT_ONLY) return fail(-1, "ipp_step_autoreset: not with IPP_PREDICT_ONLY");
+    if (reset_src && (!reset_gt || !init_action)) return fail(-1, "reset_src needs reset_gt and init_action");
+    AutoReset ar = {reset_src, reset_gt, reset_src ? prev_action : nullptr, {0.0, 0.0, 0.0}};
+    if (init_action) for (int k = 0; k < 3; ++k) ar.init[k] = init_action[k];
+    return step_impl(engine, env_ids, nullptr, n, action, prev_action, meas_noise, flags, reward, status, stream, ar);
 }
 
 int ipp_generate_grf(void* engine, int32_t n, const float* white_noise, float* gt_out, void* stream) {

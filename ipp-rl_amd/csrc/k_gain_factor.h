@@ -110,11 +110,14 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // rank / spans the node's (m, span) record is written; nothing of the root env slot is modified.
 // QCONST: qrows is read through the constant address space (scalar loads whatever the compiler can prove about
 // aliasing); the caller guarantees the rows are complete and visible before the call and unchanged during it.
-template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false>
+// RESET (ipp_step_autoreset): an item with ar->src[item] >= 0 resets its env once its step is complete: every wave
+// waits for its own stores / atomics before it counts itself done, the last wave then rewrites the env's planes.
+template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false, bool RESET = false>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out, const ChainCols* cc = nullptr,
-                                           float* new_cols = nullptr, float* diag_rw = nullptr, int* node_meta = nullptr) {
+                                           float* new_cols = nullptr, float* diag_rw = nullptr, int* node_meta = nullptr,
+                                           const AutoReset* ar = nullptr) {
     constexpr int kWaveTile = VEC * kWave;  // cells per wave tile
     constexpr int QS = (MC + 3) & ~3;
     const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut; double* red = lds.red;
@@ -386,6 +389,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         red[wave] = wave_part;
         if (units) atomicAdd(v.counters, units);
     }
+    int reset_k = -1;
+    if (RESET && ar->src) reset_k = __builtin_amdgcn_readfirstlane(ar->src[item]);
+    if (RESET && reset_k >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores / atomics have landed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int arrived = 0;
     if (lane == 0) arrived = atomicAdd(done_waves, 1);
@@ -403,6 +409,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); }
     }
     if (commit_item && !CHAIN && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+    if (RESET && reset_k >= 0) wave_reset_env(v, *ar, h.dst, reset_k, lane);  // (after the rank store above, same lane 0)
 }
 
 // Stand-alone gain kernel (after k_prepare): stages L^-1 | y, the spans and the prior table, then gain_tiles.

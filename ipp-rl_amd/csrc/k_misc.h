@@ -32,6 +32,29 @@ __global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_ite
     if (gt_in) v.gt[(size_t)env * v.Npad + cell] = valid ? gt_in[(size_t)item * v.N + cell] : 0.f;
 }
 
+// ipp_step_autoreset behind the step kernels that do not reset in-kernel: item i resets its env when ar.src[i] >= 0.
+__global__ void k_reset_flagged(View v, const int* __restrict__ env_ids, int n_items, AutoReset ar) {
+    const int item = blockIdx.y;
+    if (item >= n_items) return;
+    const int k = ar.src[item];
+    if (k < 0) return;
+    const int env = env_ids ? env_ids[item] : item;
+    if (env < 0 || env >= v.cap) return;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell == 0) {
+        v.rank[env] = 0;
+        v.prior[2 * env + 0] = v.sv0;
+        v.prior[2 * env + 1] = v.ls0;
+        if (ar.prev)
+            for (int j = 0; j < 3; ++j) ar.prev[3 * env + j] = ar.init[j];
+    }
+    if (cell >= v.Npad) return;
+    const bool valid = cell < v.N;
+    v.mean[(size_t)env * v.Npad + cell] = valid ? 0.5f : 0.f;
+    v.diag[(size_t)env * v.Npad + cell] = valid ? (float)v.sv0 : 0.f;
+    v.gt[(size_t)env * v.Npad + cell] = valid ? ar.gt[(size_t)k * v.N + cell] : 0.f;
+}
+
 // Dense state: P <- Matern prior (mapping/mappings.py:242-261).  Workgroup = kBandRows rows x 1024 columns.
 __global__ __launch_bounds__(256) void k_reset_dense(View v, const int* __restrict__ env_ids, int n_items, int n_bands,
                                                      int n_ctiles) {

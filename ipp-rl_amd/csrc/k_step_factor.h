@@ -39,7 +39,7 @@ template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     View v, const int* __restrict__ env_ids, int n_items,
     const double* __restrict__ action, const double* __restrict__ prev_action, const float* __restrict__ meas_noise,
-    unsigned flags, int lut_rows, int* __restrict__ status_out, float* __restrict__ reward_out) {
+    unsigned flags, int lut_rows, int* __restrict__ status_out, float* __restrict__ reward_out, AutoReset ar) {
     constexpr int QS = (MC + 3) & ~3;
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
@@ -95,8 +95,12 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
         lds.work, 1, QS, nullptr, lds.Ls, nullptr, lds.ys, nullptr, lds.span_s, mid);
     const ItemHdr h = uniform_hdr(*hs);  // (every path of the prologue ends with a barrier)
     IPP_TICK_DECL(tick);
-    if (h.m == 0) {
+    if (h.m == 0) {  // nothing to stream (bad footprint): no step, but a scheduled reset still happens
         if (tid == 0) reward_out[item] = 0.f;
+        if (ar.src && tid < kWave) {
+            const int k = __builtin_amdgcn_readfirstlane(ar.src[item]);
+            if (k >= 0 && h.env >= 0 && h.env < v.cap) wave_reset_env(v, ar, h.env, k, tid);
+        }
         return;
     }
     // -HT rows (sign of the downdate folded in, padding lanes zero) and the zero rows behind them -> global scratch
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, false, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out);
+    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, false, true, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
+                                                                nullptr, nullptr, &ar);
 }
 
 }  // namespace ipp

@@ -264,7 +264,12 @@ class IPPEngine:
 
     def step(self, actions, prev_actions, env_ids=None, dst_ids=None, meas_noise=None, *, cov_only=False,
              predict_only=False, adaptive=True, use_flight_time=True, given_observation=False, reward_out=None,
-             status_out=None, update_prev=False):
+             status_out=None, update_prev=False, reset_src=None, reset_gt=None, init_action=None):
+        """
+        One batched env step.  reset_src / reset_gt / init_action (factor engines, in-place committed steps): the
+        episode resets that fall on this step, folded into the launch (ipp_step_autoreset): reset_src [n] int32
+        device tensor with the index into reset_gt ([k, H, W] float32 device tensor) or -1 per item.
+        """
         torch = _torch()
         a = self._dev(actions, torch.float64).reshape(-1, 3)
         p = self._dev(prev_actions, torch.float64).reshape(-1, 3)
@@ -285,6 +290,21 @@ class IPPEngine:
                 (_ffi.IPP_GIVEN_OBSERVATION if given_observation else 0) | (_ffi.IPP_UPDATE_PREV if update_prev else 0)
         if update_prev and (predict_only or not isinstance(prev_actions, torch.Tensor) or p.data_ptr() != prev_actions.data_ptr()):
             raise ValueError("update_prev needs prev_actions as a contiguous float64 device tensor and a committed step")
+        if reset_src is not None:
+            if dst is not None or predict_only:
+                raise ValueError("reset_src: in-place committed steps only")
+            if not isinstance(prev_actions, torch.Tensor) or p.data_ptr() != prev_actions.data_ptr():
+                raise ValueError("reset_src needs prev_actions as a contiguous float64 device tensor (the reset writes it)")
+            src = self._dev(reset_src, torch.int32)
+            g = self._dev(reset_gt, torch.float32)
+            if src.numel() != n or g is None:
+                raise ValueError("reset_src must have one entry per item and needs reset_gt")
+            init = (C.c_double * 3)(*[float(x) for x in init_action])
+            _ffi.check(self._lib.ipp_step_autoreset(self._h, self._ptr(ids), n, self._ptr(a), self._ptr(p), self._ptr(nz), flags,
+                                                    self._ptr(reward), self._ptr(status), self._ptr(src), self._ptr(g), init,
+                                                    self.stream))
+            self._keep = (a, p, ids, nz, src, g)
+            return reward, status
         _ffi.check(self._lib.ipp_step(self._h, self._ptr(ids), self._ptr(dst), n, self._ptr(a), self._ptr(p), self._ptr(nz),
                                       flags, self._ptr(reward), self._ptr(status), self.stream))
         self._keep = (a, p, ids, dst, nz)

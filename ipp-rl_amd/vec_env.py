@@ -54,7 +54,7 @@ class VecIPPEnv:
     def __init__(self, cfg: EngineConfig, num_envs: int, state: str = "factor", episode_steps: int = 40,
                  device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
                  rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
-                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0):
+                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0, fused_reset: bool = False):
         import torch
 
         self.torch = torch
@@ -84,6 +84,13 @@ class VecIPPEnv:
             ph = self.phase.cpu().numpy()
             self._reset_ids_host = [np.nonzero(ph == p)[0].astype(np.int32) for p in range(self.episode_steps)]
             self._reset_ids_by_phase = [torch.as_tensor(i, device=dev) for i in self._reset_ids_host]
+        # fused_reset: scheduled resets folded into the step launch (ipp_step_autoreset): per phase, the index of every
+        # env's new ground truth among the staged fields, -1 for the envs that carry on (built on first use).  Off by
+        # default: the envs that reset are the highest-rank items of the launch, the ones its tail waits for, and
+        # their extra work costs more (4096 envs: +15 us per step) than the separate reset launch it saves
+        self._fused_reset = bool(fused_reset and stagger and state == "factor" and not shuffle_prior_cov and
+                                 4 * B * self.episode_steps <= (64 << 20))
+        self._reset_src_by_phase = {}
         self._white = torch.empty((B, cfg.n_cells), dtype=torch.float32, device=dev)
         # staggered runs prepare the next resets' ground truths on a side stream while the step kernels run
         # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
@@ -150,6 +157,14 @@ class VecIPPEnv:
             else:
                 self.episode[ids.cpu().numpy()] += 1
 
+    def _reset_src(self, p: int):
+        src = self._reset_src_by_phase.get(p)
+        if src is None:
+            host = np.full(self.num_envs, -1, dtype=np.int32)
+            host[self._reset_ids_host[p]] = np.arange(len(self._reset_ids_host[p]), dtype=np.int32)
+            src = self._reset_src_by_phase[p] = self.torch.as_tensor(host, device=self.device)
+        return src
+
     def _phase_ending_at(self, t: int) -> int:
         """Phase whose envs finish their episode with step index t: env e has done (t + 1 + phase_e) steps."""
         return (self.episode_steps - ((t + 1) % self.episode_steps)) % self.episode_steps
@@ -204,10 +219,20 @@ class VecIPPEnv:
             self._noise_pos = (self._noise_pos + 1) % self.NOISE_RING
         else:
             nz = meas_noise
-        # full-batch steps let the kernel store the new previous waypoint (IPP_UPDATE_PREV): no copy launch
+        # full-batch steps let the kernel store the new previous waypoint (IPP_UPDATE_PREV): no copy launch; with staged
+        # ground truths the scheduled resets ride in the same launch as well (ipp_step_autoreset)
+        fused = None
+        if self._fused_reset and env_ids is None and scheduled is not None and scheduled[1] is not None:
+            p, k, n = scheduled
+            main.wait_event(self._staged_ready[k])
+            fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
         self.engine.step(a, self.prev, env_ids=env_ids, meas_noise=nz, adaptive=self.adaptive,
                          use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status,
-                         update_prev=env_ids is None)
+                         update_prev=env_ids is None, **(fused or {}))
+        if fused is not None:
+            self._staged_free[scheduled[1]].record(main)
+            self.episode[self._reset_ids_host[scheduled[0]]] += 1
+            scheduled = None
         if env_ids is not None:
             self.prev[torch.as_tensor(env_ids, device=self.device).long()] = a
         self.t += 1

@@ -1,0 +1,95 @@
+"""
+ipp_step_autoreset (episode resets folded into the step launch) against ipp_step followed by ipp_reset_episode:
+bit-identical rewards, planes, ranks and previous waypoints on every factor-state kernel path, and VecIPPEnv with
+and without the fused resets.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+INIT = (2.0, 2.0, 14.0)
+
+
+def _engine(window_rows, tile_threads, capacity, dim=50):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    return IPPEngine(cfg, capacity=capacity, state="factor", rank_cap=90, window_rows=window_rows,
+                     tile_threads=tile_threads), cfg
+
+
+def _actions(cfg, rs, n):
+    res = cfg.resolution
+    a = np.empty((n, 3))
+    a[:, 0] = res * rs.randint(0, cfg.x_dim, size=n) + 0.5 * res
+    a[:, 1] = res * rs.randint(0, cfg.y_dim, size=n) + 0.5 * res
+    a[:, 2] = rs.randint(5, 15, size=n)
+    return a
+
+
+@pytest.mark.parametrize("window_rows,tile_threads", [(12, 256), (12, 128), (12, 64), (0, 0)])
+def test_step_autoreset_equals_step_then_reset(window_rows, tile_threads):
+    import torch
+
+    B, steps = 24, 7
+    rs = np.random.RandomState(7)
+    a_eng, cfg = _engine(window_rows, tile_threads, B)
+    b_eng, _ = _engine(window_rows, tile_threads, B)
+    gts = torch.as_tensor(rs.uniform(size=(B, cfg.n_cells)), dtype=torch.float32, device="cuda")
+    for e in (a_eng, b_eng):
+        e.reset(gt=gts)
+    prev_a = torch.tensor(INIT, dtype=torch.float64, device="cuda").repeat(B, 1)
+    prev_b = prev_a.clone()
+    for t in range(steps):
+        acts = _actions(cfg, rs, B)
+        if t == 3:
+            acts[5] = (np.nan, 1.0, 8.0)  # nothing to stream for this item; its reset must still happen
+        eps = torch.as_tensor(rs.normal(size=(B, 9)), dtype=torch.float32, device="cuda")
+        ids = np.sort(rs.choice(B, size=5, replace=False)) if t % 2 == 1 else np.zeros(0, dtype=np.int64)
+        if t == 3 and 5 not in ids:
+            ids = np.sort(np.append(ids[:-1], 5))
+        new_gt = torch.as_tensor(rs.uniform(size=(max(len(ids), 1), cfg.n_cells)), dtype=torch.float32, device="cuda")
+        src = np.full(B, -1, dtype=np.int32)
+        src[ids] = np.arange(len(ids))
+        ra, sa = a_eng.step(acts, prev_a, meas_noise=eps, update_prev=True)
+        if len(ids):
+            a_eng.reset(env_ids=ids.astype(np.int32), gt=new_gt[: len(ids)], prev=prev_a, init_action=INIT)
+        rb, sb = b_eng.step(acts, prev_b, meas_noise=eps, update_prev=True, reset_src=src, reset_gt=new_gt, init_action=INIT)
+        assert torch.equal(sa, sb)
+        assert torch.equal(torch.nan_to_num(ra, nan=-7.0), torch.nan_to_num(rb, nan=-7.0))
+        assert torch.equal(torch.nan_to_num(prev_a, nan=-7.0), torch.nan_to_num(prev_b, nan=-7.0)), t
+        assert torch.equal(a_eng.ranks(), b_eng.ranks()), t
+    for e in range(B):
+        for rd in ("read_mean", "read_diag", "read_gt"):
+            assert torch.equal(getattr(a_eng, rd)(e), getattr(b_eng, rd)(e)), (e, rd)
+    # and the states keep evolving identically afterwards
+    acts = _actions(cfg, rs, B)
+    ra, _ = a_eng.step(acts, prev_a)
+    rb, _ = b_eng.step(acts, prev_b)
+    assert torch.equal(ra, rb)
+
+
+def test_vec_env_fused_resets_equal_separate_resets():
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B, T = 64, 8
+    envs = [VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=12, seed=5, fused_reset=f) for f in (True, False)]
+    assert envs[0]._fused_reset and not envs[1]._fused_reset
+    for env in envs:
+        env.reset()
+    alts = [float(a) for a in range(5, 15)]
+    for t in range(3 * T):
+        acts = cell_centre_actions(cfg, t, 0, B, B, alts)
+        r0, s0 = envs[0].step(acts)
+        r1, s1 = envs[1].step(acts)
+        assert torch.equal(r0, r1), t
+        assert torch.equal(s0, s1)
+        assert torch.equal(envs[0].engine.ranks(), envs[1].engine.ranks()), t
+        assert torch.equal(envs[0].prev, envs[1].prev), t
+    assert np.array_equal(envs[0].episode, envs[1].episode)
+    for e in (0, 7, 63):
+        assert torch.equal(envs[0].mean(e), envs[1].mean(e))
+        assert torch.equal(envs[0].ground_truth(e), envs[1].ground_truth(e))
