@@ -1,6 +1,7 @@
 // C-ABI of the MI355X-native batched IPP environment-step engine (see include/ipp_engine.h).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ipp_engine.hip -o libipp_hip.so
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -240,25 +241,21 @@ void grf_kernel_host(int H, int W, double c, std::vector<double>& h) {
         }
 }
 
-struct ProfScope {
-    Engine* e;
-    int kind;
-    hipStream_t s;
+// Kernel launch; with profiling on (bench.py's roofline leg) the start / stop events are attached to the dispatch
+// itself (hipExtLaunchKernelGGL), so their difference is the kernel's own duration as rocprofv3 reports it, not the
+// interval between two event packets around it (which adds the dispatch latency, 20-25 us on this pool).
+template <typename... P, typename... A>
+void timed_launch(Engine* e, int kind, void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
+    if (!e->profile) {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+        return;
+    }
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(Engine* e_, int kind_, hipStream_t s_) : e(e_), kind(kind_), s(s_) {
-        if (e->profile) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, s);
-        }
-    }
-    ~ProfScope() {
-        if (e->profile) {
-            (void)hipEventRecord(b, s);
-            e->prof[kind].pending.emplace_back(a, b);
-        }
-    }
-};
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, a, b, 0, static_cast<P>(args)...);
+    e->prof[kind].pending.emplace_back(a, b);
+}
 
 void prof_drain(ProfSlot& p) {
     for (auto& pr : p.pending) {
@@ -288,41 +285,33 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                   const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
                   hipEvent_t prep_done, const AutoReset& ar) {
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
-        ProfScope ps(e, 0, s);
-        // persistent grid: no more workgroups than the GPU holds at once, the rest of the items through tickets
-        // persistent grid: no more workgroups than the GPU holds at once, the rest of the items through tickets
-        hipLaunchKernelGGL((k_step_factor<MC, VEC>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev,
-                           noise, flags, e->lut_rows, status, reward, ar);
+        timed_launch(e, 0, k_step_factor<MC, VEC>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev, noise,
+                     flags, e->lut_rows, status, reward, ar);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
     }
-    {
-        ProfScope ps(e, 2, s);
-        if (v.mode == IPP_FACTOR)
-            hipLaunchKernelGGL((k_prepare<MC, IPP_FACTOR>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
-                               action, prev, noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
-        else
-            hipLaunchKernelGGL((k_prepare<MC, IPP_DENSE>), dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n,
-                               action, prev, noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
-    }
+    if (v.mode == IPP_FACTOR)
+        timed_launch(e, 2, k_prepare<MC, IPP_FACTOR>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n, action, prev,
+                     noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
+    else
+        timed_launch(e, 2, k_prepare<MC, IPP_DENSE>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n, action, prev,
+                     noise, flags, status, (float*)nullptr, (int*)nullptr, (int*)nullptr);
     if (prep_done) (void)hipEventRecord(prep_done, s);
     {
-        ProfScope ps(e, 0, s);
         const int grid = grid_for(n, v.n_tiles);
         if (v.mode == IPP_FACTOR && v.window_rows > 0 && v.T == kWave)
-            hipLaunchKernelGGL((k_gain_wave<MC, VEC>), dim3(n), dim3(kWave), e->gain_lds, s, v, v.q, n, flags, reward);
+            timed_launch(e, 0, k_gain_wave<MC, VEC>, dim3(n), dim3(kWave), e->gain_lds, s, v, v.q, n, flags, reward);
         else if (v.mode == IPP_FACTOR && v.window_rows > 0)
-            hipLaunchKernelGGL((k_gain_factor<MC, VEC>), dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_rows, reward);
+            timed_launch(e, 0, k_gain_factor<MC, VEC>, dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_rows, reward);
         else if (v.mode == IPP_FACTOR)
-            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_FACTOR>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
+            timed_launch(e, 0, k_gain<MC, VEC, IPP_FACTOR>, dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
         else
-            hipLaunchKernelGGL((k_gain<MC, VEC, IPP_DENSE>), dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
+            timed_launch(e, 0, k_gain<MC, VEC, IPP_DENSE>, dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
     }
     if (v.n_tiles > 1 && !(v.mode == IPP_FACTOR && v.window_rows > 0)) hipLaunchKernelGGL(k_reward_finalize, dim3((n + 255) / 256), dim3(256), 0, s, v, n, reward);
     if (v.mode == IPP_DENSE && !(flags & IPP_PREDICT_ONLY)) {
-        ProfScope ps(e, 1, s);
         const int grid = grid_for(n, e->n_bands * v.n_tiles);
-        hipLaunchKernelGGL((k_downdate<MC, VEC>), dim3(grid), dim3(v.T), 0, s, v, n, e->n_bands);
+        timed_launch(e, 1, k_downdate<MC, VEC>, dim3(grid), dim3(v.T), 0, s, v, n, e->n_bands);
     }
 }
 

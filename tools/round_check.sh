@@ -19,6 +19,7 @@ grep -v amdgpu.ids $O/extras.txt | tail -12
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o kt -- python3 bench.py --no-cpu-baseline > $O/trace.log 2>&1
 find $O/trace -name "*kernel_stats.csv" | head -2
+python tools/trace_phases.py $O/trace/kt_kernel_trace.csv $O/trace.log > $O/trace_phases.txt 2>&1; cat $O/trace_phases.txt
 bash tools/pmc_run.sh $O/pmc > $O/pmc_run.log 2>&1
 python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json
 # the other bench variants (exact factor mode, one-wave kernel, dense state): FETCH / WRITE passes only
