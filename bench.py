@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--state", choices=["factor", "dense"], default="factor")
     ap.add_argument("--episode-steps", type=int, default=40)
     ap.add_argument("--tile-threads", type=int, default=0)
-    ap.add_argument("--window-rows", type=int, default=12,
-                    help="factor state: keep new columns of U within R grid rows of the footprint (truncated |Wc| < 3e-8 for "
-                         "the example prior, parity-tested at 1e-5); 0 = exact full columns")
+    ap.add_argument("--window-rows", type=int, default=-1,
+                    help="factor state: keep new columns of U within R grid rows of the footprint; -1 = the smallest R for which "
+                         "the dropped prior covariances stay below 1e-6 (ipp_min_window_rows: 10 for the example prior, which the "
+                         "bench never rescales; parity-tested at 1e-5); 0 = exact full columns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=40)

@@ -79,11 +79,16 @@ typedef struct ipp_config {
                                  grid rows within R of its footprint (|Wc| < 3e-8 beyond 12 rows for the example
                                  prior); streamed bytes shrink accordingly and are counted as such.
                                  The dropped entries scale like exp(-sqrt(3) R resolution / length_scale): choose R
-                                 from the prior (12 = 13 length scales for the example config), 0 when in doubt */
+                                 from the prior (12 = 13 length scales for the example config), 0 when in doubt,
+                                 or ask ipp_min_window_rows.  ipp_engine_create refuses an R that drops prior
+                                 covariances above 1e-6 for the largest length scale a reset may install */
     int32_t score_scratch;    /* 1 = reserve the scratch of ipp_score_actions in the arena: band of G = P M P
                                  (N x 190 doubles) and, for IPP_FACTOR, one dense P (N x Npad floats) */
     int32_t node_capacity;    /* tree nodes of ipp_tree_step (each (max_measurements + 1) x Npad floats); 0 = none */
-    int32_t reserved0;
+    int32_t fixed_prior;      /* windowed IPP_FACTOR engines: 1 = no reset installs a length scale above
+                                 cfg.length_scale (no shuffle_prior_cov), 0 = up to 1.2 x (mappings.py:238-240).
+                                 Sets the length scale the window bound is checked for; a reset beyond it
+                                 poisons the env (prior, mean, diag = NaN) instead of losing accuracy silently */
 } ipp_config;
 
 typedef struct ipp_info {
@@ -114,6 +119,13 @@ typedef struct ipp_step_item {
 
 int         ipp_abi_version(void);
 const char* ipp_last_error(void);
+
+/*
+ * Smallest window_rows > 0 ipp_engine_create accepts for `cfg` (prior, resolution, fixed_prior): the smallest R
+ * with  sigma^2 (1 + a) exp(-a) <= 1e-6,  a = sqrt(3) R resolution / l_max.  10 for the example config with
+ * fixed_prior = 1, 12 with the 1.2 x headroom of shuffle_prior_cov.
+ */
+int ipp_min_window_rows(const ipp_config* cfg, int32_t* rows /*[host]*/);
 
 /*
  * Size of the device arena the engine needs for `cfg` (state slabs for `capacity` envs + per-call

@@ -29,7 +29,7 @@ class IppConfig(C.Structure):
         ("value_threshold", C.c_double), ("interval_factor", C.c_double),
         ("cluster_radius", C.c_double),
         ("state_repr", C.c_int32), ("capacity", C.c_int32), ("rank_cap", C.c_int32), ("max_batch", C.c_int32),
-        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("score_scratch", C.c_int32), ("node_capacity", C.c_int32), ("reserved0", C.c_int32),
+        ("max_measurements", C.c_int32), ("tile_threads", C.c_int32), ("window_rows", C.c_int32), ("score_scratch", C.c_int32), ("node_capacity", C.c_int32), ("fixed_prior", C.c_int32),
     ]
 
 
@@ -58,6 +58,7 @@ _P = C.c_void_p
 # name -> (restype, argtypes); exactly the symbols include/ipp_engine.h declares
 PROTOTYPES = {
     "ipp_abi_version": (C.c_int, []),
+    "ipp_min_window_rows": (C.c_int, [_P, _P]),
     "ipp_last_error": (C.c_char_p, []),
     "ipp_engine_arena_bytes": (C.c_int, [C.POINTER(IppConfig), C.POINTER(C.c_uint64)]),
     "ipp_engine_create": (C.c_int, [C.POINTER(IppConfig), C.c_int, _P, C.c_uint64, C.POINTER(_P)]),

@@ -110,6 +110,7 @@ struct View {
     int meas_cap, fp_cap, q_stride, q_rows;
     uint64_t q_item;  // floats of Q scratch per item: (q_rows + 2*kPipe pad rows) * q_stride
     double res, tanx, tany, rf_alt, coeff_a, coeff_b, sv0, ls0, vmax, amax, thr, kf;
+    double ls_max;   // windowed factor state: largest length scale the window is good for (0: no limit)
     // state slabs
     float* mean;     // [cap][Npad]
     float* diag;     // [cap][Npad]

@@ -94,6 +94,20 @@ uint64_t q_item_floats(const Layout& L) {
     return (lq + (uint64_t)(L.q_rows + 8) * L.QS + 15) & ~(uint64_t)15;
 }
 
+// Windowed factor columns: the largest length scale a reset may install and the prior covariance dropped at the
+// window edge for it (Matern 3/2 at R rows).
+constexpr double kWindowBound = 1e-6;
+double max_length_scale(const ipp_config& c) { return (c.fixed_prior ? 1.0 : 1.2) * c.length_scale; }
+double window_bound(const ipp_config& c, int rows) {
+    const double a = std::sqrt(3.0) * (double)rows * c.resolution / max_length_scale(c);
+    return c.signal_variance * (1.0 + a) * std::exp(-a);
+}
+int min_window_rows(const ipp_config& c) {
+    int r = 1;
+    while (r < (1 << 20) && window_bound(c, r) > kWindowBound) ++r;
+    return r;
+}
+
 int plan(const ipp_config& c, Layout& L) {
     if (c.x_dim <= 0 || c.y_dim <= 0) return fail(-1, "x_dim/y_dim must be positive");
     if (!(c.resolution > 0)) return fail(-1, "resolution must be positive");
@@ -130,13 +144,11 @@ int plan(const ipp_config& c, Layout& L) {
     if (c.state_repr == IPP_FACTOR && c.window_rows > 0) {
         // the columns are cut where the prior covariance to the footprint has decayed: refuse windows that are too
         // narrow for this prior (length scale up to 1.2 x nominal under shuffle_prior_cov, mappings.py:238-240)
-        const double d = (double)c.window_rows * c.resolution, ls = 1.2 * c.length_scale;
-        const double a = std::sqrt(3.0) * d / ls;
-        const double bound = c.signal_variance * (1.0 + a) * std::exp(-a);
-        if (c.window_rows < std::max(c.x_dim, c.y_dim) && bound > 1e-6)
-            return fail(-1, "window_rows = %d drops prior covariances up to %.1e (> 1e-6) for length_scale %.3g m at %.3g m cells: "
-                            "use window_rows >= %d, or 0 for exact columns", c.window_rows, bound, c.length_scale, c.resolution,
-                        (int)std::ceil(19.0 * ls / (std::sqrt(3.0) * c.resolution)));
+        const double bound = window_bound(c, c.window_rows);
+        if (c.window_rows < std::max(c.x_dim, c.y_dim) && bound > kWindowBound)
+            return fail(-1, "window_rows = %d drops prior covariances up to %.1e (> 1e-6) for length scales up to %.3g m at %.3g m cells: "
+                            "use window_rows >= %d, or 0 for exact columns", c.window_rows, bound, max_length_scale(c), c.resolution,
+                        min_window_rows(c));
         // windowed factor state: one workgroup per item, wave-granular tiles of 64 * VEC cells (k_gain_factor.h);
         // tile_threads is the workgroup size (waves share the item's Q block and prior table in LDS)
         L.T = (c.tile_threads > 0) ? c.tile_threads : 256;  // 256: fused workgroup kernel (k_step_factor.h), 64: one wave per item (k_gain_wave.h)
@@ -441,6 +453,13 @@ extern "C" {
 int ipp_abi_version(void) { return IPP_ABI_VERSION; }
 const char* ipp_last_error(void) { return g_err.c_str(); }
 
+int ipp_min_window_rows(const ipp_config* cfg, int32_t* rows) {
+    if (!cfg || !rows) return fail(-1, "null argument");
+    if (!(cfg->resolution > 0) || !(cfg->length_scale > 0) || !(cfg->signal_variance > 0)) return fail(-1, "resolution, length_scale and signal_variance must be positive");
+    *rows = min_window_rows(*cfg);
+    return 0;
+}
+
 int ipp_engine_arena_bytes(const ipp_config* cfg, uint64_t* bytes) {
     if (!cfg || !bytes) return fail(-1, "null argument");
     Layout L;
@@ -467,6 +486,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.meas_cap = L.MC; v.fp_cap = L.FC; v.q_stride = L.QS; v.q_rows = L.q_rows; v.q_item = q_item_floats(L);
     v.res = cfg->resolution; v.tanx = cfg->tan_half_fov_x; v.tany = cfg->tan_half_fov_y; v.rf_alt = cfg->rf_altitude;
     v.coeff_a = cfg->coeff_a; v.coeff_b = cfg->coeff_b; v.sv0 = cfg->signal_variance; v.ls0 = cfg->length_scale;
+    v.ls_max = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0 && cfg->window_rows < std::max(cfg->x_dim, cfg->y_dim)) ? max_length_scale(*cfg) : 0.0;
     v.vmax = cfg->max_v; v.amax = cfg->max_a; v.thr = cfg->value_threshold; v.kf = cfg->interval_factor;
     char* base = reinterpret_cast<char*>(arena);
     v.mean = reinterpret_cast<float*>(base + L.off_mean);

@@ -15,8 +15,10 @@ __global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_ite
     if (item >= n_items) return;
     const int env = env_ids ? env_ids[item] : item;
     if (env < 0 || env >= v.cap) return;
-    const double sv = prior_scale ? prior_scale[2 * item + 0] : v.sv0;
-    const double ls = prior_scale ? prior_scale[2 * item + 1] : v.ls0;
+    double sv = prior_scale ? prior_scale[2 * item + 0] : v.sv0;
+    double ls = prior_scale ? prior_scale[2 * item + 1] : v.ls0;
+    // a length scale the column window was not sized for (ipp_config.fixed_prior): fail loudly, not inaccurately
+    if (v.ls_max > 0.0 && ls > v.ls_max * (1.0 + 1e-12)) sv = ls = NAN;
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell == 0) {
         v.rank[env] = 0;
@@ -27,7 +29,7 @@ __global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_ite
     }
     if (cell >= v.Npad) return;
     const bool valid = cell < v.N;
-    v.mean[(size_t)env * v.Npad + cell] = valid ? 0.5f : 0.f;
+    v.mean[(size_t)env * v.Npad + cell] = valid ? (isnan(sv) ? NAN : 0.5f) : 0.f;
     v.diag[(size_t)env * v.Npad + cell] = valid ? (float)sv : 0.f;
     if (gt_in) v.gt[(size_t)env * v.Npad + cell] = valid ? gt_in[(size_t)item * v.N + cell] : 0.f;
 }

@@ -70,7 +70,11 @@ class IPPEngine:
 
     def __init__(self, cfg: EngineConfig, capacity: int, state: str = "factor", rank_cap: int = 360,
                  max_batch: Optional[int] = None, device: str = "cuda:0", max_measurements: int = 9,
-                 tile_threads: int = 0, window_rows: int = 0, score_scratch: bool = False, node_capacity: int = 0):
+                 tile_threads: int = 0, window_rows: int = 0, score_scratch: bool = False, node_capacity: int = 0,
+                 fixed_prior: bool = False):
+        """window_rows: 0 = exact columns, R > 0 = columns kept within R grid rows of their footprint, -1 = the smallest
+        R the engine accepts for this prior (ipp_min_window_rows).  fixed_prior: no reset will install a length scale above
+        cfg.length_scale (no shuffle_prior_cov), which lets the window be 10 instead of 12 rows for the example config."""
         torch = _torch()
         self._lib = _ffi.load()
         if not torch.cuda.is_available():
@@ -96,7 +100,15 @@ class IPPEngine:
             raise ValueError("state must be 'factor' or 'dense'")
         c.capacity, c.rank_cap, c.max_batch = self.capacity, int(rank_cap), self.max_batch
         c.max_measurements, c.tile_threads = int(max_measurements), int(tile_threads)
+        c.fixed_prior = 1 if fixed_prior else 0
         c.window_rows = int(window_rows)
+        if c.window_rows < 0:
+            if state != "factor":
+                c.window_rows = 0
+            else:
+                rows = C.c_int32(0)
+                _ffi.check(self._lib.ipp_min_window_rows(C.byref(c), C.byref(rows)))
+                c.window_rows = int(rows.value)
         c.score_scratch = 1 if score_scratch else 0
         c.node_capacity = int(node_capacity)
         self._c = c

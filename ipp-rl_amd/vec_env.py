@@ -67,7 +67,7 @@ class VecIPPEnv:
         self.adaptive, self.use_flight_time = adaptive, use_flight_time
         rank_cap = int(rank_cap) if rank_cap else 9 * self.episode_steps
         self.engine = IPPEngine(cfg, capacity=self.num_envs, state=state, rank_cap=rank_cap, device=device,
-                                tile_threads=tile_threads, window_rows=window_rows)
+                                tile_threads=tile_threads, window_rows=window_rows, fixed_prior=not shuffle_prior_cov)
         dev = self.engine.device
         self.device = dev
         B = self.num_envs

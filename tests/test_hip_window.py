@@ -147,3 +147,38 @@ def test_window_too_narrow_for_the_prior_is_refused():
         IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, max_measurements=25, window_rows=12)
     IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, max_measurements=25, window_rows=0).close()
     IPPEngine(cfg, capacity=2, state="factor", rank_cap=64, max_measurements=25, window_rows=100).close()  # >= grid: exact
+
+
+def test_min_window_rows_follow_the_prior_headroom(golden):
+    """ipp_min_window_rows: 12 rows with the 1.2 x length-scale headroom of shuffle_prior_cov, 10 when the caller
+    promises a fixed prior; the narrower window is refused without that promise, meets the parity bar with it, and a
+    reset that breaks the promise poisons the env instead of losing accuracy silently."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd._ffi import IppError
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    with pytest.raises(IppError, match="window_rows"):
+        IPPEngine(cfg, capacity=2, state="factor", rank_cap=360, window_rows=10)
+    assert IPPEngine(cfg, capacity=2, state="factor", rank_cap=360, window_rows=-1).info.window_rows == 12
+    eng = IPPEngine(cfg, capacity=2, state="factor", rank_cap=360, window_rows=-1, fixed_prior=True)
+    assert eng.info.window_rows == 10
+    for name in ("episode_rf1_50_s0", "episode_mixed_50_s1"):
+        g = golden(name)
+        eng.reset(env_ids=[0], white_noise=g["white"][None])
+        prev = np.array([2.0, 2.0, 14.0])
+        worst = 0.0
+        for t, a in enumerate(g["actions"]):
+            reward, status = eng.step(a[None], prev[None], env_ids=[0], meas_noise=g["eps"][t][None])
+            assert int(status[0]) == 0
+            worst = max(worst, abs(float(reward[0]) - g["reward"][t]), np.max(np.abs(host(eng.read_mean(0)) - g["mean"][t])),
+                        np.max(np.abs(host(eng.read_diag(0)) - g["diag"][t])))
+            prev = a
+        err_rows = np.max(np.abs(host(eng.read_cov(0))[g["sample_rows"]] - g["P_final_rows"]))
+        print(f"[window 10, fixed prior, {name}] worst reward/mean/diag error {worst:.2e}, P rows {err_rows:.2e}")
+        assert worst < TOL and err_rows < TOL
+    ok = np.array([[cfg.signal_variance * 1.1, cfg.length_scale * 0.9]])
+    eng.reset(env_ids=[1], prior_scale=ok, gt=np.zeros((1, 50, 50)))
+    assert np.isfinite(host(eng.read_diag(1))).all()
+    too_long = np.array([[cfg.signal_variance, cfg.length_scale * 1.1]])
+    eng.reset(env_ids=[1], prior_scale=too_long, gt=np.zeros((1, 50, 50)))
+    assert np.isnan(host(eng.read_diag(1))).all() and np.isnan(host(eng.read_mean(1))).all()
