@@ -112,6 +112,13 @@ def load():
             f"HIP engine library not found at {LIB_PATH}: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # The engine shares the HIP runtime of the process with PyTorch (device memory, streams).  PyTorch's wheel carries
+    # its own libamdhip64: it has to be the first HIP runtime the process loads, otherwise the engine binds to
+    # /opt/rocm's copy and the process ends up with two runtimes, one of which sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # symbol checks on a machine without torch
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         try:
