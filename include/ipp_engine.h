@@ -102,6 +102,7 @@ typedef struct ipp_info {
     int32_t window_rows;
     uint64_t arena_bytes;     /* total bytes the engine carves from the caller's arena */
     uint64_t cov_slot_bytes;  /* bytes of covariance state per env slot */
+    uint64_t step_lds_bytes;  /* dynamic LDS per workgroup of the streaming step kernel (occupancy: 160 KiB per CU) */
 } ipp_info;
 
 /* Debug / test view of the last ipp_step's per-item prologue (host struct, filled by ipp_debug_step_item). */

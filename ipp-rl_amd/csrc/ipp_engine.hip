@@ -646,6 +646,7 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     out->window_rows = e->v.window_rows;
     out->arena_bytes = e->used_bytes;
     out->cov_slot_bytes = e->v.cov_slot * 4;
+    out->step_lds_bytes = e->gain_lds;
     return 0;
 }
 
