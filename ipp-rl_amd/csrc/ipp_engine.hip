@@ -409,16 +409,20 @@ int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* 
     if (e->grf_dft) {  // even n <= 256: half-spectrum DFT, normalisation fused (k_grf_dft.h)
         const bool small = v.W <= 100;
         const int nt = small ? 256 : 1024;
-        const int rows = (v.W + (nt / v.W) - 1) / (nt / v.W);
+        const int xb = (v.W % 4 == 0) ? 4 : 2;                 // columns per thread in the row-inverse stage
+        const int rgroups = std::max(1, nt / (v.W / xb));      // row groups
+        const int rows = (v.W + rgroups - 1) / rgroups;        // rows per thread
         const size_t lds = grf_dft_lds_bytes(v.W, e->grf_kc, small);
-        if (small && rows <= 10)
-            hipLaunchKernelGGL((k_grf_dft<10, 256, true>), dim3(n), dim3(256), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
-        else if (small)
-            hipLaunchKernelGGL((k_grf_dft<50, 256, true>), dim3(n), dim3(256), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
-        else if (rows <= 44)
-            hipLaunchKernelGGL((k_grf_dft<44, 1024, false>), dim3(n), dim3(1024), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
-        else
-            hipLaunchKernelGGL((k_grf_dft<64, 1024, false>), dim3(n), dim3(1024), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out);
+#define IPP_GRF_LAUNCH(OPT, XB, NT, WLDS) \
+    hipLaunchKernelGGL((k_grf_dft<OPT, XB, NT, WLDS>), dim3(n), dim3(NT), lds, s, v, env_ids, n, white, v.grf_cs, v.grf_g, e->grf_kc, gt_out)
+        if (small && xb == 4) IPP_GRF_LAUNCH(10, 4, 256, true);        // rows <= 10 for every n <= 100
+        else if (small && rows <= 10) IPP_GRF_LAUNCH(10, 2, 256, true);
+        else if (small) IPP_GRF_LAUNCH(20, 2, 256, true);              // n = 54 .. 98, n = 2 mod 4
+        else if (xb == 4 && rows <= 10) IPP_GRF_LAUNCH(10, 4, 1024, false);   // n <= 200
+        else if (xb == 4) IPP_GRF_LAUNCH(16, 4, 1024, false);                 // n <= 256
+        else if (rows <= 20) IPP_GRF_LAUNCH(20, 2, 1024, false);              // n <= 202
+        else IPP_GRF_LAUNCH(32, 2, 1024, false);                              // n <= 256
+#undef IPP_GRF_LAUNCH
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -76,9 +76,10 @@ def test_factor_step_vs_oracle_factor_form(dim, window_rows, tile_threads):
     print(f"[{dim}x{dim}, window {window_rows}, T={tile_threads}] worst reward error {worst:.2e}")
 
 
-@pytest.mark.parametrize("n", [10, 36, 50, 64, 100, 120, 200, 256, 258, 15])
+@pytest.mark.parametrize("n", [10, 36, 50, 64, 74, 98, 100, 120, 150, 200, 254, 256, 258, 15])
 def test_grf_sizes_vs_oracle(n):
-    """Even n <= 256: half-spectrum DFT kernel (256 threads up to n = 100, 1024 threads above); n = 258 and odd n (the
+    """Even n <= 256: half-spectrum DFT kernel (256 threads up to n = 100, 1024 threads above; 2 or 4 columns per thread:
+    the list covers every instantiation); n = 258 and odd n (the
     reference's amplitude table loses its last row / column there, ground_truths.py:8-11): circular-convolution
     kernel.  All against numpy's FFT path."""
     from ipp_rl_amd import EngineConfig, IPPEngine
