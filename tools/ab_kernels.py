@@ -74,6 +74,20 @@ def main():
                 z[0::2] = perm[:half]
                 z[1::2] = perm.flip(0)[: B - half]
                 perm = z
+            elif mode.startswith("spread"):  # heaviest 1/k at the head of each of the 16 ranges of the XCD map, rest natural
+                k = int(mode[6:] or 16)
+                nh = B // k
+                head = perm[:nh]
+                keep = torch.ones(B, dtype=torch.bool, device=perm.device)
+                keep[head] = False
+                rest = torch.nonzero(keep).flatten()
+                ln = B // 16
+                hp, rp = nh // 16, ln - nh // 16
+                parts = []
+                for q in range(16):
+                    parts.append(head[q * hp:(q + 1) * hp])
+                    parts.append(rest[q * rp:(q + 1) * rp])
+                perm = torch.cat(parts)
             elif mode.startswith("head"):  # "head<k>[tail<j>]": heaviest 1/k first, lightest 1/j last, the rest natural
                 k, _, j = mode[4:].partition("tail")
                 head = perm[: B // int(k)]
