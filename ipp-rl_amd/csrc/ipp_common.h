@@ -39,7 +39,6 @@ constexpr int kWave = 64;          // CDNA wavefront
 #endif
 constexpr int kPrepThreads = IPP_PREP_THREADS;  // prologue workgroup
 constexpr int kMaxTileThreads = 640;
-constexpr int kQChunk = 128;       // rows of Q staged in LDS per pass of the streaming loop
 constexpr int kBandRows = 20;      // rows of P per dense-downdate workgroup
 constexpr double kSqrt3 = 1.7320508075688772;
 

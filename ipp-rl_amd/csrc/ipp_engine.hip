@@ -533,8 +533,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     }
     e->n_bands = (L.N + kBandRows - 1) / kBandRows;
     e->prep_lds = prep_lds_bytes(L, *cfg);
-    e->q_chunk = std::min(1024, (L.q_rows + 2 * kPipe - 1) / (2 * kPipe) * (2 * kPipe));
-    if (const char* qc = getenv("IPP_QCHUNK")) e->q_chunk = std::max(2 * kPipe, atoi(qc) / (2 * kPipe) * (2 * kPipe));  // A/B experiments
+    e->q_chunk = 2 * kPipe;  // (k_gain reads Q through the scalar cache: the LDS area only holds the prior table)
     // prior table of the factor base term lives in LDS when the grid is small enough (<= 48 KiB)
     e->lut_cap = (v.mode == IPP_FACTOR && L.N <= 12288) ? L.N : 0;
     e->gain_lds = gain_lds_bytes(v, e->q_chunk, e->lut_cap);

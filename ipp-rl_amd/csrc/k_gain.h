@@ -83,44 +83,46 @@ __device__ __forceinline__ void store_stream(float* p, const float (&o)[VEC]) {
 #endif
 }
 
-// acc[c][j] += sum_k row_k[cell0 + c] * Q[k][j] over the `cnt` rows whose Q is staged in Qs (the prologue
-// stores Q with the sign of the update folded in).
-// rowidx (LDS) maps the streaming index to the row of the covariance slab (dense: footprint cell of P;
-// factor: the columns of U stored on this tile).
+// acc[c][j] += sum_k row_k[cell0 + c] * Q[k][j] over the item's streaming rows (the prologue stores Q with the sign
+// of the update folded in).  rowidx (LDS) maps the streaming index to the row of the covariance slab (dense:
+// footprint cell of P; factor: the columns of U stored on this tile).
+// The Q rows are read straight from the item's global block through the constant address space
+// (scalar loads: wave-uniform address, written by the prologue kernel before this launch): no LDS staging, no
+// barriers in the loop, and with Q out of the vector registers the request groups hold G = 8 rows instead of 4.
+// zero_row: index of the first of the >= 8 zero rows behind the item's Q rows (k_prepare.h).
+#ifndef IPP_GAIN_GROUP_SQ
+#define IPP_GAIN_GROUP_SQ 8
+#endif
 template <int MC, int VEC, int MODE>
-__device__ __forceinline__ void stream_rows(const float* __restrict__ cov_src,
-                                            const int* rowidx, int k0, int cnt, int last_row, size_t npad, int cell0,
-                                            const float* Qs, float (&acc)[VEC][MC]) {
+__device__ __forceinline__ void stream_rows_sq(const float* __restrict__ cov_src, const int* rowidx, int rows, size_t npad,
+                                               int cell0, const float* qrows, int zero_row, float (&acc)[VEC][MC]) {
     constexpr int QS = (MC + 3) & ~3;
-    // the row base is wave-uniform (SGPR pair); only the 32-bit cell offset is per lane
-    auto row_base = [&](int k) -> size_t {
-        const int kc = min(k, last_row);  // rows past the end re-read the last row against a zero Q row
-        return (size_t)__builtin_amdgcn_readfirstlane(rowidx[kc]) * npad;
-    };
-    // groups of G rows requested together, then consumed; nothing loaded is carried over the back edge
-    // (hipcc turns a carried group into register copies that each wait for their load, see k_gain_wave.h)
-    constexpr int G = IPP_GAIN_GROUP;
-    static_assert(G <= 2 * kPipe, "zero Q rows after the staged chunk cover 2*kPipe rows");
+    constexpr int G = IPP_GAIN_GROUP_SQ;
+    static_assert(G <= 8, "the prologue keeps 8 zero rows behind Q");
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    cfloat_p qc0 = (cfloat_p)(const void*)qrows;
     typedef float rowv __attribute__((ext_vector_type(VEC)));
-    for (int kk = 0; kk < cnt; kk += G) {
+    for (int kk = 0; kk < rows; kk += G) {
         rowv u[G];
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-            u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + row_base(k0 + kk + i) + cell0));
-        __builtin_amdgcn_sched_barrier(0);
+        int qk[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            float qv[QS];
+            const int sidx = kk + i;
+            const int ri = __builtin_amdgcn_readfirstlane(rowidx[min(sidx, rows - 1)]);  // rows past the end: last row x zero Q
+            u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(cov_src + (size_t)ri * npad + cell0));
+            qk[i] = sidx < rows ? (MODE == IPP_DENSE ? sidx : ri) : zero_row;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all G requests leave before the first wait
 #pragma unroll
-            for (int t4 = 0; t4 < QS / 4; ++t4) {
-                const float4 q4 = *reinterpret_cast<const float4*>(&Qs[(kk + i) * QS + 4 * t4]);
-                qv[4 * t4 + 0] = q4.x; qv[4 * t4 + 1] = q4.y; qv[4 * t4 + 2] = q4.z; qv[4 * t4 + 3] = q4.w;
-            }
+        for (int i = 0; i < G; ++i) {
+            cfloat_p qc = qc0 + (size_t)qk[i] * QS;
+            float qv[MC];
+#pragma unroll
+            for (int j = 0; j < MC; ++j) qv[j] = qc[j];
 #pragma unroll
             for (int j = 0; j < MC; ++j)
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(u[i][c], qv[j], acc[c][j]);
-            if (i & 1) __builtin_amdgcn_sched_barrier(0);  // at most two Q rows in registers
         }
     }
 }
@@ -239,27 +241,8 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
     }
 
     // ------------------------------------------------------------------ streaming loop
-    for (int k0 = 0; k0 < rows; k0 += q_chunk) {
-        const int cnt = min(q_chunk, rows - k0);
-        if (k0 > 0) __syncthreads();
-        {
-            float4* dst = reinterpret_cast<float4*>(Qs);
-            constexpr int Q4 = QS / 4;
-            const int n4 = cnt * Q4, tot4 = (cnt + 2 * kPipe) * Q4;
-            for (int i = tid; i < tot4; i += T) {
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < n4) {
-                    const int a = i / Q4, part = i - a * Q4;
-                    // dense: Q rows are already in streaming order; factor: row of the a-th stored column
-                    const int qrow = (MODE == IPP_DENSE) ? (k0 + a) : rowidx[k0 + a];
-                    val = *reinterpret_cast<const float4*>(qg + (size_t)qrow * QS + 4 * part);
-                }
-                dst[i] = val;
-            }
-        }
-        __syncthreads();
-        stream_rows<MC, VEC, MODE>(cov_src, rowidx, k0, cnt, rows - 1, (size_t)v.Npad, cell0, Qs, acc);
-    }
+    if (rows > 0)
+        stream_rows_sq<MC, VEC, MODE>(cov_src, rowidx, rows, (size_t)v.Npad, cell0, qg, (MODE == IPP_DENSE) ? h.f : h.rank, acc);
 
     // ------------------------------------------------------------------ epilogue
     float mean_in[VEC], diag_in[VEC];
