@@ -359,3 +359,36 @@ def test_vec_env_shuffled_priors_vs_oracle():
     reward, _ = env.step(acts, auto_reset=False)
     want = orc.predict_step(ocfg, P, prev, acts[e], {"max_v": 2.0, "max_a": 2.0}, info)[0]
     assert abs(float(reward[e]) - want) < TOL
+
+
+def test_fullsize_windowed_fused_path_tracks_the_exact_mode():
+    """BASELINE configs[1] at full size (4096 envs, 50x50, staggered 40-step episodes with their resets): the bench's
+    default path (fixed prior -> window 10, fused kernel, ground truths staged on the side stream) against the exact
+    factor mode (full columns, k_prepare + k_gain) step by step: rewards within 1e-5, and mean / diag of sampled envs at
+    the end.  Same seeds, so both see the same ground truths and measurement noise."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B, T, steps = 4096, 40, 50
+    fast = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=77)
+    exact = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=0, seed=77)
+    assert fast.engine.info.window_rows == 10 and exact.engine.info.window_rows == 0
+    fast.reset()
+    exact.reset()
+    alts = [float(a) for a in range(5, 15)]
+    worst = 0.0
+    for t in range(steps):
+        acts = torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, alts)).cuda()
+        r0, s0 = fast.step(acts)
+        r1, s1 = exact.step(acts)
+        assert int(s0.abs().sum()) == 0 and int(s1.abs().sum()) == 0
+        worst = max(worst, float((r0.double() - r1.double()).abs().max()))
+        assert torch.equal(fast.engine.ranks(), exact.engine.ranks()), t
+    print(f"[4096 envs, {steps} steps] worst |reward(window 10, fused) - reward(exact)| = {worst:.2e}")
+    assert worst < 1e-5
+    for e in (0, 1, 39, 40, 2047, 4095):
+        assert float((fast.mean(e).double() - exact.mean(e).double()).abs().max()) < 1e-5
+        assert float((fast.diag(e).double() - exact.diag(e).double()).abs().max()) < 1e-5
+        assert torch.equal(fast.ground_truth(e), exact.ground_truth(e))
