@@ -12,7 +12,7 @@ Parity status: PINNED for everything except the rf=2 ``INTER_AREA`` downsample
 nor installed in this image, so ``area_resize`` restates OpenCV's published
 ``computeResizeAreaTab`` algorithm and is "parity unpinned".  Every other
 function below was checked against outputs of the imported reference
-(``tools/gen_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``).
+(``tests/golden/gen_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``).
 
 All ``file:line`` citations are relative to the reference repository root.
 Conventions: grid is H x W (H = y_dim rows, W = x_dim cols), N = H*W, flat cell

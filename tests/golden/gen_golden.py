@@ -14,14 +14,14 @@ restatement of INTER_AREA (oracle.ipp_oracle.area_resize); therefore every
 fixture value that passed through it (rf=2 observations ``z`` and anything
 downstream of them) is tagged ``unpinned_*`` -- it pins nothing about OpenCV.
 
-Usage:  python tools/gen_golden.py        (writes tests/golden/*.npz)
+Usage:  python tests/golden/gen_golden.py        (writes tests/golden/*.npz)
 """
 import os
 import sys
 import types
 
 REF = "/root/reference"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "tests", "golden")
 
 if not os.path.isdir(REF):
@@ -482,7 +482,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     print("writing golden vectors to", OUT)
     only = sys.argv[1:]
-    if only:  # e.g. `python tools/gen_golden.py features`: regenerate the named fixtures only
+    if only:  # e.g. `python tests/golden/gen_golden.py features`: regenerate the named fixtures only
         for name in only:
             globals()["gen_" + name]()
         return

@@ -1,6 +1,6 @@
 """
 Pins the CPU oracle (oracle/ipp_oracle.py) against golden vectors recorded from the imported
-reference (tools/gen_golden.py).  fp64 vs fp64: tolerances are round-off only (<= 1e-12).
+reference (tests/golden/gen_golden.py).  fp64 vs fp64: tolerances are round-off only (<= 1e-12).
 """
 import numpy as np
 import pytest
