@@ -196,11 +196,15 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             const int trow0 = (tile * kWaveTile) / v.W, trow1 = min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
             const int dmax = max(max(abs(trow0 - h.yu), abs(trow0 - h.yd)), max(abs(trow1 - h.yu), abs(trow1 - h.yd)));
             const bool tile_lut = dmax < lut_rows;
+            // rf = 1 (altitude <= rf_altitude): every measurement block is one cell, the other three table entries
+            // carry weight 0: skip them (wave-uniform)
+            const int n_fc = (h.rf == 1) ? 1 : 4;
             auto block_term = [&](int b, float (&cb)[VEC]) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
+                    if (a >= n_fc) break;
                     const int yx = fb_yx[4 * b + a];
                     const float wa = fb_w[4 * b + a];
                     const int fy = yx >> 16, fx = yx & 0xffff;
