@@ -119,7 +119,16 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
         const int k = idx / QS, i = idx - k * QS;
         qrows_w[idx] = (k < h.rank && i < h.m) ? -lds.work[idx] : 0.f;
     }
+    // The rows are read back through the scalar cache, i.e. from L2, not through the vector L1 the stores went
+    // through.  __syncthreads() alone does not order that: at workgroup scope hipcc emits no vmcnt wait for global
+    // stores on gfx950 (the waves of a workgroup share their vector L1, so the memory model needs none), and a scalar
+    // load behind the barrier can reach L2 before a store that is still on its way: one wrong env in ~10^5 item steps
+    // at 4096 envs (tests/test_hip_edge_cases.py, full-size fused-vs-exact test).  So: every wave waits for its own
+    // stores to be acknowledged, then the barrier, then any line of this block left in the (non-coherent) scalar
+    // cache by an earlier launch is dropped.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
     if (tid < kWave) {
         const int status = solve_wave<MC>(v, h, item, flags_eff, lds.small, lds.work, lds.Ls, lds.ys, status_out);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
