@@ -371,7 +371,7 @@ def test_fullsize_windowed_fused_path_tracks_the_exact_mode():
     from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
 
     cfg = EngineConfig(x_dim=50, y_dim=50)
-    B, T, steps = 4096, 40, 50
+    B, T, steps = 4096, 40, 160  # (long enough to have caught the 1-in-10^5 race of the scalar read-back)
     fast = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=77)
     exact = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=0, seed=77)
     assert fast.engine.info.window_rows == 10 and exact.engine.info.window_rows == 0
