@@ -43,10 +43,12 @@ def main():
     reward = torch.empty(B, dtype=torch.float32, device="cuda")
     status = torch.empty(B, dtype=torch.int32, device="cuda")
 
-    def one_wave():
+    def one_wave(keep=None):
         p = prev
         for d in range(Dp):
             eng.tree_step(roots, paths[d], acts[d], p, new_ids=new_ids[d], reward_out=reward, status_out=status)
+            if keep is not None:
+                keep.append(reward.clone())
             p = acts[d]
 
     one_wave(); torch.cuda.synchronize()
@@ -56,6 +58,15 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.reps * 1e3
     assert int(status.abs().sum()) == 0
+    # the same wave again and again must give the same bits (a data race in the kernel would not): 40 waves
+    ref = []
+    one_wave(ref)
+    mismatches = 0
+    for _ in range(40):
+        got = []
+        one_wave(got)
+        mismatches += sum(int((a != b).sum()) for a, b in zip(ref, got))
+    assert mismatches == 0, f"{mismatches} rewards differ between identical simulation waves"
     print(f"[{args.grid}x{args.grid}, {B} roots, root rank {float(eng.ranks().float().mean()):.0f}, depth {Dp}] "
           f"{ms:.3f} ms per simulation wave = {B * Dp / ms * 1e3:.3e} tree steps/s ({ms / Dp:.3f} ms per level)")
 
