@@ -75,7 +75,7 @@ def test_vec_env_fused_resets_equal_separate_resets():
     from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
 
     cfg = EngineConfig(x_dim=50, y_dim=50)
-    B, T = 64, 8
+    B, T = 4096, 8  # full-size batch: races show at this scale, not at 64 envs
     envs = [VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=12, seed=5, fused_reset=f) for f in (True, False)]
     assert envs[0]._fused_reset and not envs[1]._fused_reset
     for env in envs:
