@@ -145,6 +145,9 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
     const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int m = h.m;
     const int T = blockDim.x;
+    // Q is read through the scalar cache, which is not coherent: drop whatever an earlier launch left of this
+    // item's block (same address every step) before the first read
+    __builtin_amdgcn_s_dcache_inv();
 
     if (m == 0 || h.status == IPP_STATUS_NOT_PD) {
         if (tid == 0) {

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;
+    __builtin_amdgcn_s_dcache_inv();  // (Q through the non-coherent scalar cache: nothing of an earlier launch may be served)
     const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int r = h.rank;
     if (h.m == 0 || h.status == IPP_STATUS_NOT_PD) {

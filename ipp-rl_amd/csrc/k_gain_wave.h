@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int lane = threadIdx.x;
+    __builtin_amdgcn_s_dcache_inv();  // (Q through the non-coherent scalar cache: nothing of an earlier launch may be served)
     const ItemHdr h = uniform_hdr(v.hdr[item]);
     const int m = h.m, r = h.rank;
     if (m == 0 || h.status == IPP_STATUS_NOT_PD) {
