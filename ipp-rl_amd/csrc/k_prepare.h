@@ -318,7 +318,11 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                     }
                 }
             }
-            const double eps = (double)eps_ld;
+            // (the conversion is pinned here: hipcc otherwise moves it up into the predicated block of the load and
+            // waits for the load there, a full memory round trip in front of every other request of the prologue)
+            float eps_f = eps_ld;
+            asm volatile("" : "+v"(eps_f));
+            const double eps = (double)eps_f;
             if (flags & IPP_GIVEN_OBSERVATION)
                 val = eps;  // caller supplies z (update_grid_map(pos, z), mappings.py:114-121)
             else
