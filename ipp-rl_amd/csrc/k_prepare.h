@@ -255,15 +255,31 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     }
     const int gcnt = gb.count();
     const float gw = (float)gb.weight;
+    // All requests of a pass leave before the first is waited for.  A column is requested only where it is stored
+    // (its tile span; about 40 % of the columns cover a given footprint), and rf = 1 items (one cell per block,
+    // wave-uniform) request only that cell.  Written as "test, load, add" per cell, hipcc waits for every load
+    // before it issues the next one: 12 .. 36 dependent round trips per pass.
+    const bool one_cell = (h.rf == 1);
     auto gather_rows = [&](int k0, const int (&sp)[UN], float (&sacc)[UN]) {
+        float l[UN][4];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = min(k0 + u * KS, r - 1);
             const float* row = CHAIN ? cc->row(k) : cov_env + (size_t)k * v.Npad;
             const int lo = sp[u] & 0xffff, hi = sp[u] >> 16;
-            float t = (gtile[0] >= lo && gtile[0] <= hi) ? row[gc[0]] : 0.f;
-            if (gcnt > 1) t += (gtile[1] >= lo && gtile[1] <= hi) ? row[gc[1]] : 0.f;
-            if (gcnt > 2) t += ((gtile[2] >= lo && gtile[2] <= hi) ? row[gc[2]] : 0.f) + ((gtile[3] >= lo && gtile[3] <= hi) ? row[gc[3]] : 0.f);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                l[u][a] = 0.f;
+                if (a == 0 || (!one_cell && a < gcnt))
+                    if (gtile[a] >= lo && gtile[a] <= hi) l[u][a] = row[gc[a]];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float t = l[u][0];
+            if (gcnt > 1) t += l[u][1];
+            if (gcnt > 2) t += l[u][2] + l[u][3];
             sacc[u] = t;
         }
     };
