@@ -25,8 +25,8 @@
 #endif
 #if IPP_TIMELINE
 constexpr int kTimelineItems = 65536;
-__device__ unsigned long long g_timeline[4 * kTimelineItems];
-#define IPP_MARK(item, k) do { if ((item) < kTimelineItems) g_timeline[4 * (item) + (k)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_timeline[8 * kTimelineItems];  // per item: start, end of phase A, end, header done, observation done, gather done
+#define IPP_MARK(item, k) do { if ((item) < kTimelineItems) g_timeline[8 * (item) + (k)] = wall_clock64(); } while (0)
 #else
 #define IPP_MARK(item, k) ((void)0)
 #endif

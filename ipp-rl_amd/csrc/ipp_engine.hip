@@ -1061,7 +1061,7 @@ int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* strea
 #endif
 #if IPP_TIMELINE
     if (const char* path = getenv("IPP_TIMELINE_FILE")) {
-        const size_t n = (size_t)4 * std::min((int)e->v.max_batch, kTimelineItems);
+        const size_t n = (size_t)8 * std::min((int)e->v.max_batch, kTimelineItems);
         std::vector<unsigned long long> tl(n);
         HIP_TRY(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_timeline), n * 8));
         if (FILE* f = fopen(path, "wb")) { fwrite(tl.data(), 8, n, f); fclose(f); }

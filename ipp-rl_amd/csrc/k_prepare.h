@@ -222,7 +222,14 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     const float* cov_env = v.cov + (size_t)h.env * v.cov_slot;
     const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
     const bool cov_only = (flags & IPP_COV_ONLY) != 0;
+    // Batch 1 is complete here on every path the hardware takes, but not on every path hipcc's wait-count tracking
+    // sees: it then waits for the spans at their first use, inside the gather, and that vmcnt(0) also drains the
+    // ground-truth / mean requests issued in front of the gather (one more round trip).  Touching the spans here puts
+    // that wait where it costs nothing.
+#pragma unroll
+    for (int u = 0; u < UN; ++u) asm volatile("" : : "v"(sp_pre[u]));
     IPP_TICK(v, 1, tick);
+    if (FRONT_ONLY && threadIdx.x == 0) IPP_MARK(item, 3);
 
     // ------------------------------------------------------------------ batch 2: footprint-dependent loads
     // (a) ground-truth crop (simulations/__init__.py:24-25), one cell per thread (f <= FC <= threads)
@@ -353,6 +360,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         vv[tid] = 0.0;
     }
     IPP_TICK(v, 2, tick);
+    if (FRONT_ONLY && threadIdx.x == 0) IPP_MARK(item, 4);
 
     if (obs_out) {  // ipp_observe: observation only
         __syncthreads();
@@ -401,6 +409,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     }
     __syncthreads();
     IPP_TICK(v, 3, tick);
+    if (FRONT_ONLY && threadIdx.x == 0) IPP_MARK(item, 5);
     if ((flags & IPP_UPDATE_PREV) && tid == 0) {
         // every thread has taken its copy of prev_action (batch 1) before the barrier above
         double* pw = const_cast<double*>(prev_action);

@@ -15,13 +15,19 @@ def main():
     path = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     bucket = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
-    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)[:n].astype(np.float64)
+    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)[:n].astype(np.float64)
     t0 = t[:, 0].min()
     start, mid, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0  # us
     ok = t[:, 2] > 0
     print(f"items {n} (with marks: {int(ok.sum())}), kernel span {end[ok].max():.1f} us")
     print(f"phase A  mean {np.mean(mid[ok] - start[ok]):.1f} us   p10 {np.percentile(mid[ok] - start[ok], 10):.1f}  p90 {np.percentile(mid[ok] - start[ok], 90):.1f}")
     print(f"phase B  mean {np.mean(end[ok] - mid[ok]):.1f} us   p10 {np.percentile(end[ok] - mid[ok], 10):.1f}  p90 {np.percentile(end[ok] - mid[ok], 90):.1f}  max {np.max(end[ok] - mid[ok]):.1f}")
+    if np.all(t[ok, 3] > 0):  # sub-phases of phase A (marks in prepare_item_ex)
+        names = ["inputs + header", "ground truth / mean + observation", "gather of U[F,:]", "tables, mask, -HT rows"]
+        cuts = [t[:, 0], t[:, 3], t[:, 4], t[:, 5], t[:, 1]]
+        for nm, a, b in zip(names, cuts[:-1], cuts[1:]):
+            d = (b[ok] - a[ok]) / 100.0
+            print(f"  {nm:36s} mean {d.mean():5.1f} us   p10 {np.percentile(d, 10):5.1f}  p90 {np.percentile(d, 90):5.1f}")
     print(f"last workgroup start at {start[ok].max():.1f} us")
     edges = np.arange(0.0, end[ok].max() + bucket, bucket)
     print(" window[us]  resident  in phase A  streaming")
