@@ -317,7 +317,9 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
 #pragma unroll
     for (int q = 0; q < (FC + kPrepThreads - 1) / kPrepThreads; ++q) {
         const int fi = tid + q * kPrepThreads;
-        if (!cov_only && fi < f) sub[fi] = (double)gt_ld[q];
+        float gt_f = gt_ld[q];
+        asm volatile("" : "+v"(gt_f));  // (conversion pinned here, see eps below: hipcc otherwise waits for this load right at its request)
+        if (!cov_only && fi < f) sub[fi] = (double)gt_f;
     }
     __syncthreads();
 
