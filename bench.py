@@ -9,17 +9,25 @@ the batch (predict + observe + mean/covariance update + reward) including the ep
 that step (episodes are 40 steps long and staggered so every step sees the stationary mix of factor ranks).
 
   python bench.py [--gpus N --steps K --warmup W]
+      N > 1 without WORLD_SIZE in the environment: this process starts the N ranks itself (before it touches the
+      GPU) as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` and relays
+      rank 0's JSON line
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W          (the driver's form: ranks read RANK / LOCAL_RANK / WORLD_SIZE)
 
 Rank 0 prints ONE JSON line.  `value` = envs of all ranks x K / max-over-ranks wall time of the K timed steps
-(inputs resident in HBM).  `roofline` is measured live with HIP events around the streaming kernel;
-`cpu_baseline` times the plain-C fp64 oracle (oracle/ipp_oracle.c, a port of the reference's NumPy path) on the
-host cores on a bounded sample of the same workload.  Synthetic data, device Philox noise.
+(inputs resident in HBM).  `roofline` is measured live with HIP events attached to the streaming kernel's
+dispatches; `cpu_baseline` times the plain-C fp64 oracle (oracle/ipp_oracle.c, a port of the reference's NumPy path)
+on the host cores on a bounded sample of the same workload.  At N = 1 the line also carries `extra`: the same
+measurement for the other BASELINE.json configs that fit one GPU (configs[2], the per-GPU share of configs[3], a
+configs[4] tree-search wave) and for the headline's neighbours (window 12, predict-only).  Synthetic data, device
+Philox noise keyed on the global env id.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,12 +41,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 ALTITUDES = [float(a) for a in range(5, 15)]  # 10 levels, min 5, max 14, spacing 1
 
 
-def parse():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=80)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--envs-total", type=int, default=0,
+                    help="strong scaling: this many envs in total, split into contiguous env-id ranges over the ranks "
+                         "(BASELINE configs[3]: --envs-total 262144 --gpus 8)")
     ap.add_argument("--grid", type=int, default=50)
     ap.add_argument("--state", choices=["factor", "dense"], default="factor")
     ap.add_argument("--episode-steps", type=int, default=40)
@@ -46,25 +57,135 @@ def parse():
     ap.add_argument("--window-rows", type=int, default=-1,
                     help="factor state: keep new columns of U within R grid rows of the footprint; -1 = the smallest R for which "
                          "the dropped prior covariances stay below 1e-6 (ipp_min_window_rows: 10 for the example prior, which the "
-                         "bench never rescales; parity-tested at 1e-5); 0 = exact full columns")
+                         "bench never rescales; 12 with --shuffle-prior; parity-tested at 1e-5); 0 = exact full columns")
+    ap.add_argument("--shuffle-prior", action="store_true",
+                    help="episodes draw (sigma^2, l) in [0.8, 1.2] x nominal like the reference's self-play "
+                         "(planning/mcts_zero/episode_generators.py:53): the window has to hold for 1.2 l -> 12 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` records (other configs) of the N = 1 line")
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--predict-only", action="store_true", help="time the predict-only rate (tree-search call)")
     ap.add_argument("--fused-resets", action="store_true",
                     help="A/B: scheduled episode resets inside the step launch (ipp_step_autoreset) instead of their own launch")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
-    return ap.parse_args()
+    return ap
 
 
-def baseline_config_name(args):
+def parse(argv=None):
+    return build_parser().parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------- multi-GPU plumbing
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(args, argv, port):
+    """The command line that starts args.gpus ranks of this script on one node (what the driver runs for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks as child processes and exit with their
+    code.  Nothing in this process has touched the GPU (torch is not even imported yet); the ranks are fresh
+    processes, never an exec of a GPU-initialised one."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(launch_command(args, argv, free_port()), env=env)
+    sys.exit(proc.returncode)
+
+
+def shard_plan(args, rank, world):
+    """Contiguous env-id range of `rank`: weak scaling = args.envs per rank, strong scaling
+    (--envs-total) = the total split evenly.  Returns (lo, hi, total_envs, scaling)."""
+    from ipp_rl_amd.vec_env import shard_range
+
+    if args.envs_total > 0:
+        lo, hi = shard_range(args.envs_total, rank, world)
+        return lo, hi, args.envs_total, "strong"
+    return rank * args.envs, (rank + 1) * args.envs, args.envs * world, "weak"
+
+
+class Ranks:
+    """torch.distributed used for exactly three things: the barrier around the timed region, the MAX over ranks of its
+    wall time, and gathering the per-rank times for the report.  No data-path collective exists (envs are
+    independent).  backend: "nccl" (= RCCL) on GPUs, "gloo" in the CPU test of this class."""
+
+    def __init__(self, backend="nccl", device=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = torch.device(f"cuda:{self.local_rank}")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def all_times(self, elapsed):
+        """([elapsed of every rank], their max)"""
+        if self.dist is None:
+            return [elapsed], elapsed
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=self.device or "cpu")
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        tmax = t.clone()
+        self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+        return [float(x.item()) for x in out], float(tmax.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def timed_region(run_steps, steps, sync, ranks):
+    """Time EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns (per-rank seconds,
+    max over ranks)."""
+    sync()
+    ranks.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    sync()
+    ranks.barrier()
+    sync()
+    return ranks.all_times(time.perf_counter() - t0)
+
+
+def aggregate_rate(total_units_per_step, steps, elapsed_max):
+    """Whole-job throughput: units of ALL ranks / the slowest rank's time."""
+    return total_units_per_step * steps / elapsed_max
+
+
+# --------------------------------------------------------------------------------------------- workload description
+def baseline_config_name(grid, envs, episode_steps, total=None):
     """Which BASELINE.json config the command line is."""
-    if args.grid == 50 and args.envs == 4096 and args.episode_steps == 40:
+    if grid == 50 and envs == 4096 and episode_steps == 40:
         return "BASELINE configs[1]"
-    if args.grid == 100 and args.envs == 32768 and args.episode_steps == 16:
+    if grid == 100 and envs == 32768 and episode_steps == 16:
         return "BASELINE configs[2]"
-    if args.grid == 50 and args.envs == 32768 and args.episode_steps == 40:
-        return "BASELINE configs[3] (per-GPU share)"
+    if grid == 50 and envs == 32768 and episode_steps == 40:
+        return "BASELINE configs[3]" + (" (per-GPU share)" if not total or total == envs else "")
     return "custom config"
 
 
@@ -112,108 +233,77 @@ def cpu_baseline(cfg, args):
     }
 
 
-def pmc_traffic(kernel_name, args):
+def pmc_traffic(kernel_name, key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command line
-    (tools/pmc_run.sh -> tools/pmc_summary.py -> profiles/*_pmc_summary.json): FETCH_SIZE x 2 (gfx950 correction,
-    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB.  None when no matching summary is committed:
-    counters cannot be collected from inside the timed process."""
+    (tools/pmc_run.sh -> tools/pmc_summary.py -> profiles/*_pmc_summary*.json): FETCH_SIZE x 2 (gfx950 correction,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB.  Returns (bytes, source file) -- (None, None) when no
+    matching summary is committed: counters cannot be collected from inside the timed process, so this number is
+    REPLAYED from the named file, not measured in this run."""
     import glob
 
-    want = workload_key(args)
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json")), reverse=True):
         try:
             with open(path) as fh:
                 summary = json.load(fh)
         except (OSError, ValueError):
             continue
-        if summary.get("_bench_args") != want:
+        if summary.get("_bench_args") != key:
             continue
         for name, counters in summary.items():
             if name.startswith("ipp::" + kernel_name + "<") and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-                return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
-    return None
+                return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, None
 
 
-def main():
-    args = parse()
-    if args.print_args:
-        print(json.dumps(workload_key(args)))
-        return
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL)
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
-
+# --------------------------------------------------------------------------------------------- the measurement
+def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_envs, episode_steps, state="factor",
+                     window_rows=-1, shuffle_prior=False, tile_threads=0, predict_only=False, fused_resets=False,
+                     steps=80, warmup=8, timed=True):
+    """One workload: build the batched env, pre-roll to the stationary rank mix, W warm-up steps, the timed region
+    (all ranks), then the roofline leg (same steps again with HIP events on the streaming kernel's dispatches).
+    Returns a dict of plain numbers."""
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
 
-    cfg = EngineConfig(x_dim=args.grid, y_dim=args.grid)
-    B, T = args.envs, args.episode_steps
-    total_envs = B * world
-    lo, hi = rank * B, (rank + 1) * B  # contiguous env-id range per GPU, no exchange between shards
-    env = VecIPPEnv(cfg, B, state=args.state, episode_steps=T, device=device, seed=1234, env_id_offset=lo,
-                    stagger=True, tile_threads=args.tile_threads, window_rows=args.window_rows,
-                    fused_reset=args.fused_resets)
+    cfg = EngineConfig(x_dim=grid, y_dim=grid)
+    B, T = envs_local, episode_steps
+    env = VecIPPEnv(cfg, B, state=state, episode_steps=T, device=device, seed=1234, env_id_offset=env_lo,
+                    stagger=True, tile_threads=tile_threads, window_rows=window_rows, fused_reset=fused_resets,
+                    shuffle_prior_cov=shuffle_prior)
     eng = env.engine
-    n_total = T + args.warmup + 2 * args.steps
+    n_total = T + warmup + 2 * steps
     # synthetic inputs resident in HBM before the timed region
     actions = torch.stack([
-        torch.as_tensor(cell_centre_actions(cfg, t, lo, hi, total_envs, ALTITUDES), dtype=torch.float64)
+        torch.as_tensor(cell_centre_actions(cfg, t, env_lo, env_lo + B, total_envs, ALTITUDES), dtype=torch.float64)
         for t in range(n_total)
     ]).to(device)
     env.reset()
     t_idx = 0
-    step_kw = {}
-    if args.predict_only:
-        # tree-search call: reward only, state untouched; pre-roll below still builds the stationary state
-        pass
     for _ in range(T):  # pre-roll: reach the stationary mix of episode phases (untimed setup, not warmup)
         env.step(actions[t_idx]); t_idx += 1
 
     def run_steps(k):
         nonlocal t_idx
         for _ in range(k):
-            if args.predict_only:
+            if predict_only:
                 eng.step(actions[t_idx], env.prev, predict_only=True, cov_only=True, reward_out=env.reward,
                          status_out=env.status)
             else:
                 env.step(actions[t_idx])
             t_idx += 1
 
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed_max = float(tmax.item())
+    run_steps(warmup)
+    per_rank, elapsed_max = timed_region(run_steps, steps, torch.cuda.synchronize, ranks)
     bad = int((env.status != 0).sum().item())
     bad_rewards = int((~torch.isfinite(env.reward)).sum().item())
 
-    # ---- roofline leg: same steps again with HIP events around the streaming kernel (rank 0 reports)
+    # ---- roofline leg: same steps again with HIP events around the streaming kernel (every rank runs it, rank 0 reports)
     eng.profile(True)
     eng.streamed_bytes(reset=True)
     rank_sum = torch.zeros((), dtype=torch.float64, device=device)
     ranks_buf = torch.empty(B, dtype=torch.int32, device=device)
-    for _ in range(args.steps):
-        if args.predict_only:
+    for _ in range(steps):
+        if predict_only:
             run_steps(1)
             rank_sum += eng.ranks(ranks_buf).double().sum()  # rows streamed (nothing appended)
         else:
@@ -222,60 +312,180 @@ def main():
             env.step(actions[t_idx], after_step_hook=lambda: rank_sum.add_(eng.ranks(ranks_buf).double().sum()))
             t_idx += 1
     torch.cuda.synchronize()
-    counted_bytes = eng.streamed_bytes(reset=True) / args.steps  # device counter: rows x valid cells actually streamed
+    counted, mask_reread = eng.streamed_bytes_detail(reset=True)  # device counters: floats actually streamed x 4
+    counted /= steps
+    mask_reread /= steps
     gain_ms, gain_n = eng.profile_read(0)
     down_ms, down_n = eng.profile_read(1)
     prep_ms, prep_n = eng.profile_read(2)
     eng.profile(False)
     N = cfg.n_cells
-    mean_rank_after = float(rank_sum.item()) / (args.steps * B)
-    if args.state == "factor":
+    mean_rank_after = float(rank_sum.item()) / (steps * B)
+    if state == "factor":
         # 4N(r + m) + 16N bytes per committed step; predict-only reads 4N r + 8N (mean, diag)
-        per_step = 4.0 * N * mean_rank_after + (8.0 * N if args.predict_only else 16.0 * N)
+        per_step = 4.0 * N * mean_rank_after + (8.0 * N if predict_only else 16.0 * N)
         kernel_ms, kernel_name = gain_ms, "k_gain"
         if int(eng.info.window_rows) > 0:  # mirrors the kernel selection in csrc/ipp_engine.hip launch_chunk()
             tt = int(eng.info.tile_threads)
             fused = tt == 256 and os.environ.get("IPP_FUSED", "1") != "0"
             kernel_name = "k_step_factor" if fused else ("k_gain_wave" if tt == 64 else "k_gain_factor")
     else:
-        per_step = (4.0 * N * 25 + 8.0 * N) if args.predict_only else (8.0 * N * N + 16.0 * N)
-        kernel_ms, kernel_name = (gain_ms, "k_gain") if args.predict_only else (down_ms, "k_downdate")
+        per_step = (4.0 * N * 25 + 8.0 * N) if predict_only else (8.0 * N * N + 16.0 * N)
+        kernel_ms, kernel_name = (gain_ms, "k_gain") if predict_only else (down_ms, "k_downdate")
     formula_bytes = per_step * B  # SURVEY 8(d) formula with full columns
     # factor state: the device counter holds what the launch really streamed (windowed columns, SURVEY 8(d): "N must be
-    # replaced by the window size actually streamed"); dense state: the formula is exact
-    bytes_per_launch = counted_bytes if args.state == "factor" else formula_bytes
+    # replaced by the window size actually streamed"), r + m + 4 floats per touched cell; dense state: the formula is exact
+    bytes_per_launch = counted if state == "factor" else formula_bytes
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    rec = {
+        "grid": grid, "envs_local": B, "episode_steps": T, "state": state, "predict_only": bool(predict_only),
+        "window_rows": int(eng.info.window_rows), "tile_threads": int(eng.info.tile_threads),
+        "per_rank_s": per_rank, "elapsed_max_s": elapsed_max, "steps": steps, "warmup": warmup,
+        "mean_rank_after_step": mean_rank_after, "bad_status": bad, "bad_rewards": bad_rewards,
+        "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
+        "bytes_per_launch": bytes_per_launch, "mask_reread_bytes_per_launch": mask_reread if state == "factor" else 0.0,
+        "formula_bytes_per_launch": formula_bytes, "achieved_gbs": achieved,
+        "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
+        "arena_gb": float(eng.info.arena_bytes) / 1e9,
+    }
+    env.engine.close()
+    del env, eng, actions
+    torch.cuda.empty_cache()
+    return rec, cfg
 
+
+def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, root_steps=5, reps=4):
+    """BASELINE configs[4]: `roots` root states x `sims` simulations on a grid x grid map, every simulation descending
+    `depth` levels with one covariance-only predict step per level (planning/mcts_zero/mcts.py:166-265), batched as
+    one ipp_tree_step launch per level over (roots x sims-in-flight) items; node storage is recycled between waves.
+    GRF ground truth (the reference's temperature dataset is not in the repo)."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    cfg = EngineConfig(x_dim=grid, y_dim=grid)
+    wave = 4  # simulations of one root in flight per launch (virtual-loss style batching): 4096 items per level
+    n_items = roots * wave
+    eng = IPPEngine(cfg, capacity=roots, state="factor", rank_cap=9 * (root_steps + depth + 1), window_rows=-1, fixed_prior=True,
+                    node_capacity=n_items * depth, max_batch=n_items, device=device)
+    white = torch.empty((roots, cfg.n_cells), dtype=torch.float32, device=device)
+    eng.normal_rows(white, cfg.n_cells, 3, 1 << 40)
+    eng.reset(white_noise=white)
+    prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device=device).repeat(roots, 1)
+    noise = torch.empty((root_steps, roots, eng.meas_cap), dtype=torch.float32, device=device)
+    eng.normal_rows(noise, eng.meas_cap, 3, 2 << 40)
+    for t in range(root_steps):  # the roots: a few executed steps each
+        a = torch.as_tensor(cell_centre_actions(cfg, t, 0, roots, roots, ALTITUDES), device=device)
+        eng.step(a, prev, meas_noise=noise[t])
+        prev = a
+    root_ids = torch.arange(roots, dtype=torch.int32, device=device).repeat_interleave(wave)
+    prev_items = prev.repeat_interleave(wave, dim=0)
+    # every simulation's actions stay near its root's last waypoint (a search explores the reachable neighbourhood)
+    acts = [torch.as_tensor(cell_centre_actions(cfg, 100 + d, 0, n_items, n_items, ALTITUDES), device=device) for d in range(depth)]
+    paths = torch.full((depth, n_items, 6), -1, dtype=torch.int32, device=device)
+    new_ids = [(d * n_items + torch.arange(n_items, device=device)).to(torch.int32) for d in range(depth)]
+    for d in range(1, depth):
+        paths[d] = paths[d - 1]
+        paths[d, :, d - 1] = new_ids[d - 1]
+    reward = torch.empty(n_items, dtype=torch.float32, device=device)
+    status = torch.empty(n_items, dtype=torch.int32, device=device)
+
+    def one_wave():
+        p = prev_items
+        for d in range(depth):
+            eng.tree_step(root_ids, paths[d], acts[d], p, new_ids=new_ids[d], reward_out=reward, status_out=status)
+            p = acts[d]
+
+    waves = sims // wave
+    one_wave()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for _ in range(waves):
+            one_wave()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ok = int(status.abs().sum().item()) == 0 and bool(torch.isfinite(reward).all().item())
+    root_rank = float(eng.ranks().float().mean().item())
+    n_steps = roots * sims * depth
+    # bytes one tree step streams (SURVEY 8(d) cfg 5: 4 N (r_root + 9 k + 9) with N -> the window's cells): not counted on
+    # the device for tree steps; report the rate
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return {"name": f"BASELINE configs[4]: {roots} roots x {sims} sims, {grid}x{grid} grid, depth {depth}, GRF ground truth "
+                    f"(predict steps at tree nodes, ipp_tree_step; {wave} simulations per root per launch)",
+            "value": n_steps / dt, "unit": "tree-steps/s", "ms_per_search": dt * 1e3, "root_rank": root_rank,
+            "launch_items": n_items, "all_status_ok": ok}
+
+
+def extra_record(name, rec, total_envs):
+    return {"name": name, "value": aggregate_rate(total_envs, rec["steps"], rec["elapsed_max_s"]), "unit": "env-steps/s",
+            "ms_per_step": 1e3 * rec["elapsed_max_s"] / rec["steps"], "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"],
+            "achieved_gbs": rec["achieved_gbs"], "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "window_rows": rec["window_rows"],
+            "mean_rank_after_step": rec["mean_rank_after_step"], "arena_gb": rec["arena_gb"],
+            "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"]}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.print_args:
+        print(json.dumps(workload_key(args)))
+        return
+    maybe_self_launch(args, argv)  # N > 1 without a launcher: become the launcher (before any GPU call)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL)
+    import torch
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    ranks = Ranks("nccl", device=device)
+    rank, world = ranks.rank, ranks.world
+    lo, hi, total_envs, scaling = shard_plan(args, rank, world)
+    B, T = hi - lo, args.episode_steps
+
+    rec, cfg = run_env_workload(torch, ranks, device, grid=args.grid, envs_local=B, env_lo=lo, total_envs=total_envs,
+                                episode_steps=T, state=args.state, window_rows=args.window_rows,
+                                shuffle_prior=args.shuffle_prior, tile_threads=args.tile_threads,
+                                predict_only=args.predict_only, fused_resets=args.fused_resets, steps=args.steps,
+                                warmup=args.warmup)
     if rank == 0:
+        traffic, traffic_source = pmc_traffic(rec["kernel"], workload_key(args))
         out = {
             "metric": "env-steps/s (batched) on 50x50 grid" if args.grid == 50 else f"env-steps/s (batched) on {args.grid}x{args.grid} grid",
-            "value": total_envs * args.steps / elapsed_max,
+            "value": aggregate_rate(total_envs, args.steps, rec["elapsed_max_s"]),
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps,
+            "ms_per_step": 1e3 * rec["elapsed_max_s"] / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{baseline_config_name(args)}: {B} parallel envs per GPU, {args.grid}x{args.grid} grid, 10 altitude "
+                "workload": f"{baseline_config_name(args.grid, B, T, total_envs)}: {B} parallel envs per GPU, {args.grid}x{args.grid} grid, 10 altitude "
                             f"levels 5-14 m, example.yaml sensor/prior/UAV, GRF ground truth, adaptive reward with "
                             f"flight-time cost; {'predict-only (reward) calls' if args.predict_only else 'full fused env step (predict + observe + update)'}",
-                "envs_per_gpu": B, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,
+                "envs_per_gpu": B, "envs_total": total_envs, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,
                 "episode_steps": T, "episode_phase": "staggered (stationary rank mix)",
-                "mean_rank_after_step": mean_rank_after, "tile_threads": int(eng.info.tile_threads), "window_rows": int(eng.info.window_rows),
-                "items_with_nonzero_status": bad, "non_finite_rewards": bad_rewards, "rng": "device Philox4x32-10",
+                "mean_rank_after_step": rec["mean_rank_after_step"], "tile_threads": rec["tile_threads"], "window_rows": rec["window_rows"],
+                "prior": "shuffled per episode (window sized for 1.2 l)" if args.shuffle_prior else "fixed (example.yaml)",
+                "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"],
+                "rng": "device Philox4x32-10 keyed on the global env id",
+                "per_rank_ms_per_step": [1e3 * t / args.steps for t in rec["per_rank_s"]],
+                "per_rank_env_steps_per_s": [B * args.steps / t for t in rec["per_rank_s"]],
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, args),
-                "kernel": kernel_name, "kernel_ms_avg": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "full_column_formula_bytes_per_launch": formula_bytes,
-                "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
+                "bound": "hbm", "achieved": rec["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "launches": rec["launches"],
+                "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
+                "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device",
+                "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
+                "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
+                "other_kernels_ms_avg": rec["other_kernels_ms_avg"],
             },
         }
         if not args.no_cpu_baseline:
@@ -284,10 +494,35 @@ def main():
             except Exception as exc:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {exc!r}"}
+    # ---- the other configs that fit one GPU, same measurement, short runs (N = 1 default line only)
+    default_line = (world == 1 and not args.no_extra and args.grid == 50 and B == 4096 and T == 40 and args.state == "factor"
+                    and args.window_rows == -1 and not args.predict_only and not args.shuffle_prior and args.tile_threads == 0)
+    if default_line:
+        extra = []
+        todo = [
+            ("BASELINE configs[1], window 12 rows (valid for shuffle_prior_cov, the reference's self-play prior)",
+             dict(grid=50, envs_local=4096, episode_steps=40, shuffle_prior=True)),
+            ("BASELINE configs[1], predict-only calls (simulate_prediction_step, no state write)",
+             dict(grid=50, envs_local=4096, episode_steps=40, predict_only=True)),
+            ("BASELINE configs[2]: 32768 envs, 100x100 grid, 16-step episodes",
+             dict(grid=100, envs_local=32768, episode_steps=16)),
+            ("BASELINE configs[3] per-GPU share: 32768 envs, 50x50 grid, 40-step episodes",
+             dict(grid=50, envs_local=32768, episode_steps=40)),
+        ]
+        for name, kw in todo:
+            try:
+                r, _ = run_env_workload(torch, ranks, device, env_lo=0, total_envs=kw["envs_local"], steps=20, warmup=4, **kw)
+                extra.append(extra_record(name, r, kw["envs_local"]))
+            except Exception as exc:
+                extra.append({"name": name, "error": repr(exc)})
+        try:
+            extra.append(run_tree_wave(torch, device))
+        except Exception as exc:
+            extra.append({"name": "BASELINE configs[4] tree wave", "error": repr(exc)})
+        out["extra"] = extra
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 5
+#define IPP_ABI_VERSION 6
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -324,6 +324,15 @@ int ipp_metrics(void* engine, const int32_t* env_ids /*[dev]*/, int32_t n, float
 int ipp_fill_normal(void* engine, float* out /*[dev]*/, uint64_t count, uint64_t seed, uint64_t subsequence,
                     void* stream);
 
+/* Row-keyed variant for sharded runs: out[p][j][c] (planes x rows x row_len) depends only on (seed,
+ * subsequence + p, row id, c) with row id = (row_ids ? row_ids[j] : j) + row_offset.  With a row = one env (its
+ * ground-truth white noise of one episode: simulations/ground_truths.py:19; its measurement noise of one step:
+ * simulations/sensor_manipulations.py:56) and row_offset = the shard's first GLOBAL env id, every env draws the same
+ * numbers however the batch is split over GPUs ("seeds derived from the global env id").
+ *   row_ids [dev] int32[rows] or NULL */
+int ipp_fill_normal_rows(void* engine, float* out /*[dev]*/, int32_t planes, int32_t rows, int32_t row_len,
+                         const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence, void* stream);
+
 /* Copy the prologue record of item `idx` of the most recent ipp_step to the host (synchronises). */
 int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out /*[host]*/, void* stream);
 
@@ -333,9 +342,14 @@ int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out /*[host]*/
 int ipp_profile_enable(void* engine, int32_t enable);
 int ipp_profile_read(void* engine, int32_t kind, double* avg_ms /*[host]*/, int64_t* launches /*[host]*/, int32_t reset);
 /* Bytes the gain kernel actually streamed / wrote since the last reset of the counter (rows x valid cells x 4 +
- * per-cell mean / diag traffic), counted on the device per workgroup: the numerator of roofline.achieved when
+ * 4 floats of mean / diag traffic per touched cell), counted on the device per workgroup: the numerator of roofline.achieved when
  * window_rows > 0.  Synchronises. */
 int ipp_streamed_bytes(void* engine, uint64_t* bytes /*[host]*/, int32_t reset, void* stream);
+/* Same, plus the bytes the fused kernel reads a second time (mean / diag of the touched tiles: once for the adaptive
+ * mask, rewards.py:11, once more by the update): traffic beyond SURVEY 8(d)'s per-cell count r + m + 4, which
+ * `bytes` follows.  mask_reread_bytes may be NULL.  Synchronises. */
+int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes /*[host]*/, uint64_t* mask_reread_bytes /*[host]*/, int32_t reset,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class IppConfig(C.Structure):
@@ -89,8 +89,10 @@ PROTOTYPES = {
     "ipp_write_cov_dense": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_metrics": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "ipp_fill_normal": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
+    "ipp_fill_normal_rows": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "ipp_debug_step_item": (C.c_int, [_P, C.c_int32, C.POINTER(IppStepItem), _P]),
     "ipp_streamed_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int32, _P]),
+    "ipp_streamed_bytes_detail": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, _P]),
     "ipp_profile_enable": (C.c_int, [_P, C.c_int32]),
     "ipp_profile_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -5,8 +5,17 @@ map operation through a small dense-state HIP engine (2 slots) looked up here.  
 computes on the CPU; without the HIP library or a GPU the first call raises.
 
 Engines are cached per configuration and are never part of an object's pickled state (the reference pickles
-Mapping objects into multiprocessing workers and experiment.pkl: SURVEY 8(b)); a forked / spawned worker opens
-its own engine lazily.
+Mapping objects into multiprocessing workers and experiment.pkl: SURVEY 8(b)).
+
+Processes.  A SPAWNED worker (multiprocessing.get_context("spawn"), torch.multiprocessing.spawn) is a fresh process:
+it unpickles the Mapping and opens its own engine lazily on first use.  A FORKED worker of a parent that has already
+opened an engine cannot use the GPU at all: HIP state does not survive fork() and PyTorch refuses to re-initialise
+the device in a forked child.  The child therefore abandons the inherited engines WITHOUT destroying them (their
+streams / events / device memory belong to the parent's runtime; calling hipStreamDestroy on them from the child can
+hang) and the first map operation raises an IppError that says to use the spawn start method -- the reference's
+`Pool(4)` in greedy_search (planning/common/optimization.py:86-90) and its self-play pools fork by default on Linux,
+so callers set `multiprocessing.set_start_method("spawn")` once.  A fork BEFORE any engine exists
+is harmless: the child initialises the GPU itself.
 """
 from __future__ import annotations
 
@@ -15,10 +24,11 @@ from typing import Dict, Tuple
 
 import numpy as np
 
+from . import _ffi
+from . import engine as _engine_mod
 from .engine import EngineConfig, IPPEngine
 
 _ENGINES: Dict[Tuple, IPPEngine] = {}
-_PID = os.getpid()
 
 
 def config_key(cfg: EngineConfig) -> Tuple:
@@ -28,10 +38,8 @@ def config_key(cfg: EngineConfig) -> Tuple:
 
 def compat_engine(cfg: EngineConfig) -> IPPEngine:
     """Dense-state engine with 2 slots for `cfg` (slot 0: working map, slot 1: scratch)."""
-    global _PID
-    if os.getpid() != _PID:  # forked worker: HIP handles do not survive a fork
-        _ENGINES.clear()
-        _PID = os.getpid()
+    if _engine_mod.forked_with_gpu():  # (engine.py abandons every inherited engine at fork, without destroying it)
+        raise _ffi.IppError(_engine_mod.FORK_MESSAGE)
     key = config_key(cfg)
     eng = _ENGINES.get(key)
     if eng is None:
@@ -41,9 +49,12 @@ def compat_engine(cfg: EngineConfig) -> IPPEngine:
     return eng
 
 
-def engine_config_from(grid_map, sensor, signal_variance: float, length_scale: float) -> EngineConfig:
-    sim = getattr(sensor, "sensor_simulation", None)
-    cluster = getattr(sim, "cluster_radius", None)
+def engine_config_from(grid_map, sensor, signal_variance: float, length_scale: float, cluster_radius=None) -> EngineConfig:
+    """cluster_radius: the simulation passes its own (it builds its first ground truth BEFORE it is attached to the
+    sensor: planning/ipp_mission_node.py:40-42, simulations/simulations.py:41); the mapping takes the attached one."""
+    cluster = cluster_radius
+    if cluster is None:
+        cluster = getattr(getattr(sensor, "sensor_simulation", None), "cluster_radius", None)
     return EngineConfig(
         x_dim=int(grid_map.x_dim), y_dim=int(grid_map.y_dim), resolution=float(grid_map.resolution),
         angle_x=float(sensor.angle_x), angle_y=float(sensor.angle_y),

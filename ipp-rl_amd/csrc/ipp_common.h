@@ -117,7 +117,7 @@ struct View {
     double* prior;   // [cap][2]  (sigma^2, l)
     int* rank;       // [cap]
     int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
-    unsigned long long* counters;  // [4] device counters (streamed cells x rows, ...)
+    unsigned long long* counters;  // [16]: [0] streamed floats (SURVEY 8(d) count), [8] floats re-read for the mask; [1..7] debug timing
     float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]
     uint64_t cov_slot;  // floats per env slot
     // per-call scratch

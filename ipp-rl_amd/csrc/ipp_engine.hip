@@ -166,7 +166,7 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_prior = o; o += up(cap * 2 * 8);
     L.off_rank = o; o += up(cap * 4);
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(cap * (uint64_t)c.rank_cap * 4) : 0;
-    L.off_cnt = o; o += up(64);
+    L.off_cnt = o; o += up(128);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
     L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
@@ -549,11 +549,11 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         while (e->lut_rows > 0 && (size_t)e->lut_rows * v.W > 12288) --e->lut_rows;  // <= 48 KiB
         const int lutf = e->lut_rows * v.W;
         if (v.meas_cap == 9)
-            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.Npad / 4)
-                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves);
+            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.n_tiles, v.Npad / 4)
+                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.n_tiles);
         else
-            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.Npad / 2)
-                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves);
+            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.n_tiles, v.Npad / 2)
+                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.n_tiles);
         if (v.T == kWave)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;
@@ -1013,6 +1013,20 @@ int ipp_fill_normal(void* engine, float* out, uint64_t count, uint64_t seed, uin
     return 0;
 }
 
+int ipp_fill_normal_rows(void* engine, float* out, int32_t planes, int32_t rows, int32_t row_len, const int32_t* row_ids,
+                         int64_t row_offset, uint64_t seed, uint64_t subsequence, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !out) return fail(-1, "null argument");
+    if (planes < 0 || rows < 0 || row_len <= 0 || planes > 65535) return fail(-1, "bad shape %d x %d x %d", planes, rows, row_len);
+    if (planes == 0 || rows == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    const long long quads = (long long)rows * ((row_len + 3) / 4);
+    hipLaunchKernelGGL(k_fill_normal_rows, dim3((unsigned)((quads + 255) / 256), (unsigned)planes), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), out, planes, rows, row_len, row_ids, (long long)row_offset, seed, subsequence);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out, void* stream) {
     Engine* e = as_engine(engine);
     if (!e || !out) return fail(-1, "null argument");
@@ -1044,14 +1058,19 @@ int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out, void* str
 }
 
 int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* stream) {
+    return ipp_streamed_bytes_detail(engine, bytes, nullptr, reset, stream);
+}
+
+int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_reread_bytes, int32_t reset, void* stream) {
     Engine* e = as_engine(engine);
     if (!e || !bytes) return fail(-1, "null argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
-    unsigned long long cells = 0;
-    HIP_TRY(hipMemcpyAsync(&cells, e->v.counters, 8, hipMemcpyDeviceToHost, s));
+    unsigned long long cnt[9] = {};
+    HIP_TRY(hipMemcpyAsync(cnt, e->v.counters, sizeof cnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *bytes = (uint64_t)cells * 4;
+    *bytes = (uint64_t)cnt[0] * 4;
+    if (mask_reread_bytes) *mask_reread_bytes = (uint64_t)cnt[8] * 4;
 #if IPP_PHASE_TIMING
     {
         unsigned long long c[8];
@@ -1067,7 +1086,7 @@ int ipp_streamed_bytes(void* engine, uint64_t* bytes, int32_t reset, void* strea
         if (FILE* f = fopen(path, "wb")) { fwrite(tl.data(), 8, n, f); fclose(f); }
     }
 #endif
-    if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 64, s));
+    if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 128, s));
     return 0;
 }
 

@@ -44,18 +44,20 @@ struct GainLds {
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
     int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
+    double* tile_red;  // [n_tiles] masked trace reduction of every tile of the item (summed in tile order at the end)
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
-                                            int mask_bytes = 0) {
+                                            int n_tiles, int mask_bytes = 0) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
         b += (size_t)((rank_cap + 3) & ~3) * 4 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
         b = ((b + 15) & ~(size_t)15) + (size_t)mask_bytes;
+        b = ((b + 15) & ~(size_t)15) + (size_t)n_tiles * 8;
         return (b + 15) & ~(size_t)15;
     }
     // work: HT staging rows of the fused prologue (0 floats for the stand-alone kernel); lut: prior table;
     // small: the fused prologue's fp64 scratch (0 floats for the stand-alone kernel)
     // mask_bytes > 0 (fused kernel): no mean / diag staging area, the env's mask bytes instead
     __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
-                                       int mask_bytes = 0) {
+                                       int n_tiles, int mask_bytes = 0) {
         Ls = reinterpret_cast<float*>(base);
         ys = Ls + MC * MC;
         work = Ls + LQ;
@@ -74,6 +76,7 @@ struct GainLds {
         ridx_all = reinterpret_cast<unsigned short*>(stage + (mask_bytes ? 0 : (size_t)waves * kWave * 8));
         // adaptive-mask bits of the whole env, one byte per VEC cells (fused kernel), behind the per-wave index lists
         mask4 = reinterpret_cast<unsigned char*>(ridx_all + (((size_t)waves * (rank_cap + 8) + 7) & ~(size_t)7));
+        tile_red = reinterpret_cast<double*>(mask4 + (((size_t)mask_bytes + 15) & ~(size_t)15));
     }
 };
 
@@ -137,8 +140,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     float* stage_w = lds.stage + (size_t)wave * kWave * 8;  // (VEC <= 4)
     const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
     const size_t npad = (size_t)v.Npad;
-    double wave_part = 0.0;
-    unsigned long long units = 0;
+    unsigned long long units = 0, extra = 0;
     bool solved = !PRE, dead = false;
 #if IPP_PHASE_TIMING
     const unsigned long long loop0_ = wall_clock64();
@@ -345,10 +347,14 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                                        : (!adaptive || ((double)mean_in[c] + v.kf * (double)diag_in[c] >= v.thr));
             if (valid && in_mask) part += (double)w2;
         }
-        wave_part += wave_sum(part);
+        part = wave_sum(part);
+        if (lane == 0) lds.tile_red[tile - h.t_lo] = part;
         const int valid_cells = max(0, min(kWaveTile, v.N - tile * kWaveTile));
-        // LMASK: phase A read mean / diag of this tile for the mask (2), the atomics read and write them again (4)
-        units += (unsigned long long)(nact + (commit ? m + (LMASK ? 6 : 4) : 2)) * valid_cells;
+        // 4 N (r + m) + 16 N per committed step = (stored rows + m new rows + mean and diag read and
+        // written) floats per touched cell.  LMASK: phase A also read mean / diag of this tile for the mask, which the
+        // atomics then read again: those 2 extra floats per cell are traffic, not algorithm -- counted separately
+        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * valid_cells;
+        if (LMASK && commit) extra += 2ull * valid_cells;
         if (commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
             if (LMASK) {
@@ -386,13 +392,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     if (lane == 0) atomicAdd(&v.counters[7], wall_clock64() - loop0_);
 #endif
     // ------------------------------------------------------------------ per-item results
-    // No closing barrier: a wave that has no tile left publishes its partial sum and exits, freeing its slot;
-    // the last wave to arrive (LDS counter) adds the partials in wave order (bit-reproducible) and writes the
-    // item's reward, rank and the span of the appended columns.
-    if (lane == 0) {
-        red[wave] = wave_part;
-        if (units) atomicAdd(v.counters, units);
-    }
+    // No closing barrier: a wave that has no tile left exits, freeing its slot; the last wave to arrive (LDS counter)
+    // adds the per-tile sums in TILE order -- the tiles are handed out dynamically, so which wave reduced which tile
+    // differs from run to run, but neither the per-tile values nor their order do: the reward is bit-reproducible by
+    // construction -- and writes the item's reward, rank and the span of the appended columns.
+    if (lane == 0 && units) atomicAdd(v.counters, units);
+    if (lane == 0 && extra) atomicAdd(v.counters + 8, extra);
     int reset_k = -1;
     if (RESET && ar->src) reset_k = __builtin_amdgcn_readfirstlane(ar->src[item]);
     if (RESET && reset_k >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores / atomics have landed
@@ -407,7 +412,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     if (lane == 0) {
         if (PRE && !CHAIN) IPP_MARK(item, 2);
         double tot = 0.0;
-        for (int w = 0; w < nw; ++w) tot += red[w];
+        for (int t = 0; t <= h.t_hi - h.t_lo; ++t) tot += lds.tile_red[t];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
         if (commit_item && !CHAIN) v.rank[h.dst] = r + m;
         if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); }
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
                                                                    float* __restrict__ reward_out) {
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave);
+    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.n_tiles);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;

@@ -339,4 +339,35 @@ __global__ void k_fill_normal(float* __restrict__ out, uint64_t count, uint64_t 
         if (q * 4 + e < count) out[q * 4 + e] = nrm[e];
 }
 
+// Row-keyed variant: out[p][j][c] (planes x rows x row_len) = normal(seed, subsequence subseq0 + p, counter =
+// (row id of j) * ceil(row_len / 4) + c / 4, element c % 4), row id = (row_ids ? row_ids[j] : j) + row_offset.
+// A row is an env (its ground-truth white noise, its measurement noise of one step): keyed on the GLOBAL env id the
+// value does not depend on which rows share a launch, i.e. on how the envs are sharded over GPUs.
+__global__ void k_fill_normal_rows(float* __restrict__ out, int planes, int rows, int row_len, const int* __restrict__ row_ids,
+                                   long long row_offset, uint64_t seed, uint64_t subseq0) {
+    const int qpr = (row_len + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * qpr) return;
+    const int j = (int)(idx / qpr), qc = (int)(idx - (long long)j * qpr);
+    const int p = blockIdx.y;
+    const uint64_t rid = (uint64_t)((row_ids ? (long long)row_ids[j] : (long long)j) + row_offset);
+    const uint64_t q = rid * (uint64_t)qpr + (uint64_t)qc;
+    const uint64_t subseq = subseq0 + (uint64_t)p;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)subseq, (uint32_t)(subseq >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    float* o = out + ((size_t)p * rows + j) * row_len + 4 * qc;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u0 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+        const float u1 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.0f * logf(fmaxf(u0, 1e-30f)));
+        float sn, cs;
+        sincosf(6.283185307179586f * u1, &sn, &cs);
+        if (4 * qc + 2 * h < row_len) o[2 * h] = rad * cs;
+        if (4 * qc + 2 * h + 1 < row_len) o[2 * h + 1] = rad * sn;
+    }
+}
+
 }  // namespace ipp

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tr[];
     const GainLds<MC> lds(smem_tr, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.Npad / VEC);
+                          kStepThreads / kWave, v.n_tiles, v.Npad / VEC);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;

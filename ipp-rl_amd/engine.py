@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -65,6 +66,37 @@ def _torch():
     return torch
 
 
+# ---- fork safety.  HIP state (streams, events, device memory) does not survive fork(), and PyTorch refuses to
+# re-initialise the device in a forked child.  A child forked from a process with live engines therefore ABANDONS them:
+# the handle is dropped without ipp_engine_destroy (hipStreamDestroy on the parent's objects can hang) and the arena
+# tensors are kept referenced forever so that nothing tries to free them.  New engines cannot be created there.
+FORK_MESSAGE = ("this process was fork()ed from a parent that had already opened the GPU engine; HIP state does not survive "
+                "fork.  Start workers with the spawn method (multiprocessing.set_start_method('spawn'), "
+                "multiprocessing.get_context('spawn').Pool(...), torch.multiprocessing.spawn): a spawned worker opens its own "
+                "engine.")
+_LIVE = weakref.WeakSet()
+_ABANDONED = []
+_forked_with_gpu = False
+
+
+def forked_with_gpu() -> bool:
+    return _forked_with_gpu
+
+
+def _after_fork_in_child():
+    global _forked_with_gpu
+    live = list(_LIVE)
+    if not live:
+        return
+    for eng in live:
+        _ABANDONED.append((eng, getattr(eng, "arena", None)))
+        eng._h = None
+    _forked_with_gpu = True
+
+
+os.register_at_fork(after_in_child=_after_fork_in_child)
+
+
 class IPPEngine:
     """B environment slots on one GPU; state lives in one caller-owned arena tensor."""
 
@@ -75,6 +107,8 @@ class IPPEngine:
         """window_rows: 0 = exact columns, R > 0 = columns kept within R grid rows of their footprint, -1 = the smallest
         R the engine accepts for this prior (ipp_min_window_rows).  fixed_prior: no reset will install a length scale above
         cfg.length_scale (no shuffle_prior_cov), which lets the window be 10 instead of 12 rows for the example config."""
+        if _forked_with_gpu:
+            raise _ffi.IppError(FORK_MESSAGE)
         torch = _torch()
         self._lib = _ffi.load()
         if not torch.cuda.is_available():
@@ -122,6 +156,7 @@ class IPPEngine:
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _ffi.check(self._lib.ipp_engine_create(C.byref(c), dev_index, C.c_void_p(base), nbytes.value, C.byref(handle)))
         self._h = handle
+        _LIVE.add(self)
         info = _ffi.IppInfo()
         _ffi.check(self._lib.ipp_engine_info(self._h, C.byref(info)))
         self.info = info
@@ -423,6 +458,23 @@ class IPPEngine:
         _ffi.check(self._lib.ipp_fill_normal(self._h, self._ptr(out), int(count), int(seed), int(subsequence), self.stream))
         return out
 
+    def normal_rows(self, out, row_len: int, seed: int, subsequence: int, row_ids=None, row_offset: int = 0):
+        """Row-keyed Philox normals (ipp_fill_normal_rows): out is a contiguous float32 device tensor [rows, row_len] or
+        [planes, rows, row_len]; out[p, j, :] depends only on (seed, subsequence + p, row_ids[j] + row_offset)."""
+        torch = _torch()
+        if out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 device tensor")
+        planes, rows = (1, out.shape[0]) if out.dim() == 2 else (out.shape[0], out.shape[1])
+        if out.shape[-1] != row_len:
+            raise ValueError("last dimension of out must be row_len")
+        ids = self._dev(row_ids, torch.int32)
+        if ids is not None and ids.numel() != rows:
+            raise ValueError("row_ids needs one entry per row")
+        _ffi.check(self._lib.ipp_fill_normal_rows(self._h, self._ptr(out), int(planes), int(rows), int(row_len), self._ptr(ids),
+                                                  int(row_offset), int(seed) & (2 ** 64 - 1), int(subsequence) & (2 ** 64 - 1), self.stream))
+        self._keep_rows = ids
+        return out
+
     def debug_item(self, idx: int) -> Dict:
         it = _ffi.IppStepItem()
         _ffi.check(self._lib.ipp_debug_step_item(self._h, int(idx), C.byref(it), self.stream))
@@ -439,6 +491,13 @@ class IPPEngine:
         b = C.c_uint64(0)
         _ffi.check(self._lib.ipp_streamed_bytes(self._h, C.byref(b), 1 if reset else 0, self.stream))
         return int(b.value)
+
+    def streamed_bytes_detail(self, reset: bool = True):
+        """(algorithmic bytes per SURVEY 8(d): r + m + 4 floats per touched cell, bytes of the fused kernel's second read of
+        mean / diag for the mask) since the last reset; synchronises."""
+        b, x = C.c_uint64(0), C.c_uint64(0)
+        _ffi.check(self._lib.ipp_streamed_bytes_detail(self._h, C.byref(b), C.byref(x), 1 if reset else 0, self.stream))
+        return int(b.value), int(x.value)
 
     def profile(self, enable: bool):
         _ffi.check(self._lib.ipp_profile_enable(self._h, 1 if enable else 0))

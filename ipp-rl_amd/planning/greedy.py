@@ -81,9 +81,10 @@ class GreedyPlanner:
         self.engine.reset(env_ids=[0], white_noise=None if white_noise is None else np.asarray(white_noise)[None],
                           gt=None if gt is None else np.asarray(gt)[None], prior_scale=prior_scale)
 
-    def run(self, budget: float, meas_noise_fn=None, previous_action=None):
+    def run(self, budget: float, meas_noise_fn=None, previous_action=None, trace: Optional[list] = None):
         """Greedy mission: score -> argmax -> execute (observe + update) until the budget is spent.
-        meas_noise_fn(m) returns the standard normals of one measurement (NumPy legacy stream for parity)."""
+        meas_noise_fn(m) returns the standard normals of one measurement (NumPy legacy stream for parity).
+        trace: a list that receives (candidates, rewards) of every step (tests)."""
         prev = INIT_ACTION.copy() if previous_action is None else np.asarray(previous_action, dtype=np.float64)
         waypoints, rewards = [], []
         while budget >= 0:
@@ -91,6 +92,8 @@ class GreedyPlanner:
             if len(cands) == 0:
                 break
             r = self.score(prev, cands)
+            if trace is not None:
+                trace.append((np.asarray(cands), r))
             best = np.asarray(cands[int(np.argmax(r))])
             eps = None
             if meas_noise_fn is not None:

@@ -27,7 +27,8 @@ class ScalarFieldSimulation(Simulation):
     def _engine(self):
         gm = self.sensor.grid_map
         mp = gm.params.get("mapping", {})
-        cfg = _runtime.engine_config_from(gm, self.sensor, mp.get("signal_variance", 1.0), mp.get("length_scale", 1.0))
+        cfg = _runtime.engine_config_from(gm, self.sensor, mp.get("signal_variance", 1.0), mp.get("length_scale", 1.0),
+                                          cluster_radius=self.cluster_radius)
         return _runtime.compat_engine(cfg)
 
     def create_ground_truth_map(self) -> np.array:

@@ -11,7 +11,9 @@ new Gaussian-random-field ground truth and (optionally) shuffled prior hyper-par
 
 Randomness: parity runs pass NumPy legacy-stream normals in (``white_noise`` / ``meas_noise`` arguments);
 throughput runs let the engine's Philox generator fill them on the device (stated in reports).
-Seeds are derived from the GLOBAL env id, so results do not depend on how envs are sharded over GPUs.
+Device noise is keyed on the GLOBAL env id (ipp_fill_normal_rows: Philox counter = global env id x row length +
+element, subsequence = stream kind + the env's episode index / the step index), so an env's ground truths and
+measurement noise do not depend on how the batch is sharded over GPUs (tests/test_hip_sharding.py).
 """
 from __future__ import annotations
 
@@ -91,6 +93,7 @@ class VecIPPEnv:
         self._fused_reset = bool(fused_reset and stagger and state == "factor" and not shuffle_prior_cov and
                                  4 * B * self.episode_steps <= (64 << 20))
         self._reset_src_by_phase = {}
+        self._prior_ring = {}
         self._white = torch.empty((B, cfg.n_cells), dtype=torch.float32, device=dev)
         # staggered runs prepare the next resets' ground truths on a side stream while the step kernels run
         # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
@@ -115,15 +118,39 @@ class VecIPPEnv:
         self._flags = (4 if adaptive else 0) | (8 if use_flight_time else 0)
 
     # ------------------------------------------------------------------ resets
-    def _prior_scale(self, ids_host: np.ndarray, episode_index: int):
+    def _prior_scale(self, ids_host: np.ndarray, episode_index):
+        """(sigma^2, l) ~ U(0.8, 1.2) x nominal per env and episode (mapping/mappings.py:238-240), from a counter hash
+        of (seed, GLOBAL env id, episode index, which draw): vectorised, no generator state, the same for an env
+        whatever the sharding.  Returns float64 [n, 2] (episode_index: scalar or [n])."""
         if not self.shuffle_prior_cov:
             return None
-        out = np.empty((len(ids_host), 2))
-        for k, e in enumerate(ids_host):
-            rs = np.random.RandomState((self.seed * 1_000_003 + int(e) + self.env_id_offset) % (2 ** 31) + episode_index)
-            out[k, 0] = rs.uniform(0.8 * self.cfg.signal_variance, 1.2 * self.cfg.signal_variance)
-            out[k, 1] = rs.uniform(0.8 * self.cfg.length_scale, 1.2 * self.cfg.length_scale)
+        gid = np.asarray(ids_host, dtype=np.uint64) + np.uint64(self.env_id_offset)
+        epi = np.broadcast_to(np.asarray(episode_index, dtype=np.uint64), gid.shape)
+        out = np.empty((len(gid), 2))
+        with np.errstate(over="ignore"):
+            for d, nominal in enumerate((self.cfg.signal_variance, self.cfg.length_scale)):
+                x = (gid * np.uint64(0x9E3779B97F4A7C15) + epi * np.uint64(0xD1B54A32D192ED03) +
+                     np.uint64((self.seed * 2 + d) & (2 ** 64 - 1)) * np.uint64(0x8CB92BA72F3D8DD7))
+                x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)  # splitmix64 finaliser
+                x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+                x ^= x >> np.uint64(31)
+                u = (x >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+                out[:, d] = nominal * (0.8 + 0.4 * u)
         return out
+
+    PRIOR_RING = 16
+
+    def _prior_scale_scheduled(self, phase: int):
+        """Device [n, 2] prior scales for the next episode of the envs of a scheduled reset group; drawn PRIOR_RING
+        episodes at a time so that the host work and the upload are off the per-step path."""
+        ids = self._reset_ids_host[phase]
+        epi = int(self.episode[ids[0]]) if len(ids) else 0
+        hit = self._prior_ring.get(phase)
+        if hit is None or not (hit[0] <= epi < hit[0] + self.PRIOR_RING):
+            block = np.stack([self._prior_scale(ids, epi + k) for k in range(self.PRIOR_RING)])
+            hit = (epi, self.torch.as_tensor(block, dtype=self.torch.float64, device=self.device))
+            self._prior_ring[phase] = hit
+        return hit[1][epi - hit[0]]
 
     def reset(self, env_ids=None, white_noise=None, gt=None, prior_scale=None, _phase=None):
         """Reset the given slots (all when None).  white_noise / gt: [n, H, W] NumPy or tensor (parity)."""
@@ -138,12 +165,13 @@ class VecIPPEnv:
         if n == 0:
             return
         if gt is None and white_noise is None:
-            # device Philox stream: subsequence = (shard offset, reset-call counter)
-            white = self._white[:n]
-            self.engine.normal(n * self.cfg.n_cells, self.seed, self._subseq_for_reset(), out=white)
-            white_noise = white
+            white_noise = self._white_for(ids, self._ids_host(ids, env_ids, _phase), self._white[:n])
         if prior_scale is None and self.shuffle_prior_cov:
-            prior_scale = self._prior_scale(ids.cpu().numpy(), self.t)
+            if _phase is not None:
+                prior_scale = self._prior_scale_scheduled(_phase)
+            else:
+                ih = self._ids_host(ids, env_ids, _phase)
+                prior_scale = self._prior_scale(ih, self.episode[np.asarray(ih, dtype=np.int64)])
         # the reset kernel also returns the UAVs to Mission.init_action (ipp_reset_episode)
         self.engine.reset(env_ids=ids, prior_scale=prior_scale, gt=gt, white_noise=white_noise, prev=self.prev,
                           init_action=INIT_ACTION)
@@ -179,15 +207,36 @@ class VecIPPEnv:
         k = t % 2
         self._side.wait_event(self._staged_free[k])
         with torch.cuda.stream(self._side):
-            white = self._staged_white[k][:n]
-            self.engine.normal(n * self.cfg.n_cells, self.seed, self._subseq_for_reset(), out=white)
+            white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white[k][:n])
             self.engine.generate_grf(white, out=self._staged[k][:n], stream=self._side)
             self._staged_ready[k].record(self._side)
         return (p, k, n)
 
-    def _subseq_for_reset(self) -> int:
-        self._reset_calls = getattr(self, "_reset_calls", 0) + 1
-        return (self.env_id_offset << 24) + self._reset_calls
+    GT_STREAM, NOISE_STREAM = 1 << 40, 2 << 40  # subsequence = stream kind + episode index / step index
+
+    def _ids_host(self, ids, env_ids, phase):
+        if phase is not None:
+            return self._reset_ids_host[phase]
+        if env_ids is None:
+            return np.arange(self.num_envs, dtype=np.int32)
+        return ids.cpu().numpy() if self.torch.is_tensor(env_ids) else np.asarray(env_ids, dtype=np.int32).ravel()
+
+    def _white_for(self, ids_dev, ids_host, out):
+        """Ground-truth white noise of the NEXT episode of the given envs: row = global env id, subsequence = that env's
+        episode index (the envs of one scheduled reset share it: one launch; a mixed set takes one launch per index)."""
+        epi = self.episode[np.asarray(ids_host, dtype=np.int64)]
+        uniq = np.unique(epi)
+        if len(uniq) == 1:
+            self.engine.normal_rows(out, self.cfg.n_cells, self.seed, self.GT_STREAM + int(uniq[0]), row_ids=ids_dev,
+                                    row_offset=self.env_id_offset)
+            return out
+        for e in uniq:  # (hand-made reset sets only; each launch fills the rows of one episode index)
+            sel = np.nonzero(epi == e)[0]
+            tmp = self.torch.empty((len(sel), self.cfg.n_cells), dtype=self.torch.float32, device=self.device)
+            self.engine.normal_rows(tmp, self.cfg.n_cells, self.seed, self.GT_STREAM + int(e),
+                                    row_ids=np.asarray(ids_host)[sel].astype(np.int32), row_offset=self.env_id_offset)
+            out[self.torch.as_tensor(sel, device=self.device)] = tmp
+        return out
 
     # ------------------------------------------------------------------ stepping
     def step(self, actions, meas_noise=None, env_ids=None, auto_reset: bool = True, after_step_hook=None):
@@ -201,20 +250,16 @@ class VecIPPEnv:
         main = torch.cuda.current_stream(self.device)
         scheduled = None
         if auto_reset and self._reset_ids_by_phase is not None:
-            if self.shuffle_prior_cov is False:
-                if self._pending_for != self.t:  # first step (or the schedule was disturbed): stage for this step now
-                    self._pending, self._pending_for = self._stage(self.t), self.t
-                scheduled = self._pending
-                self._pending, self._pending_for = self._stage(self.t + 1), self.t + 1
-            else:
-                p = self._phase_ending_at(self.t)
-                if self._reset_ids_by_phase[p].numel():
-                    scheduled = (p, None, int(self._reset_ids_by_phase[p].numel()))
+            if self._pending_for != self.t:  # first step (or the schedule was disturbed): stage for this step now
+                self._pending, self._pending_for = self._stage(self.t), self.t
+            scheduled = self._pending
+            self._pending, self._pending_for = self._stage(self.t + 1), self.t + 1
         if meas_noise is None:
             if self._noise_pos == 0:
+                # plane p of the ring = step (fills * NOISE_RING + p); row = global env id
+                self.engine.normal_rows(self._noise_ring, self.engine.meas_cap, self.seed, self.NOISE_STREAM +
+                                        self._noise_fills * self.NOISE_RING, row_offset=self.env_id_offset)
                 self._noise_fills += 1
-                self.engine.normal(self._noise_ring.numel(), self.seed ^ 0x5DEECE66D,
-                                   (self.env_id_offset << 24) + self._noise_fills, out=self._noise_ring)
             nz = self._noise_ring[self._noise_pos]
             self._noise_pos = (self._noise_pos + 1) % self.NOISE_RING
         else:

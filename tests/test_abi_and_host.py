@@ -185,3 +185,39 @@ def test_engine_config_from_params_and_workload_helpers():
     assert np.array_equal(np.concatenate(parts), full)  # sharding does not change any env's inputs
     assert np.all((full[:, 0] - 2.0) % 4.0 == 0) and set(np.unique(full[:, 2])) <= {5.0, 6.0, 7.0}
     assert [shard_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+
+
+def test_forked_child_abandons_inherited_engines_and_refuses_new_ones():
+    """HIP state does not survive fork(): the at-fork hook drops every live engine's handle WITHOUT calling
+    ipp_engine_destroy (no GPU needed to check that: a stand-in object is registered as a live engine), and both
+    IPPEngine() and the compat runtime raise an IppError that names the spawn start method."""
+    import os
+
+    from ipp_rl_amd import EngineConfig, _runtime, engine
+    from ipp_rl_amd._ffi import IppError
+
+    class Standin:
+        def __init__(self):
+            self._h, self.arena, self.destroyed = 123, object(), False
+
+    live = Standin()
+    engine._LIVE.add(live)
+    assert not engine.forked_with_gpu()
+    pid = os.fork()
+    if pid == 0:
+        code = 0
+        try:
+            ok = live._h is None and engine.forked_with_gpu() and any(a is live.arena for _, a in engine._ABANDONED)
+            for make in (lambda: engine.IPPEngine(EngineConfig(), capacity=1), lambda: _runtime.compat_engine(EngineConfig())):
+                try:
+                    make()
+                    ok = False
+                except IppError as exc:
+                    ok = ok and "spawn" in str(exc)
+            code = 0 if ok else 1
+        except BaseException:  # noqa: BLE001
+            code = 2
+        os._exit(code)
+    assert os.waitpid(pid, 0)[1] == 0
+    assert live._h == 123 and not engine.forked_with_gpu()  # the parent is unaffected
+    engine._LIVE.discard(live)

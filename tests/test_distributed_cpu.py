@@ -1,15 +1,22 @@
 """
-World-size-2 gloo test of bench.py's multi-process logic on CPU: contiguous env-id shards, inputs derived from the
-global env id (so the union over ranks equals the single-process workload), barrier + MAX-over-ranks timing,
-aggregate = sum of per-rank units / max time.  No data-path collective exists (envs are independent).
+World-size-2 gloo test of bench.py's OWN multi-process code on CPU (no GPU call is reached): `Ranks` (process group,
+barrier, per-rank times, MAX over ranks), `shard_plan` (contiguous env-id ranges, weak and strong scaling),
+`timed_region` and `aggregate_rate`, plus the `--gpus N` self-launch decision.  No data-path collective exists
+(envs are independent); the workload inputs derive from the global env id, so the union over ranks equals the
+single-process workload.
 """
+import json
 import os
 import socket
+import sys
+import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _free_port():
@@ -19,39 +26,87 @@ def _free_port():
 
 
 def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import sys
-
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import bench
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.vec_env import cell_centre_actions
 
+    ranks = bench.Ranks("gloo")  # the class bench.main() builds with "nccl"
+    assert (ranks.rank, ranks.world) == (rank, world)
     cfg = EngineConfig(x_dim=50, y_dim=50)
-    per_gpu, total = 16, 16 * world
-    lo, hi = rank * per_gpu, (rank + 1) * per_gpu
-    acts = torch.as_tensor(cell_centre_actions(cfg, 7, lo, hi, total, list(range(5, 15))))
-    gathered = [torch.empty_like(acts) for _ in range(world)]
-    dist.all_gather(gathered, acts)
-    dist.barrier()
-    elapsed = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)  # rank 1 is the slow one
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        np.save(os.path.join(out_dir, "gathered.npy"), torch.cat(gathered).numpy())
-        np.save(os.path.join(out_dir, "tmax.npy"), elapsed.numpy())
-    dist.barrier()
-    dist.destroy_process_group()
+    weak = bench.shard_plan(bench.parse(["--envs", "16"]), rank, world)
+    strong = bench.shard_plan(bench.parse(["--envs-total", "33"]), rank, world)
+    lo, hi, total, _ = weak
+    acts = cell_centre_actions(cfg, 7, lo, hi, total, bench.ALTITUDES)
+    calls = []
+
+    def run_steps(k):  # rank 1 is the slow one
+        for _ in range(k):
+            time.sleep(0.004 * (rank + 1))
+            calls.append(1)
+
+    per_rank, tmax = bench.timed_region(run_steps, 5, lambda: None, ranks)
+    value = bench.aggregate_rate(total, 5, tmax)
+    np.save(os.path.join(out_dir, f"acts{rank}.npy"), acts)
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+        json.dump({"weak": weak, "strong": strong, "per_rank": per_rank, "tmax": tmax, "value": value, "calls": len(calls)}, fh)
+    ranks.close()
 
 
-def test_two_rank_sharding_and_timing(tmp_path):
+def test_two_rank_sharding_and_timing_through_bench_functions(tmp_path):
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.vec_env import cell_centre_actions
+    import bench
 
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    full = cell_centre_actions(EngineConfig(x_dim=50, y_dim=50), 7, 0, 32, 32, list(range(5, 15)))
-    assert np.array_equal(np.load(tmp_path / "gathered.npy"), full)
-    tmax = float(np.load(tmp_path / "tmax.npy")[0])
-    assert abs(tmax - 0.020) < 1e-12
-    value = 32 * 5 / tmax  # whole-job units / max-over-ranks time
-    assert abs(value - 8000.0) < 1e-6
+    out = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    # shards: contiguous, disjoint, covering; weak = 16 per rank, strong = 33 split 16 / 17
+    assert [o["weak"] for o in out] == [[0, 16, 32, "weak"], [16, 32, 32, "weak"]]
+    assert [o["strong"] for o in out] == [[0, 16, 33, "strong"], [16, 33, 33, "strong"]]
+    full = cell_centre_actions(EngineConfig(x_dim=50, y_dim=50), 7, 0, 32, 32, bench.ALTITUDES)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"acts{r}.npy") for r in range(world)]), full)
+    # timing: exactly 5 steps each; every rank sees the same per-rank list; the max is rank 1's time (>= 5 x 8 ms);
+    # rank 0's own time includes waiting at the closing barrier, so it is >= its own 20 ms of work
+    for o in out:
+        assert o["calls"] == 5 and len(o["per_rank"]) == 2
+        assert o["per_rank"] == out[0]["per_rank"] and o["tmax"] == out[0]["tmax"]
+        assert o["tmax"] == max(o["per_rank"]) and o["tmax"] >= 0.040 and o["per_rank"][0] >= 0.020
+        assert abs(o["value"] - 32 * 5 / o["tmax"]) < 1e-9
+
+
+def test_self_launch_decision_and_command(monkeypatch):
+    import bench
+
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    args = bench.parse(argv)
+    cmd = bench.launch_command(args, argv, 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-len(argv) - 1].endswith("bench.py") and cmd[-len(argv):] == argv
+    seen = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(c, env=None):
+        seen.append((c, env))
+        return Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    # ranks started by a launcher (WORLD_SIZE set) and single-GPU runs never re-launch
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.maybe_self_launch(args, argv)
+    monkeypatch.delenv("WORLD_SIZE")
+    bench.maybe_self_launch(bench.parse([]), [])
+    assert seen == []
+    # N > 1 without a launcher: one child launcher, its exit code is ours; torch has not been imported by bench itself
+    try:
+        bench.maybe_self_launch(args, argv)
+        raise AssertionError("expected SystemExit")
+    except SystemExit as exc:
+        assert exc.code == 7
+    assert len(seen) == 1 and seen[0][0][:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert seen[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -147,12 +147,21 @@ def test_greedy_scoring_and_mission(golden):
     pl = GreedyPlanner(EngineConfig(x_dim=10, y_dim=10), 6, 10, 2, UAV, adaptive=True, state="factor")
     pl.reset(white_noise=g["mission_white"])
     eps_iter = iter(g["mission_eps"])
-    wps, rewards, budget = pl.run(60.0, meas_noise_fn=lambda a: next(eps_iter))
-    n = min(len(wps), len(g["mission_waypoints"]))
-    same = [np.array_equal(wps[i], g["mission_waypoints"][i]) for i in range(n)]
-    assert same[0]
-    if all(same) and len(wps) == len(g["mission_waypoints"]):
-        assert abs(budget - g["mission_budget"][-1]) < 1e-9
-        tr = float(pl.engine.read_diag(0).sum())
-        assert abs(tr - g["mission_traces"][-1]) < 1e-3
-        assert np.max(np.abs(pl.engine.read_mean(0).cpu().numpy() - g["mission_final_mean"])) < TOL
+    trace = []
+    wps, rewards, budget = pl.run(60.0, meas_noise_fn=lambda a: next(eps_iter), trace=trace)
+    want = g["mission_waypoints"]
+    same = [i < len(wps) and np.array_equal(wps[i], want[i]) for i in range(len(want))]
+    if not all(same):
+        # the only legitimate way to leave the reference's path: at the first differing step the reference's waypoint is
+        # a candidate whose reward ties with ours within the fp32 parity tolerance (argmax over near-equal rewards)
+        i = same.index(False)
+        cands, r = trace[i]
+        j = np.nonzero((cands == want[i]).all(axis=1))[0]
+        assert len(j) == 1, f"step {i}: the reference's waypoint {want[i]} is not among the candidates"
+        assert r.max() - r[j[0]] < TOL, f"step {i}: chose {wps[i]} (reward {r.max()}) over {want[i]} (reward {r[j[0]]}): not a tie"
+        pytest.skip(f"waypoint {i} is a tie within {TOL}: the rest of the mission cannot be compared")
+    assert len(wps) == len(want)
+    assert abs(budget - g["mission_budget"][-1]) < 1e-9
+    tr = float(pl.engine.read_diag(0).sum())
+    assert abs(tr - g["mission_traces"][-1]) < 1e-3
+    assert np.max(np.abs(pl.engine.read_mean(0).cpu().numpy() - g["mission_final_mean"])) < TOL

@@ -180,9 +180,11 @@ def test_out_of_place_fork_and_predict_only(state, window_rows):
     del eng2
 
 
-def test_fullsize_invariants_and_sharding_equivalence():
+@pytest.mark.parametrize("window_rows", [0, -1])
+def test_fullsize_invariants_and_sharding_equivalence(window_rows):
     """cfg2 size (4096 envs, 50x50, factor state): trace monotone, reward >= 0, cached diag == diag(P0 - U U^T) on
-    sampled envs, and a 2-way shard (2 engines x 2048 envs) reproduces every env's result bit for bit."""
+    sampled envs, and a 2-way shard (2 engines x 2048 envs) reproduces every env's result bit for bit -- on the exact
+    path (k_prepare + k_gain) and on the bench's path (window from the prior, fused k_step_factor)."""
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.vec_env import cell_centre_actions
     import torch
@@ -190,8 +192,10 @@ def test_fullsize_invariants_and_sharding_equivalence():
     B, dim, steps = 4096, 50, 6
     cfg = EngineConfig(x_dim=dim, y_dim=dim)
     alts = [float(a) for a in range(5, 15)]
-    full, _ = make(dim, state="factor", capacity=B, rank_cap=64)
-    halves = [make(dim, state="factor", capacity=B // 2, rank_cap=64)[0] for _ in range(2)]
+    kw = dict(window_rows=window_rows, fixed_prior=window_rows < 0)
+    full, _ = make(dim, state="factor", capacity=B, rank_cap=64, **kw)
+    halves = [make(dim, state="factor", capacity=B // 2, rank_cap=64, **kw)[0] for _ in range(2)]
+    assert full.info.window_rows == (10 if window_rows < 0 else 0)
     white = full.normal(B * dim * dim, seed=7).reshape(B, -1)
     full.reset(white_noise=white)
     for h, eng in enumerate(halves):
@@ -275,14 +279,16 @@ def test_vec_env_staggered_schedule_and_determinism():
         assert np.allclose(prev[done], [2.0, 2.0, 14.0]) and np.allclose(prev[~done], acts[~done])
     for e in range(B):
         assert np.array_equal(host(envs[0].ground_truth(e)), host(envs[1].ground_truth(e)))
-    # the staged fields are a pure function of (seed, reset-call counter): a third party can regenerate one
+    # the staged fields are a pure function of (seed, global env id, episode index): a third party can regenerate one
     env = envs[0]
     last_p = env._phase_ending_at(steps - 1)
     ids = env._reset_ids_host[last_p]
-    calls_before = steps  # one staging call per step with a non-empty phase (every phase is non-empty here), +1 ahead
-    white = env.engine.normal(len(ids) * dim * dim, env.seed, (env.env_id_offset << 24) + calls_before + 1)
-    gt = env.engine.generate_grf(white.reshape(len(ids), -1))
-    assert np.array_equal(host(gt[0]), host(env.ground_truth(int(ids[0]))).reshape(-1))
+    e0 = int(ids[0])
+    white = torch.empty((1, dim * dim), dtype=torch.float32, device="cuda")
+    env.engine.normal_rows(white, dim * dim, env.seed, env.GT_STREAM + int(env.episode[e0]) - 1, row_ids=[e0],
+                           row_offset=env.env_id_offset)
+    gt = env.engine.generate_grf(white)
+    assert np.array_equal(host(gt[0]), host(env.ground_truth(e0)).reshape(-1))
 
 
 def test_philox_normals_deterministic_and_standard():
@@ -351,7 +357,7 @@ def test_vec_env_shuffled_priors_vs_oracle():
     # one env step by step against the oracle with that env's drawn prior
     e = 0
     env.reset()
-    sv, ls = env._prior_scale(np.array([e]), env.t)[0]
+    sv, ls = env._prior_scale(np.array([e]), env.episode[e] - 1)[0]  # the draw of the episode that reset() just started
     P = orc.matern_prior(ocfg, sv, ls)
     prev = np.array([2.0, 2.0, 14.0])
     info = {"mean": 0.5 * np.ones((dim, dim)), "value_threshold": 0.4, "interval_factor": 0.0}

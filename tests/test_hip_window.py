@@ -55,8 +55,9 @@ def test_window12_episode_vs_golden(golden, name, tile_threads):
 
 def test_window0_and_huge_window_agree_and_count_formula_bytes():
     """window_rows = 0 (tile-workgroup kernel) and a window larger than the grid (workgroup-per-item kernel with every
-    tile active) are the same mathematics: results agree to rounding and both count the full-column formula bytes
-    (the fused kernel reads mean / diag once more for its mask: + 8 N bytes per committed step, counted as such)."""
+    tile active) are the same mathematics: results agree to rounding and both count the full-column formula bytes of
+    SURVEY 8(d), 4 N (r + m) + 16 N per committed step (the fused kernel reads mean / diag once more for its mask: 8 N
+    bytes per committed step, reported separately by ipp_streamed_bytes_detail)."""
     dim = 20
     a_eng, b_eng = engine(dim, 0, 128), engine(dim, 1000, 256)
     rs = np.random.RandomState(4)
@@ -76,7 +77,8 @@ def test_window0_and_huge_window_agree_and_count_formula_bytes():
         total += 4.0 * dim * dim * (r_before + m) + 16.0 * dim * dim
         assert abs(float(ra[0]) - float(rb[0])) < 1e-6
         prev = a
-    assert a_eng.streamed_bytes() == int(total) and b_eng.streamed_bytes() == int(total + 12 * 8.0 * dim * dim)
+    assert a_eng.streamed_bytes(reset=False) == int(total) and a_eng.streamed_bytes_detail() == (int(total), 0)
+    assert b_eng.streamed_bytes_detail() == (int(total), int(12 * 8.0 * dim * dim))  # second read of mean / diag (mask)
     assert np.max(np.abs(host(a_eng.read_cov(0)) - host(b_eng.read_cov(0)))) < 1e-6
 
 
