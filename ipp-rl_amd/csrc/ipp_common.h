@@ -34,6 +34,7 @@ __device__ unsigned long long g_timeline[8 * kTimelineItems];  // per item: star
 namespace ipp {
 
 constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kCountSlots = 64;    // byte-counter slots (View::counters)
 #ifndef IPP_PREP_THREADS
 #define IPP_PREP_THREADS 128
 #endif
@@ -117,7 +118,11 @@ struct View {
     double* prior;   // [cap][2]  (sigma^2, l)
     int* rank;       // [cap]
     int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
-    unsigned long long* counters;  // [16]: [0] streamed floats (SURVEY 8(d) count), [8] floats re-read for the mask; [1..7] debug timing
+    // kCountSlots slots of 16 words (128 B apart): a workgroup adds its totals to slot (item % kCountSlots), word 0 =
+    // streamed floats (SURVEY 8(d) count), word 8 = floats re-read for the mask.  One address for all workgroups cost
+    // 5 % (one counter) / 19 % (two) of the fused step kernel: the waves' exits queued up behind same-address atomics.
+    // (slot 0, words 1..7: debug phase timing)
+    unsigned long long* counters;
     float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]
     uint64_t cov_slot;  // floats per env slot
     // per-call scratch

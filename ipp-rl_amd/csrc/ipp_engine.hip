@@ -166,7 +166,7 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_prior = o; o += up(cap * 2 * 8);
     L.off_rank = o; o += up(cap * 4);
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(cap * (uint64_t)c.rank_cap * 4) : 0;
-    L.off_cnt = o; o += up(128);
+    L.off_cnt = o; o += up((uint64_t)kCountSlots * 128);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
     L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
@@ -1066,11 +1066,14 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
     if (!e || !bytes) return fail(-1, "null argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
-    unsigned long long cnt[9] = {};
+    static_assert(kCountSlots * 16 <= 1024, "counter slots");
+    unsigned long long cnt[kCountSlots * 16] = {};
     HIP_TRY(hipMemcpyAsync(cnt, e->v.counters, sizeof cnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *bytes = (uint64_t)cnt[0] * 4;
-    if (mask_reread_bytes) *mask_reread_bytes = (uint64_t)cnt[8] * 4;
+    uint64_t units = 0, extra = 0;
+    for (int k = 0; k < kCountSlots; ++k) { units += cnt[16 * k]; extra += cnt[16 * k + 8]; }
+    *bytes = units * 4;
+    if (mask_reread_bytes) *mask_reread_bytes = extra * 4;
 #if IPP_PHASE_TIMING
     {
         unsigned long long c[8];
@@ -1086,7 +1089,7 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
         if (FILE* f = fopen(path, "wb")) { fwrite(tl.data(), 8, n, f); fclose(f); }
     }
 #endif
-    if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, 128, s));
+    if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, (size_t)kCountSlots * 128, s));
     return 0;
 }
 

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
     if (tid == 0) {  // traffic accounting: rows streamed (+ appended) on this tile, mean / diag read (+ write)
         const int valid = max(0, min(v.tile_cells, v.N - tile * v.tile_cells));
         const unsigned long long units = (unsigned long long)(rows + (h.commit ? m + 4 : 2)) * valid;
-        atomicAdd(v.counters, units);
+        atomicAdd(v.counters + (size_t)((item * 5 + tile) & (kCountSlots - 1)) * 16, units);
     }
     if (!h.commit) return;
     float outv[VEC];

@@ -396,8 +396,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     // adds the per-tile sums in TILE order -- the tiles are handed out dynamically, so which wave reduced which tile
     // differs from run to run, but neither the per-tile values nor their order do: the reward is bit-reproducible by
     // construction -- and writes the item's reward, rank and the span of the appended columns.
-    if (lane == 0 && units) atomicAdd(v.counters, units);
-    if (lane == 0 && extra) atomicAdd(v.counters + 8, extra);
+    // byte counters: per workgroup in LDS, then one pair of global atomics by the last wave, spread over slots
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(red);  // red[0..1], zeroed with the tile counter
+    if (lane == 0 && units) atomicAdd(cnt, units);
+    if (lane == 0 && extra) atomicAdd(cnt + 1, extra);
     int reset_k = -1;
     if (RESET && ar->src) reset_k = __builtin_amdgcn_readfirstlane(ar->src[item]);
     if (RESET && reset_k >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores / atomics have landed
@@ -416,6 +418,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
         if (commit_item && !CHAIN) v.rank[h.dst] = r + m;
         if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); }
+        unsigned long long* slot = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
+        if (cnt[0]) atomicAdd(slot, cnt[0]);
+        if (cnt[1]) atomicAdd(slot + 8, cnt[1]);
     }
     if (commit_item && !CHAIN && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
     if (RESET && reset_k >= 0) wave_reset_env(v, *ar, h.dst, reset_k, lane);  // (after the rank store above, same lane 0)
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     }
     const float* __restrict__ blk = q_all + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]
     for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
-    if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; }
+    if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
     fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
     {

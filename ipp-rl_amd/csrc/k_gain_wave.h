@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
     if (lane == 0) {
         reward_out[item] = (float)(item_part / (h.cost_d + 1.0));  // rewards.py:31
         if (h.commit) v.rank[h.dst] = r + m;
-        if (units) atomicAdd(v.counters, units);
+        if (units) atomicAdd(v.counters + (size_t)(item & (kCountSlots - 1)) * 16, units);
     }
     if (h.commit && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
 }

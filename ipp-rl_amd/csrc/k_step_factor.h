@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     // ---- phase A: header, observation, gather of HT(i,k) = work[k*QS + i].  While the footprint-dependent loads are
     // in flight the workgroup builds the prior table and the block tables (pure arithmetic on the header).
     auto mid = [&](const ItemHdr& hh) {
-        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; }
+        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
         // adaptive mask of the whole env (rewards.py:11: pre-step mean and pre-step diag), one byte per VEC cells: the
         // tile loop then needs neither mean nor diag (their updates are no-return atomics)

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     // ---- phase A; under the footprint-dependent loads: tables, mask bits of the touched tiles (root mean, parent
     // diag), and the new node's diagonal starts as a copy of its parent's (the tile epilogues subtract from it)
     auto mid = [&](const ItemHdr& hh) {
-        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; }
+        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
         typedef float cellv __attribute__((ext_vector_type(VEC)));
         const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
