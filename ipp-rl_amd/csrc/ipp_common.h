@@ -107,6 +107,7 @@ struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL
     int mode, cap, rank_cap, max_batch;
     int window_rows, tile_cells;
+    int win_tiles;  // windowed factor state: most tiles [t_lo, t_hi] one step can touch (n_tiles when not windowed)
     int meas_cap, fp_cap, q_stride, q_rows;
     uint64_t q_item;  // floats of Q scratch per item: (q_rows + 2*kPipe pad rows) * q_stride
     double res, tanx, tany, rf_alt, coeff_a, coeff_b, sv0, ls0, vmax, amax, thr, kf;
@@ -123,6 +124,7 @@ struct View {
     // 5 % (one counter) / 19 % (two) of the fused step kernel: the waves' exits queued up behind same-address atomics.
     // (slot 0, words 1..7: debug phase timing)
     unsigned long long* counters;
+    int* tickets;    // [kTicketSlots] item ticket counters of the pipelined step kernel, one per launch in flight (k_step_pipe.h)
     float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]
     uint64_t cov_slot;  // floats per env slot
     // per-call scratch

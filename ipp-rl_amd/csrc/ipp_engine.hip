@@ -17,6 +17,7 @@
 #include "k_gain.h"
 #include "k_gain_factor.h"
 #include "k_step_factor.h"
+#include "k_step_pipe.h"
 #include "k_gain_wave.h"
 #include "k_misc.h"
 #include "k_grf_dft.h"
@@ -75,6 +76,10 @@ struct Engine {
     bool profile = false;
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
+    bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
+    size_t pipe_lds = 0;
+    int pipe_grid = 0;    // resident workgroups of k_step_pipe on this device
+    unsigned launch_seq = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_prep[8] = {};
@@ -84,7 +89,7 @@ struct Engine {
 
 struct Layout {
     int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
-    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
+    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
         off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, total, cov_slot_floats;
 };
 
@@ -152,6 +157,11 @@ int plan(const ipp_config& c, Layout& L) {
         // windowed factor state: one workgroup per item, wave-granular tiles of 64 * VEC cells (k_gain_factor.h);
         // tile_threads is the workgroup size (waves share the item's Q block and prior table in LDS)
         L.T = (c.tile_threads > 0) ? c.tile_threads : 256;  // 256: fused workgroup kernel (k_step_factor.h), 64: one wave per item (k_gain_wave.h)
+        // Large batches of short items on large grids (BASELINE configs[2]: 32768 envs of 100x100, ranks <= 144, ~10 tiles
+        // of ~20 rows per item): the per-item latency chain of the fused kernel and its workgroup-granular dispatch leave
+        // the stream at 32 % of peak; the prologue as its own kernel + a 128-thread gain kernel streams at 50 % and is 15 %
+        // faster per step with the two pipelined over 4 chunks.  Tree steps need the fused layout.
+        if (c.tile_threads <= 0 && c.node_capacity <= 0 && (n4 + 63) / 64 >= 24 && c.capacity >= 8192 && c.rank_cap <= 192) L.T = 128;
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;
@@ -167,6 +177,7 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_rank = o; o += up(cap * 4);
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(cap * (uint64_t)c.rank_cap * 4) : 0;
     L.off_cnt = o; o += up((uint64_t)kCountSlots * 128);
+    L.off_tick = o; o += up((uint64_t)kTicketSlots * 4);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
     L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
@@ -296,6 +307,13 @@ template <int MC, int VEC>
 void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
                   const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
                   hipEvent_t prep_done, const AutoReset& ar) {
+    if (e->pipe && !ar.src) {  // persistent producer / consumer workgroups drawing items from a ticket counter
+        const int slot = (int)(e->launch_seq++ & (kTicketSlots - 1));
+        timed_launch(e, 0, k_step_pipe<MC, VEC>, dim3(std::min(n, e->pipe_grid)), dim3(kPipeThreads), e->pipe_lds, s, v, env_ids, n, action,
+                     prev, noise, flags, e->lut_rows, status, reward, slot);
+        if (prep_done) (void)hipEventRecord(prep_done, s);
+        return;
+    }
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
         timed_launch(e, 0, k_step_factor<MC, VEC>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev, noise,
                      flags, e->lut_rows, status, reward, ar);
@@ -336,7 +354,9 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
                 const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
                 const AutoReset& ar) {
     int chunks = e->step_chunks;
-    if (chunks <= 0) chunks = 1;  // measured on MI355X: no gain from 2 chunks, slower from 4; opt in with IPP_STEP_CHUNKS
+    // measured on MI355X: at 4096 items of 50x50 no gain from 2 chunks, slower from 4; at 32768 items of 100x100 on the
+    // split path 4 chunks hide most of the prologue kernel under the previous chunk's gain kernel
+    if (chunks <= 0) chunks = (!e->fused && e->v.mode == IPP_FACTOR && e->v.window_rows > 0 && e->v.T == 128 && n >= 16384) ? 4 : 1;
     if (e->profile) chunks = 1;  // kernels are timed alone (bench.py roofline leg)
     chunks = std::min(chunks, kMaxChunks);
     if (chunks <= 1 || !e->side) {
@@ -500,8 +520,15 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.rank = reinterpret_cast<int*>(base + L.off_rank);
     v.colspan = reinterpret_cast<int*>(base + L.off_span);
     v.counters = reinterpret_cast<unsigned long long*>(base + L.off_cnt);
+    v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
     v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
+    v.win_tiles = v.n_tiles;
+    if (v.window_rows > 0) {
+        // rows a step can touch: the footprint (ny <= m <= MC blocks of rf <= 2 rows) + window_rows on both sides
+        const long rows = std::min<long>(v.H, 2L * v.window_rows + 2L * L.MC);
+        v.win_tiles = (int)std::min<long>(v.n_tiles, (rows * v.W + v.tile_cells - 1) / v.tile_cells + 1);
+    }
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;
     v.hdr = reinterpret_cast<ItemHdr*>(base + L.off_hdr);
@@ -549,11 +576,19 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         while (e->lut_rows > 0 && (size_t)e->lut_rows * v.W > 12288) --e->lut_rows;  // <= 48 KiB
         const int lutf = e->lut_rows * v.W;
         if (v.meas_cap == 9)
-            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.n_tiles, v.Npad / 4)
-                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.n_tiles);
+            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, v.win_tiles * kWave)
+                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles);
         else
-            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.n_tiles, v.Npad / 2)
-                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.n_tiles);
+            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave)
+                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles);
+        if (e->fused) {
+            e->pipe_lds = (v.meas_cap == 9) ? PipeLds<9>::bytes(v.rank_cap, lutf, v.win_tiles) : PipeLds<25>::bytes(v.rank_cap, lutf, v.win_tiles);
+            e->pipe = e->pipe_lds <= 160 * 1024;
+            // off by default: one producer wave needs ~50 us per item against ~37 us of its three consumers, so the
+            // pipeline is producer-bound (0.357 vs 0.313 ms at 4096 items of 50x50); IPP_PIPE=1 opts in
+            const char* pp = getenv("IPP_PIPE");
+            e->pipe = e->pipe && pp && atoi(pp) != 0;
+        }
         if (v.T == kWave)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;
@@ -581,6 +616,17 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    if (e->pipe) {
+        const void* kfn = (v.meas_cap == 9) ? reinterpret_cast<const void*>(&k_step_pipe<9, 4>) : reinterpret_cast<const void*>(&k_step_pipe<25, 2>);
+        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->pipe_lds);
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPipeThreads, e->pipe_lds) != hipSuccess || per_cu <= 0) per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+        if (const char* g = getenv("IPP_PIPE_WGS")) per_cu = atoi(g);  // experiments: workgroups per CU
+        e->pipe_grid = per_cu * cus;
+        if (e->pipe_grid <= 0) e->pipe = false;
+        (void)hipGetLastError();
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);

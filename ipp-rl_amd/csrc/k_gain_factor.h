@@ -26,7 +26,7 @@
 #define IPP_SF_PIPE 10  // same, fused step kernel (A/B on MI355X: 6..12 within 3 %, 10 the most consistent)
 #endif
 #ifndef IPP_GF_ABLATE
-#define IPP_GF_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no row stream, 8 = no compaction
+#define IPP_GF_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no row stream, 8 = no compaction, 16 = no mean / diag atomics, 32 = no new-row stores
 #endif
 #ifndef IPP_GF_MINWAVES
 #define IPP_GF_MINWAVES 4
@@ -44,7 +44,7 @@ struct GainLds {
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
     int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
-    double* tile_red;  // [n_tiles] masked trace reduction of every tile of the item (summed in tile order at the end)
+    double* tile_red;  // [win_tiles] masked trace reduction of every touched tile (summed in tile order at the end)
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
                                             int n_tiles, int mask_bytes = 0) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
@@ -56,6 +56,7 @@ struct GainLds {
     // work: HT staging rows of the fused prologue (0 floats for the stand-alone kernel); lut: prior table;
     // small: the fused prologue's fp64 scratch (0 floats for the stand-alone kernel)
     // mask_bytes > 0 (fused kernel): no mean / diag staging area, the env's mask bytes instead
+    __device__ __forceinline__ GainLds() {}
     __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
                                        int n_tiles, int mask_bytes = 0) {
         Ls = reinterpret_cast<float*>(base);
@@ -105,7 +106,8 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // the accumulators hold Wc L = P[:,F] H_F^T per cell, and the tile epilogue applies L^-1 (upper triangular, 45 FMAs
 // per cell) once lds.solve_flag says wave 0 has finished the m x m algebra.  The stream therefore starts right
 // after the gather instead of after S / Cholesky / L^-1 / Q.
-// LMASK (fused kernel): the adaptive mask of the whole env was put into lds.mask4 by phase A and mean / diag are
+// LMASK (fused kernel): the adaptive mask of the touched tiles [t_lo, t_hi] was put into lds.mask4 by phase A (one byte
+// per VEC cells, indexed from tile t_lo; View::win_tiles bounds the tile count) and mean / diag are
 // updated with no-return float atomics (one add per cell, bit-identical to load + add + store): the tile loop has no
 // mean / diag loads, whose latency sat in front of every tile's stream.
 // CHAIN (ipp_tree_step): the streamed columns come from a chained tree state (cc), the m new columns go to the new
@@ -115,7 +117,8 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // aliasing); the caller guarantees the rows are complete and visible before the call and unchanged during it.
 // RESET (ipp_step_autoreset): an item with ar->src[item] >= 0 resets its env once its step is complete: every wave
 // waits for its own stores / atomics before it counts itself done, the last wave then rewrites the env's planes.
-template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false, bool RESET = false>
+// NW > 0: that many waves of the workgroup run the tile loop of this item (k_step_pipe: the consumer waves), else all.
+template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false, bool RESET = false, int NW = 0>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out, const ChainCols* cc = nullptr,
@@ -127,7 +130,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     int* next_tile = lds.next_tile; int* done_waves = lds.done_waves; const int* span_s = lds.span_s;
     const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
     const int tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = T / kWave;
+    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = NW > 0 ? NW : T / kWave;
     const int m = h.m, r = h.rank;
     const float s3 = (float)(kSqrt3 * v.res) / h.ls;
     typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -146,7 +149,9 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const unsigned long long loop0_ = wall_clock64();
 #endif
 
-    // tiles are handed out dynamically (LDS counter): a wave that finishes a short tile takes the next one
+    // tiles are handed out dynamically (LDS counter): a wave that finishes a short tile takes the next one, in address
+    // order.  (Handing them out from the footprint's tile outwards -- longest first -- measured 3-9 % SLOWER on every
+    // config: neighbouring tiles streamed at the same time share DRAM pages of the same stored rows.)
     for (;;) {
         int tile = 0;
         if (lane == 0) tile = h.t_lo + atomicAdd(next_tile, 1);
@@ -317,7 +322,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         float mean_in[VEC], diag_in[VEC];
         unsigned mbits = 0xffu;
         if (LMASK) {
-            mbits = lds.mask4[tile * kWave + lane];
+            mbits = lds.mask4[(tile - h.t_lo) * kWave + lane];
         } else {
             const float* st = stage_w + lane * VEC;
 #pragma unroll
@@ -363,7 +368,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 float* mu = v.mean + (size_t)h.dst * npad + cell0;
 #pragma unroll
                 for (int c = 0; c < VEC; ++c)
-                    if (cell0 + c < v.N) {
+                    if (cell0 + c < v.N && !((IPP_GF_ABLATE & 16) && acc[0][0] != 12345.f)) {
                         unsafeAtomicAdd(dg + c, -dred[c]);
                         if (!(flags & IPP_COV_ONLY)) unsafeAtomicAdd(mu + c, dmean[c]);
                     }
@@ -379,7 +384,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
 #pragma unroll
             for (int j = 0; j < MC; ++j)
-                if (j < m) {
+                if (j < m && !((IPP_GF_ABLATE & 32) && acc[0][0] != 12345.f)) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
                     store_stream<VEC>((CHAIN ? new_cols + (size_t)j * npad : cov_dst + (size_t)(r + j) * npad) + cell0, outv);
@@ -407,12 +412,13 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     int arrived = 0;
     if (lane == 0) arrived = atomicAdd(done_waves, 1);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (!CHAIN && arrived == 0 && lane == 0) IPP_MARK(item, 6);  // first wave out
     if (arrived != nw - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (PRE) dead = __hip_atomic_load(lds.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without tiles never looked)
     const bool commit_item = h.commit && !dead;
     if (lane == 0) {
-        if (PRE && !CHAIN) IPP_MARK(item, 2);
+        if (!CHAIN) IPP_MARK(item, 2);
         double tot = 0.0;
         for (int t = 0; t <= h.t_hi - h.t_lo; ++t) tot += lds.tile_red[t];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
                                                                    float* __restrict__ reward_out) {
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.n_tiles);
+    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;

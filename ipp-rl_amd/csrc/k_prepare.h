@@ -82,7 +82,15 @@ struct NoMidWork { __device__ __forceinline__ void operator()(const ItemHdr&) co
 //   mid_work     called once between issuing the footprint-dependent loads and consuming them (free compute slot)
 //   CHAIN / cc   factor columns come from a chained tree state (ChainCols) instead of the env's own slab; rank_chain
 //                is then the state's column count
-template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid, bool CHAIN = false>
+// WAVE (NT == 64): the caller is ONE wave of a larger workgroup (the producer wave of k_step_pipe): every barrier of the
+// prologue becomes a wave-level LDS fence instead of a workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync();
+template <bool WAVE>
+__device__ __forceinline__ void prep_sync() {
+    if (WAVE) wave_lds_sync(); else __syncthreads();
+}
+
+template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid, bool CHAIN = false, bool WAVE = false>
 __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int item, const int* __restrict__ env_ids,
                                                     const int* __restrict__ dst_ids, const double* __restrict__ action,
                                                     const double* __restrict__ prev_action,
@@ -109,7 +117,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // barrier), (2) everything that does (ground-truth crop, mean at the footprint, the first pass of U rows).
     constexpr int MP = (MC <= 16) ? 16 : 32;  // lanes per streaming index: i = tid % MP, no runtime division
     constexpr int KS = kPrepThreads / MP;     // rows of U gathered per step of a pass
-    constexpr int UN = (kPrepThreads >= 256) ? 12 : 8;  // rows per thread and pass, all in flight together
+    constexpr int UN = (kPrepThreads >= 256) ? 12 : (WAVE ? 12 : 8);  // rows per thread and pass, all in flight together
 
     // ------------------------------------------------------------------ batch 1
     const int env0 = env_ids ? env_ids[item] : item + v.env_base;
@@ -209,7 +217,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         }
         for (int i = tid; i < MC * MC; i += kPrepThreads) { linv_f[i] = 0.f; if (linv_f2) linv_f2[i] = 0.f; }
         for (int i = tid; i < MC; i += kPrepThreads) { y_f[i] = 0.f; if (y_f2) y_f2[i] = 0.f; }
-        __syncthreads();  // *hs visible to the caller's threads
+        prep_sync<WAVE>();  // *hs visible to the caller's threads
         if ((flags & IPP_UPDATE_PREV) && tid == 0) {
             double* pw = const_cast<double*>(prev_action);
             pw[3 * item + 0] = ax; pw[3 * item + 1] = ay; pw[3 * item + 2] = az;
@@ -229,7 +237,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
 #pragma unroll
     for (int u = 0; u < UN; ++u) asm volatile("" : : "v"(sp_pre[u]));
     IPP_TICK(v, 1, tick);
-    if (FRONT_ONLY && threadIdx.x == 0) IPP_MARK(item, 3);
+    if ((FRONT_ONLY || WAVE) && threadIdx.x == 0) IPP_MARK(item, 3);
 
     // ------------------------------------------------------------------ batch 2: footprint-dependent loads
     // (a) ground-truth crop (simulations/__init__.py:24-25), one cell per thread (f <= FC <= threads)
@@ -321,9 +329,20 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         asm volatile("" : "+v"(gt_f));  // (conversion pinned here, see eps below: hipcc otherwise waits for this load right at its request)
         if (!cov_only && fi < f) sub[fi] = (double)gt_f;
     }
-    __syncthreads();
+    prep_sync<WAVE>();
 
     // ------------------------------------------------------------------ observation + innovation
+    // rf = 2: the INTER_AREA weights of both axes (orows x h and ocols x w entries, <= 2 MC each) are evaluated one
+    // per lane into LDS first (the S / L scratch is free here): computed serially by the m output lanes they were
+    // ~30 fp64 calls with divisions per lane, 10 us of the prologue for 40 % of the items
+    double* wyt = L;           // [orows][h.h]
+    double* wxt = L + 2 * MC;  // [ocols][h.w]
+    if (!cov_only && h.rf > 1) {
+        const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
+        for (int idx = tid; idx < orows * h.h; idx += kPrepThreads) wyt[idx] = area_weight(h.h, orows, idx / h.h, idx % h.h);
+        for (int idx = tid; idx < ocols * h.w; idx += kPrepThreads) wxt[idx] = area_weight(h.w, ocols, idx / h.w, idx % h.w);
+        prep_sync<WAVE>();
+    }
     if (!cov_only) {
         if (tid < m) {
             double val;
@@ -331,14 +350,14 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                 val = sub[tid];
             } else {
                 // cv2.resize(sub, dsize=(ceil(h/rf), ceil(w/rf))) -> width=ceil(h/rf), height=ceil(w/rf)
-                const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
+                const int ocols = (h.h + h.rf - 1) / h.rf;
                 const int orow = tid / ocols, ocol = tid - orow * ocols;
                 val = 0.0;
                 for (int sy = 0; sy < h.h; ++sy) {
-                    const double wy = area_weight(h.h, orows, orow, sy);
+                    const double wy = wyt[orow * h.h + sy];
                     if (wy == 0.0) continue;
                     for (int sx = 0; sx < h.w; ++sx) {
-                        const double wx = area_weight(h.w, ocols, ocol, sx);
+                        const double wx = wxt[ocol * h.w + sx];
                         if (wx != 0.0) val += sub[sy * h.w + sx] * wx * wy;
                     }
                 }
@@ -362,10 +381,10 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         vv[tid] = 0.0;
     }
     IPP_TICK(v, 2, tick);
-    if (FRONT_ONLY && threadIdx.x == 0) IPP_MARK(item, 4);
+    if ((FRONT_ONLY || WAVE) && threadIdx.x == 0) IPP_MARK(item, 4);
 
     if (obs_out) {  // ipp_observe: observation only
-        __syncthreads();
+        prep_sync<WAVE>();
         if (tid < MC) obs_out[(size_t)item * MC + tid] = (tid < m) ? (float)zz[tid] : 0.f;
         if (tid == 0) {
             obs_m[item] = m;
@@ -377,7 +396,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
             if (status_out) status_out[item] = h.status;
             hs->m = 0;  // nothing to stream
         }
-        __syncthreads();
+        prep_sync<WAVE>();
         return hs;
     }
 
@@ -409,9 +428,9 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         for (int a = tid / 32; a < f; a += kPrepThreads / 32)
             for (int b = tid & 31; b < f; b += 32) big[a * (FC + 1) + b] = cov_env[(size_t)cellidx[a] * v.Npad + cellidx[b]];
     }
-    __syncthreads();
+    prep_sync<WAVE>();
     IPP_TICK(v, 3, tick);
-    if (FRONT_ONLY && threadIdx.x == 0) IPP_MARK(item, 5);
+    if ((FRONT_ONLY || WAVE) && threadIdx.x == 0) IPP_MARK(item, 5);
     if ((flags & IPP_UPDATE_PREV) && tid == 0) {
         // every thread has taken its copy of prev_action (batch 1) before the barrier above
         double* pw = const_cast<double*>(prev_action);
@@ -466,7 +485,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
             }
         }
     }
-    __syncthreads();
+    prep_sync<WAVE>();
     IPP_TICK(v, 4, tick);
 
     // ------------------------------------------------------------------ Cholesky S = C C^T (C lower), fp64
@@ -478,14 +497,14 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
             if (!(d > 0.0)) okflag[0] = 0;
             L[c * LD + c] = sqrt(d);
         }
-        __syncthreads();
+        prep_sync<WAVE>();
         if (okflag[0] == 0) break;
         if (tid > c && tid < m) {
             double s = S[tid * LD + c];
             for (int k = 0; k < c; ++k) s -= L[tid * LD + k] * L[c * LD + k];
             L[tid * LD + c] = s / L[c * LD + c];
         }
-        __syncthreads();
+        prep_sync<WAVE>();
     }
     const bool pd = okflag[0] != 0;
     int status = h.status;
@@ -503,7 +522,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                 Li[i * LD + j] = -s / L[i * LD + i];
             }
         }
-        __syncthreads();
+        prep_sync<WAVE>();
         if (tid < m) {  // y = L_inv^T v   (mappings.py:189,196: W v = Wc L^-T v)
             double s = 0.0;
             for (int i = 0; i <= tid; ++i) s += Li[i * LD + tid] * vv[i];
@@ -536,7 +555,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                     }
             }
         }
-        __syncthreads();
+        prep_sync<WAVE>();
         if (tid < m) {  // y = S_inv v
             double s = 0.0;
             for (int i = 0; i < m; ++i) s += Li[tid * LD + i] * vv[i];
@@ -545,9 +564,10 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     } else {
         status = IPP_STATUS_NOT_PD;  // factor form cannot hold an indefinite update
     }
-    __syncthreads();
+    prep_sync<WAVE>();
     IPP_TICK(v, 5, tick);
 
+    if (WAVE && threadIdx.x == 0) IPP_MARK(item, 7);
     // ------------------------------------------------------------------ outputs for the streaming kernels
     const bool dead = (MODE == IPP_FACTOR) && !pd;
     for (int idx = tid; idx < MC * MC; idx += kPrepThreads) {
@@ -752,6 +772,186 @@ __device__ __forceinline__ int solve_wave(const View& v, const ItemHdr& h, const
     return status;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same m x m algebra by one wave with the matrices in REGISTERS (MC = 9; other caps use solve_wave): the LDS
+// version above is a chain of ~40 dependent LDS round trips with a wave fence between them (14-17 us per item, measured
+// in the fused kernels' timelines); here lane i holds row i of S / C and lane j column j of L^-1, wave-uniform values
+// travel through v_readlane, and the factor part of S is summed with one lane per stored column k (no serial loop over
+// the rank).  HT(i,k) = ht[i*si + k*sk].  Also writes Q = -HT^T L^-1 (fp32 rows [k][QS], then 8 zero rows) when q_out is
+// not null: the consumers of k_step_pipe stream against Q, so their tile epilogue needs no L^-1.
+// mapping/mappings.py:178-197.  Same outputs as solve_wave (L^-1 / y in fp32, debug copies in fp64, header, status).
+__device__ __forceinline__ double bcast_lane(double x, int src) {  // src: wave-uniform constant
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int MC>
+__device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, const int item, unsigned flags,
+                                               unsigned char* small, const float* ht, int si, int sk, float* linv_f,
+                                               float* y_f, float* __restrict__ q_out, int* __restrict__ status_out) {
+    static_assert(MC == 9, "register layout written for MC = 9");
+    constexpr int LD = MC + 1;
+    constexpr int QS = (MC + 3) & ~3;
+    const PrepLds<MC> pl(small);
+    double* S = pl.S; double* zz = pl.zz; double* vv = pl.vv;
+    const double* ktab = pl.ktab; const int* bfi = pl.bfi; const int* bcnt = pl.bcnt; const double* bwt = pl.bwt;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int m = h.m, r = h.rank;
+    const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
+    const bool cov_only = (flags & IPP_COV_ONLY) != 0;
+    double* dbg = v.dbg + (size_t)item * (2 * MC * MC + 2 * MC);
+
+    // ---- S, prior part + R: lane p owns pair p = (i <= j), p = j (j + 1) / 2 + i  (45 pairs <= 64 lanes)
+    int pi = 0, pj = 0;
+    {
+        int j = (int)((sqrtf(8.0f * lane + 1.0f) - 1.0f) * 0.5f);
+        while (j * (j + 1) / 2 > lane) --j;
+        while ((j + 1) * (j + 2) / 2 <= lane) ++j;
+        pj = j;
+        pi = lane - j * (j + 1) / 2;
+    }
+    const bool pair_on = pj < m;  // (pi <= pj)
+    double mine = 0.0;
+    if (pair_on) {
+        const int ci = bcnt[pi], cj = bcnt[pj];  // 1, 2 or 4
+        const int sh = (cj == 4) ? 2 : (cj == 2 ? 1 : 0);
+        const double wij = bwt[pi] * bwt[pj];
+        for (int c = 0; c < ci * cj; ++c) {
+            const int fa = bfi[4 * pi + (c >> sh)], fb = bfi[4 * pj + (c & (cj - 1))];
+            const int lya = fa / h.w, lxa = fa - lya * h.w, lyb = fb / h.w, lxb = fb - lyb * h.w;
+            mine += wij * ktab[abs(lya - lyb) * h.w + abs(lxa - lxb)];
+        }
+        if (pi == pj) mine += R;
+    }
+    // ---- factor part: - sum_k HT[i][k] HT[j][k] by the pair's own lane, all pairs in lock step (two LDS reads per k,
+    // eight k in flight; no cross-lane reduction: 45 wave-wide fp64 butterflies through ds_bpermute took 25 us);
+    // fp64 products of fp32 values are exact
+    if (pair_on) {
+        const float* hi = ht + pi * si;
+        const float* hj = ht + pj * si;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = 0;
+        for (; k + 8 <= r; k += 8) {
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x[u] = hi[(k + u) * sk]; y[u] = hj[(k + u) * sk]; }
+            a0 = fma((double)x[0], (double)y[0], a0); a1 = fma((double)x[1], (double)y[1], a1);
+            a2 = fma((double)x[2], (double)y[2], a2); a3 = fma((double)x[3], (double)y[3], a3);
+            a0 = fma((double)x[4], (double)y[4], a0); a1 = fma((double)x[5], (double)y[5], a1);
+            a2 = fma((double)x[6], (double)y[6], a2); a3 = fma((double)x[7], (double)y[7], a3);
+        }
+        for (; k < r; ++k) a0 = fma((double)hi[k * sk], (double)hj[k * sk], a0);
+        mine -= (a0 + a1) + (a2 + a3);
+    }
+    if (pair_on) {
+        S[pi * LD + pj] = mine;
+        S[pj * LD + pi] = mine;
+    }
+    wave_lds_sync();
+
+    // ---- Cholesky S = C C^T in registers: lane i holds row i (c[k] = C[i][k]); the reference uses L = C^T.  mappings.py:185
+    double c[MC];
+#pragma unroll
+    for (int k = 0; k < MC; ++k) c[k] = (lane < m && k < m) ? S[min(lane, MC - 1) * LD + k] : ((k == lane) ? 1.0 : 0.0);
+    if (lane < MC) {  // debug copy of S (tests read it through ipp_debug_step_item)
+#pragma unroll
+        for (int k = 0; k < MC; ++k) dbg[lane * MC + k] = (lane < m && k < m) ? c[k] : 0.0;
+    }
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+        if (j < m) {  // wave-uniform
+            double t = c[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = fma(-c[k], bcast_lane(c[k], j), t);  // - C[i][k] C[j][k]
+            const double d = bcast_lane(t, j);
+            if (!(d > 0.0)) pd = false;
+            const double sq = sqrt(d);
+            c[j] = (lane == j) ? sq : t / sq;  // rows above the diagonal hold junk that is never read
+        }
+    }
+    int status = h.status;
+    // ---- L^-1 = inv(C^T) (upper triangular): lane j holds column j, li[i] = Linv[i][j].  mappings.py:186
+    double li[MC];
+#pragma unroll
+    for (int i = 0; i < MC; ++i) li[i] = 0.0;
+    if (pd) {
+#pragma unroll
+        for (int i = MC - 1; i >= 0; --i) {
+            if (i < m) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = i + 1; k < MC; ++k) {
+                    if (k < m) {
+                        const double cki = bcast_lane(c[i], k);  // C[k][i] = U[i][k]
+                        if (k <= lane) sacc = fma(cki, li[k], sacc);
+                    }
+                }
+                const double cii = bcast_lane(c[i], i);
+                li[i] = (lane == i) ? 1.0 / cii : ((lane > i && lane < m) ? -sacc / cii : 0.0);
+            }
+        }
+    } else {
+        status = IPP_STATUS_NOT_PD;  // factor form cannot hold an indefinite update
+    }
+    const bool dead = !pd;
+    // y = L_inv^T v   (mappings.py:189,196: W v = Wc L^-T v)
+    double yv = 0.0;
+    if (pd && lane < m) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+            if (i <= lane) yv = fma(li[i], vv[i], yv);
+    }
+    if (lane < MC) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const double val = (!dead && i < m && lane < m) ? li[i] : 0.0;
+            linv_f[i * MC + lane] = (float)val;
+            dbg[MC * MC + i * MC + lane] = val;
+        }
+        const double yval = (!dead && !cov_only && lane < m) ? yv : 0.0;
+        y_f[lane] = (float)yval;
+        dbg[2 * MC * MC + lane] = (lane < m) ? zz[lane] : 0.0;
+        dbg[2 * MC * MC + MC + lane] = yval;
+    }
+    if (lane == 0) {
+        ItemHdr ho = h;
+        ho.status = status;
+        ho.fallback = 0;
+        if (dead) { ho.commit = 0; ho.rows = 0; }
+        v.hdr[item] = ho;
+        *pl.hs = ho;
+        if (status_out) status_out[item] = status;
+    }
+    wave_lds_sync();
+    if (q_out) {
+        // Q[k][j] = -sum_{i<=j} HT[i][k] Linv[i][j]: lane <-> k, L^-1 (fp32) broadcast from LDS
+        for (int k0 = 0; k0 < r; k0 += kWave) {
+            const int k = k0 + lane;
+            if (k < r) {
+                float hv[MC], q[QS];
+#pragma unroll
+                for (int i = 0; i < MC; ++i) hv[i] = (i < m) ? ht[i * si + k * sk] : 0.f;
+#pragma unroll
+                for (int j = 0; j < QS; ++j) {
+                    float acc = 0.f;
+                    if (j < MC) {
+#pragma unroll
+                        for (int i = 0; i <= j; ++i) acc = fmaf(hv[i], linv_f[i * MC + j], acc);
+                    }
+                    q[j] = -acc;
+                }
+                float4* dst = reinterpret_cast<float4*>(q_out + (size_t)k * QS);
+#pragma unroll
+                for (int j4 = 0; j4 < QS / 4; ++j4) dst[j4] = make_float4(q[4 * j4], q[4 * j4 + 1], q[4 * j4 + 2], q[4 * j4 + 3]);
+            }
+        }
+        for (int idx = lane; idx < 8 * QS; idx += kWave) q_out[(size_t)r * QS + idx] = 0.f;  // zero rows behind Q (pipeline tail)
+    }
+    return status;
+}
+
 // Stand-alone prologue kernel: one workgroup per item.
 template <int MC, int MODE>
 __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(View v, const int* __restrict__ env_ids,
@@ -767,6 +967,28 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]: one block for the gain kernel
     float* big = reinterpret_cast<float*>(smem + ((prep_small_bytes<MC>() + 15) & ~(size_t)15));
+    if constexpr (MC == 9 && MODE == IPP_FACTOR) {
+        if (!obs_out) {
+            // factor state: the workgroup stops after the gather, wave 0 finishes the m x m algebra in registers and writes
+            // Q (solve_wave_fast): the block-wide LDS Cholesky took ~15 us of a ~45 us item
+            ItemHdr* hs = prepare_item_ex<MC, MODE, kPrepThreads, true>(v, item, env_ids, dst_ids, action, prev_action, meas_noise, flags,
+                                                                        status_out, nullptr, nullptr, nullptr, smem, big, 0, 1, nullptr,
+                                                                        v.linv + (size_t)item * MC * MC, blk_out, v.yv + (size_t)item * MC,
+                                                                        blk_out + MC * MC, nullptr, NoMidWork());
+            if (threadIdx.x >= kWave) return;
+            const ItemHdr h = uniform_hdr(*hs);
+            if (h.m == 0) return;
+            const PrepLds<MC> pl(smem);
+            float* Ls = reinterpret_cast<float*>(pl.L);  // (the L scratch is free: 90 doubles >= 81 + 9 floats)
+            float* ys = Ls + MC * MC;
+            solve_wave_fast<MC>(v, h, item, flags, smem, big, (h.rank + 3) & ~3, 1, Ls, ys, blk_out + LQ, status_out);
+            wave_lds_sync();
+            const int lane = threadIdx.x;
+            for (int i = lane; i < MC * MC; i += kWave) { const float x = Ls[i]; v.linv[(size_t)item * MC * MC + i] = x; blk_out[i] = x; }
+            if (lane < MC) { const float x = ys[lane]; v.yv[(size_t)item * MC + lane] = x; blk_out[MC * MC + lane] = x; }
+            return;
+        }
+    }
     prepare_item<MC, MODE, kPrepThreads>(v, item, env_ids, dst_ids, action, prev_action, meas_noise, flags, status_out,
                                          obs_out, obs_m, obs_shape, smem, big, 0, 1, blk_out + LQ,
                                          v.linv + (size_t)item * MC * MC, blk_out, v.yv + (size_t)item * MC,

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
     const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.n_tiles, v.Npad / VEC);
+                          kStepThreads / kWave, v.win_tiles, v.win_tiles * kWave);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
                     const bool in = !adaptive || ((double)mu[u][c] + v.kf * (double)dg[u][c] >= v.thr);
                     bits |= (in ? 1u : 0u) << c;
                 }
-                lds.mask4[q] = (unsigned char)bits;
+                lds.mask4[q - q_lo] = (unsigned char)bits;
             }
         }
         const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
@@ -124,10 +124,13 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
 
     // ---- wave 0 finishes the m x m algebra while waves 1..3 already stream (they need L^-1 only in a tile epilogue)
     if (tid < kWave) {
-        const int status = solve_wave<MC>(v, h, item, flags, lds.small, lds.work, lds.Ls, lds.ys, status_out);
+        int status;
+        if constexpr (MC == 9) status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.work, 1, QS, lds.Ls, lds.ys, nullptr, status_out);
+        else status = solve_wave<MC>(v, h, item, flags, lds.small, lds.work, lds.Ls, lds.ys, status_out);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         IPP_TICK(v, 5, tick);
+        if (tid == 0) IPP_MARK(item, 7);  // m x m algebra done
     }
 
     // ---- phase B

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tr[];
     const GainLds<MC> lds(smem_tr, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.n_tiles, v.Npad / VEC);
+                          kStepThreads / kWave, v.win_tiles, v.win_tiles * kWave);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) bits |= (((double)mu[c] + v.kf * (double)dg[c] >= v.thr) ? 1u : 0u) << c;
             }
-            lds.mask4[q] = (unsigned char)bits;
+            lds.mask4[q - hh.t_lo * kWave] = (unsigned char)bits;
         }
         if (expand) {
             const float4* src = reinterpret_cast<const float4*>(parent_diag);
@@ -130,7 +130,9 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();
     if (tid < kWave) {
-        const int status = solve_wave<MC>(v, h, item, flags_eff, lds.small, lds.work, lds.Ls, lds.ys, status_out);
+        int status;
+        if constexpr (MC == 9) status = solve_wave_fast<MC>(v, h, item, flags_eff, lds.small, lds.work, 1, QS, lds.Ls, lds.ys, nullptr, status_out);
+        else status = solve_wave<MC>(v, h, item, flags_eff, lds.small, lds.work, lds.Ls, lds.ys, status_out);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }

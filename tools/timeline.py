@@ -28,6 +28,18 @@ def main():
         for nm, a, b in zip(names, cuts[:-1], cuts[1:]):
             d = (b[ok] - a[ok]) / 100.0
             print(f"  {nm:36s} mean {d.mean():5.1f} us   p10 {np.percentile(d, 10):5.1f}  p90 {np.percentile(d, 90):5.1f}")
+    if np.all(t[ok, 6] > 0):
+        first_out, solved = (t[:, 6] - t0) / 100.0, (t[:, 7] - t0) / 100.0
+        print(f"wave 0's m x m algebra after phase A: mean {np.mean(solved[ok] - mid[ok]):.1f} us   p90 {np.percentile(solved[ok] - mid[ok], 90):.1f}")
+        print(f"first wave out -> last wave out: mean {np.mean(end[ok] - first_out[ok]):.1f} us   p90 {np.percentile(end[ok] - first_out[ok], 90):.1f}")
+    # slot refill: for every workgroup start after the first wave of starts, the time since the latest earlier end
+    order_e = np.sort(end[ok])
+    late = np.sort(start[ok])[min(1024, int(ok.sum()) - 1):]
+    if len(late):
+        gaps = []
+        for k, s0 in enumerate(late):  # k-th late start reuses (at best) the slot of the k-th end
+            gaps.append(s0 - order_e[min(k, len(order_e) - 1)])
+        print(f"k-th late start minus k-th end (slot refill delay): mean {np.mean(gaps):.1f} us   p10 {np.percentile(gaps, 10):.1f}  p90 {np.percentile(gaps, 90):.1f}")
     print(f"last workgroup start at {start[ok].max():.1f} us")
     edges = np.arange(0.0, end[ok].max() + bucket, bucket)
     print(" window[us]  resident  in phase A  streaming")
