@@ -29,6 +29,14 @@ class TreeNodePool:
     def __len__(self) -> int:
         return self._next
 
+    def allocate(self, n: int = 1):
+        """Reserve n node ids for a caller that issues ipp_tree_step itself (planning/mcts_zero/mcts.py)."""
+        if self._next + n > self.capacity:
+            raise RuntimeError(f"node pool exhausted ({self.capacity} nodes)")
+        first = self._next
+        self._next += n
+        return first if n == 1 else np.arange(first, first + n, dtype=np.int32)
+
     def path(self, node: Optional[int]) -> List[int]:
         """Node ids from the root's child down to `node` (empty for the root itself), -1 padded to the engine's depth."""
         ids: List[int] = []

@@ -478,6 +478,114 @@ def gen_features():
     save("features", **out)
 
 
+
+# ----------------------------------------------------------------------------- 12. MCTS-zero tree search (8(f) rank 1)
+class _StubQueues:
+    """Stand-in for the inference worker's queues (planning/mcts_zero/inference_workers.py): uniform policy over all
+    actions and a value that is a pure function of the request's action mask, so the build's driver can use the same
+    stub.  Records every request."""
+
+    def __init__(self, num_actions):
+        self.num_actions = num_actions
+        self.pending = None
+        self.masks = []
+
+    # request queue
+    def put(self, msg):
+        self.pending = msg
+        self.masks.append(np.array(msg["action_msk"], dtype=bool))
+
+    # reply queue
+    def get(self):
+        msk = np.asarray(self.pending["action_msk"], dtype=bool)
+        return {"policy": np.ones(self.num_actions) / self.num_actions, "value": stub_value(msk)}
+
+    def empty(self):
+        return False
+
+    get_nowait = get
+
+
+def stub_value(mask):
+    """Leaf value of the stubbed network: depends on the valid-action mask only."""
+    return 0.05 * float(int(mask.sum()) % 7) + 0.3
+
+
+def gen_mcts():
+    import planning.mcts_zero.mcts as ref_mcts
+    from planning.common.features import EpisodeHistory
+
+    out = {}
+    cases = [
+        # name, grid, adaptive, root steps, sims, altitudes (min, max, spacing), budget, horizon, seed
+        ("a5", 5, False, 2, 96, (8, 14, 6), 30.0, 3, 3),
+        ("b10", 10, True, 3, 80, (8, 14, 6), 40.0, 5, 5),
+    ]
+    for name, dim, adaptive, root_steps, sims, (amin, amax, aspc), budget, horizon, seed in cases:
+        params = load_params(dim, dim)
+        gm, sensor, sim, mapping = build(params, seed=seed)
+        uav = {"max_v": 2, "max_a": 2}
+        # the root: a few executed rf = 1 measurements (noisy observations), so that mean and covariance are generic
+        rs = np.random.RandomState(100 + seed)
+        prev = np.array([2.0, 2.0, 14.0])
+        root_actions, root_eps = [], []
+        for _ in range(root_steps):
+            a = np.array([4.0 * rs.randint(0, dim) + 2.0, 4.0 * rs.randint(0, dim) + 2.0, 8.0])
+            st = np.random.get_state()
+            z = sensor.take_measurement(a, verbose=False)
+            np.random.set_state(st)
+            eps = np.random.normal(0, 1, z.shape)
+            mapping.update_grid_map(a, z)
+            root_actions.append(a)
+            ep = np.zeros(9)
+            ep[: eps.size] = eps.ravel()
+            root_eps.append(ep)
+            prev = a
+        hyper = dict(params["experiment"]["missions"][0]["hyper_params"])
+        hyper.update(num_mcts_simulations=sims, non_blocking_read=False)
+        scenario = {"value_threshold": 0.4, "interval_factor": 0} if adaptive else None
+        meta = {"budget": budget, "initial_budget": budget, "episode_horizon": horizon, "min_altitude": amin,
+                "max_altitude": amax, "altitude_spacing": aspc, "uav_specifications": uav, "scenario_info": scenario}
+        num_actions = dim * dim * (int((amax - amin) / aspc) + 1)
+        queues = _StubQueues(num_actions)
+        # The reference's state key is hash(str(P)) (mcts.py:20-21).  NumPy abbreviates arrays of more than 1000 elements to
+        # their corners, which makes almost all states of a 10x10 map (100x100 matrix) collide; with the print threshold
+        # raised the key sees the whole matrix (printed to 8 digits: states reached by the same measurements in a
+        # different order are one node).  The fixtures are recorded in that well-defined regime.
+        np.set_printoptions(threshold=sys.maxsize)
+        # features.py:98-99 zeroes rows / columns of the LIVE node states in place when adaptive (an aliasing side effect of
+        # building network inputs, which the stub ignores anyway): recorded with a non-mutating stand-in.
+        ref_mcts.generate_input_feature_planes = lambda *a, **k: None
+        mcts = ref_mcts.MCTS(mapping, hyper, meta, queues, queues)
+        root = ref_mcts.Node(gm.cov_matrix.copy())
+        np.random.seed(1000 + seed)
+        policy, valid = mcts.get_policy(root, 0, prev.copy(), budget, EpisodeHistory(hyper["input_history_length"]), temperature=1)
+        rep = root.state_representation()
+        np.set_printoptions(threshold=1000)
+        out.update({
+            f"{name}_white": None, f"{name}_dim": dim, f"{name}_adaptive": adaptive, f"{name}_sims": sims, f"{name}_budget": budget,
+            f"{name}_horizon": horizon, f"{name}_alts": np.array([amin, amax, aspc], dtype=np.float64), f"{name}_seed": 1000 + seed,
+            f"{name}_gt": sim.ground_truth_map, f"{name}_root_actions": np.array(root_actions), f"{name}_root_eps": np.array(root_eps),
+            f"{name}_root_mean": gm.mean, f"{name}_root_diag": np.diag(gm.cov_matrix), f"{name}_prev": prev,
+            f"{name}_policy": np.array(policy), f"{name}_valid": np.array(valid),
+            f"{name}_root_Nsa": mcts.Nsa[rep], f"{name}_root_Qsa": mcts.Qsa[rep], f"{name}_root_Ps": mcts.Ps[rep],
+            f"{name}_root_Ns": mcts.Ns[rep], f"{name}_num_nodes": len(mcts.Ps), f"{name}_inferences": mcts.inference_counter,
+            f"{name}_revisits": mcts.revisits_counter, f"{name}_new_visits": mcts.new_visits_counter,
+            f"{name}_total_Ns": sum(mcts.Ns.values()), f"{name}_mask_sums": np.array([m.sum() for m in queues.masks]),
+        })
+        out.pop(f"{name}_white")
+        print(f"  mcts {name}: {len(mcts.Ps)} nodes, {mcts.inference_counter} inferences, root visits {int(mcts.Ns[rep])}, "
+              f"max Nsa {int(mcts.Nsa[rep].max())}, revisits {mcts.revisits_counter}")
+    out["hyper_puct_init"] = hyper["puct_init"]
+    out["hyper_puct_base"] = hyper["puct_base"]
+    out["hyper_forced_playout_factor"] = hyper["forced_playout_factor"]
+    out["hyper_max_valid_action_distance"] = hyper["max_valid_action_distance"]
+    out["hyper_gamma"] = hyper["gamma"]
+    out["hyper_dirichlet_alpha"] = hyper["dirichlet_alpha"]
+    out["hyper_dirichlet_eps"] = hyper["dirichlet_eps"]
+    save("mcts", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("writing golden vectors to", OUT)
@@ -496,6 +604,7 @@ def main():
     gen_greedy()
     gen_costs()
     gen_features()
+    gen_mcts()
     shapes = sorted(set(RESIZE_CALLS))
     print("cv2.resize stub was called with (src shape, dsize):", shapes)
 

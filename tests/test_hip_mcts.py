@@ -1,0 +1,192 @@
+"""
+GPU tests of the batched tree-search driver (ipp_rl_amd/planning/mcts_zero/mcts.py) against golden
+vectors recorded from the reference's own MCTS (planning/mcts_zero/mcts.py:83-296) with a stubbed inference queue
+(uniform priors, value = a function of the valid-action mask) under the same NumPy seed: visit counts, policy, Q values,
+node / inference / revisit counters of an 80-96 simulation search must come out the same, with every covariance step on
+the device (fp32 state: Q values within 1e-5, counts exactly).  tests/golden/gen_golden.py::gen_mcts documents the two
+regimes the fixtures were recorded in (print threshold, non-mutating feature planes).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+UAV = {"max_v": 2, "max_a": 2}
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def stub_value(mask):
+    return 0.05 * float(int(mask.sum()) % 7) + 0.3
+
+
+def stub_infer(requests):
+    return [(None, stub_value(r["action_msk"])) for r in requests]
+
+
+def hyper_from(g, sims):
+    return dict(gamma=float(g["hyper_gamma"]), puct_init=float(g["hyper_puct_init"]), puct_base=float(g["hyper_puct_base"]),
+                forced_playout_factor=float(g["hyper_forced_playout_factor"]),
+                max_valid_action_distance=float(g["hyper_max_valid_action_distance"]), dirichlet_alpha=float(g["hyper_dirichlet_alpha"]),
+                dirichlet_eps=float(g["hyper_dirichlet_eps"]), num_mcts_simulations=int(sims))
+
+
+def build_root(g, name, capacity=1, slot=0, node_capacity=256):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    dim, horizon = int(g[f"{name}_dim"]), int(g[f"{name}_horizon"])
+    steps = len(g[f"{name}_root_actions"])
+    eng = IPPEngine(EngineConfig(x_dim=dim, y_dim=dim), capacity=capacity, state="factor", rank_cap=9 * (steps + horizon + 2),
+                    window_rows=-1, fixed_prior=True, node_capacity=node_capacity, max_batch=max(capacity, 64))
+    eng.reset(env_ids=[slot], gt=g[f"{name}_gt"][None])
+    prev = np.array([2.0, 2.0, 14.0])
+    for a, eps in zip(g[f"{name}_root_actions"], g[f"{name}_root_eps"]):
+        _, st = eng.step(a[None], prev[None], env_ids=[slot], meas_noise=eps[None])
+        assert int(st[0]) == 0
+        prev = a
+    assert np.max(np.abs(host(eng.read_mean(slot)) - g[f"{name}_root_mean"])) < TOL
+    assert np.max(np.abs(host(eng.read_diag(slot)) - g[f"{name}_root_diag"])) < TOL
+    return eng
+
+
+def meta_from(g, name):
+    amin, amax, aspc = g[f"{name}_alts"]
+    adaptive = bool(g[f"{name}_adaptive"])
+    return {"budget": float(g[f"{name}_budget"]), "initial_budget": float(g[f"{name}_budget"]),
+            "episode_horizon": int(g[f"{name}_horizon"]), "min_altitude": float(amin), "max_altitude": float(amax),
+            "altitude_spacing": float(aspc), "uav_specifications": UAV,
+            "scenario_info": {"value_threshold": 0.4, "interval_factor": 0} if adaptive else None}
+
+
+@pytest.mark.parametrize("name", ["a5", "b10"])
+def test_search_reproduces_the_reference_mcts(golden, name):
+    from ipp_rl_amd.planning.mcts_zero.mcts import BatchedMCTS
+
+    g = golden("mcts")
+    eng = build_root(g, name)
+    mcts = BatchedMCTS(eng, hyper_from(g, g[f"{name}_sims"]), meta_from(g, name), stub_infer)
+    np.random.seed(int(g[f"{name}_seed"]))  # the reference draws from the global legacy stream: same calls, same order
+    out = mcts.get_policy([0], g[f"{name}_prev"][None], [float(g[f"{name}_budget"])], rngs=[np.random])
+    policy, valid = out[0]
+    root = mcts.last_roots[0]
+    nsa = np.zeros(mcts.num_actions)
+    qsa = np.zeros(mcts.num_actions)
+    ps = np.zeros(mcts.num_actions)
+    nsa[root.idx], qsa[root.idx], ps[root.idx] = root.Nsa, root.Qsa, root.Ps
+    print(f"[{name}] nodes {mcts.stats['nodes']} inferences {mcts.stats['inferences']} device steps {mcts.stats['device_steps']} in "
+          f"{mcts.stats['launches']} launches; root visits {root.Ns}; max |Q - ref| {np.max(np.abs(qsa - g[f'{name}_root_Qsa'])):.2e}")
+    assert np.array_equal(nsa, g[f"{name}_root_Nsa"])          # visit counts of every root action
+    assert root.Ns == int(g[f"{name}_root_Ns"])
+    assert np.max(np.abs(qsa - g[f"{name}_root_Qsa"])) < TOL    # node rewards / backed-up values
+    assert np.max(np.abs(ps[root.idx] - g[f"{name}_root_Ps"][root.idx])) < 1e-12  # priors incl. the Dirichlet draw
+    assert np.array_equal(np.asarray(valid, dtype=bool), g[f"{name}_valid"].astype(bool))
+    assert np.max(np.abs(np.asarray(policy) - g[f"{name}_policy"])) < 1e-12
+    assert mcts.stats["nodes"] == int(g[f"{name}_num_nodes"]) and mcts.stats["inferences"] == int(g[f"{name}_inferences"])
+    assert mcts.stats["revisits"] == int(g[f"{name}_revisits"]) and mcts.stats["new_visits"] == int(g[f"{name}_new_visits"])
+    # every edge was evaluated on the device once; the reference recomputes a dense update per traversal
+    assert mcts.stats["device_steps"] <= mcts.stats["revisits"] + mcts.stats["new_visits"]
+    # the root env slot is untouched by the search
+    assert np.max(np.abs(host(eng.read_diag(0)) - g[f"{name}_root_diag"])) < TOL
+
+
+def test_batched_roots_equal_single_root_searches_and_parallel_simulations():
+    """16 roots searched in lock step (one ipp_tree_step launch per tree level for all of them) give exactly the results of
+    16 separate searches with the same generators; 4 simulations in flight per root keep the accounting consistent."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.mcts_zero.mcts import BatchedMCTS
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    dim, R, sims, horizon = 20, 16, 48, 4
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    eng = IPPEngine(cfg, capacity=R, state="factor", rank_cap=9 * (3 + horizon + 2), window_rows=-1, fixed_prior=True,
+                    node_capacity=R * (sims + 8), max_batch=4 * R)
+    rs = np.random.RandomState(2)
+    eng.reset(white_noise=rs.normal(size=(R, dim, dim)))
+    prev = np.tile([2.0, 2.0, 14.0], (R, 1))
+    for t in range(3):
+        acts = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
+        eng.step(acts, prev, meas_noise=rs.normal(size=(R, 9)))
+        prev = acts
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+                 dirichlet_alpha=1.0, dirichlet_eps=0.25, num_mcts_simulations=sims)
+    meta = {"budget": 60.0, "initial_budget": 60.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
+            "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
+    roots = list(range(R))
+    batched = BatchedMCTS(eng, hyper, meta, stub_infer)
+    out_b = batched.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(100 + r) for r in roots])
+    nsa_b = [nd.Nsa.copy() for nd in batched.last_roots]
+    launches_b = batched.stats["launches"]
+    single_launches = 0
+    for r in roots:
+        one = BatchedMCTS(eng, hyper, meta, stub_infer)
+        out_1 = one.get_policy([r], prev[r][None], [60.0], rngs=[np.random.RandomState(100 + r)])
+        assert np.array_equal(one.last_roots[0].Nsa, nsa_b[r]) and np.array_equal(one.last_roots[0].idx, batched.last_roots[r].idx)
+        assert np.allclose(out_1[0][0], out_b[r][0], atol=0, rtol=0)
+        single_launches += one.stats["launches"]
+    assert launches_b < single_launches / 4  # lock step: launches are shared by the roots
+    par = BatchedMCTS(eng, hyper, meta, stub_infer, sims_in_flight=4)
+    out_p = par.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(100 + r) for r in roots])
+    for r in roots:
+        nd = par.last_roots[r]
+        assert nd.Ns == int(nd.Nsa.sum()) and nd.Ns >= sims - 4 and np.all(nd.Nsa >= 0)  # virtual visits all undone
+        assert out_p[r] is not None and abs(sum(out_p[r][0]) - 1.0) < 1e-9
+    assert par.stats["launches"] < launches_b  # fewer, larger launches
+
+
+def test_rollout_policies_vs_oracle():
+    """Classic-MCTS rollout pieces (planning/mcts_mission.py:167-272) on ipp_tree_score_actions: valid-action mask,
+    greedy action = first maximiser of the per-candidate oracle rewards from a tree node's state, epsilon-greedy's draw
+    sequence, progressive-widening rule."""
+    from oracle import ipp_oracle as orc
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.common.actions import action_dict_to_np_array, enumerate_actions
+    from ipp_rl_amd.planning.rollout import RolloutPolicy
+    from ipp_rl_amd.planning.tree import TreeNodePool
+
+    dim = 20
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    ocfg = orc.OracleConfig(x_dim=dim, y_dim=dim)
+    eng = IPPEngine(cfg, capacity=1, state="factor", rank_cap=90, window_rows=12, node_capacity=8, max_batch=512, score_scratch=True)
+    rs = np.random.RandomState(9)
+    white = rs.normal(size=(dim, dim))
+    eng.reset(env_ids=[0], white_noise=white[None])
+    st = orc.env_reset(ocfg, white)
+    prev = np.array([2.0, 2.0, 14.0])
+    for a in ([38.0, 42.0, 8.0], [46.0, 38.0, 14.0]):
+        a = np.array(a)
+        eps = rs.normal(size=9)
+        eng.step(a[None], prev[None], env_ids=[0], meas_noise=eps[None])
+        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
+        orc.env_step(ocfg, st, a, eps[:m])
+        prev = a
+    pool = TreeNodePool(eng, 8)
+    a1 = np.array([42.0, 46.0, 8.0])
+    _, _, kid = pool.expand([0], [None], a1[None], prev[None])
+    info = {"mean": st.mean, "value_threshold": 0.4, "interval_factor": 0.0}
+    _, P1, _, _ = orc.predict_step(ocfg, st.P, prev, a1, UAV, info)
+
+    class G:
+        x_dim, y_dim, resolution, num_grid_cells = dim, dim, 4.0, dim * dim
+
+    actions_np = action_dict_to_np_array(enumerate_actions(G, 8, 14, 6))
+    np.random.seed(4)
+    pol = RolloutPolicy(eng, actions_np, UAV, max_greedy_radius=13.0, adaptive=True, rng=np.random)
+    msk = pol.next_actions_mask(a1, 30.0, UAV)
+    d = np.linalg.norm(actions_np - a1, axis=1)
+    assert msk.sum() > 20 and np.all(d[msk] < 13.0) and np.all(d[msk] > 0)
+    cands = actions_np[msk]
+    want = np.array([orc.predict_step(ocfg, P1, a1, c, UAV, info)[0] for c in cands])
+    got = pol.score(0, pool.path(int(kid[0])), a1, cands)
+    assert np.max(np.abs(got - want)) < TOL
+    assert np.array_equal(pol.greedy_action(0, pool.path(int(kid[0])), a1, cands), cands[int(np.argmax(want))])
+    # epsilon-greedy consumes the stream like the reference: one uniform, then (exploring) one choice
+    np.random.seed(11)
+    u = np.random.uniform(0, 1)
+    explore_idx = np.random.choice(len(cands))
+    np.random.seed(11)
+    act = pol.eps_greedy_policy(0, pool.path(int(kid[0])), a1, 30.0, epsilon=0.5)
+    assert np.array_equal(act, cands[int(np.argmax(want))] if u > 0.5 else cands[explore_idx])
+    assert RolloutPolicy.widen(0, 0, 3, 0.5, 10) and RolloutPolicy.widen(3, 4, 3, 0.5, 10) and not RolloutPolicy.widen(7, 4, 3, 0.5, 10)
+    assert not RolloutPolicy.widen(5, 100, 3, 0.5, 5)
