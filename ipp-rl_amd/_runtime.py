@@ -26,9 +26,12 @@ import numpy as np
 
 from . import _ffi
 from . import engine as _engine_mod
+from ._device_array import DeviceCov, SlotStore
 from .engine import EngineConfig, IPPEngine
 
 _ENGINES: Dict[Tuple, IPPEngine] = {}
+_STORES: Dict[int, "SlotStore"] = {}  # id(engine) -> device state slots handed out as DeviceCov objects
+STATE_SLOTS = int(os.environ.get("IPP_COMPAT_SLOTS", "16"))  # dense states kept on the device per compat engine
 
 
 def config_key(cfg: EngineConfig) -> Tuple:
@@ -37,16 +40,35 @@ def config_key(cfg: EngineConfig) -> Tuple:
 
 
 def compat_engine(cfg: EngineConfig) -> IPPEngine:
-    """Dense-state engine with 2 slots for `cfg` (slot 0: working map, slot 1: scratch)."""
+    """Dense-state engine for `cfg`: slot 0 working map, slot 1 scratch (ground truth / observations), slots 2.. hold the
+    map states the planners keep alive (DeviceCov, _device_array.py)."""
     if _engine_mod.forked_with_gpu():  # (engine.py abandons every inherited engine at fork, without destroying it)
         raise _ffi.IppError(_engine_mod.FORK_MESSAGE)
     key = config_key(cfg)
     eng = _ENGINES.get(key)
     if eng is None:
         m_cap = 9 if cfg.resolution >= 2 else 25
-        eng = IPPEngine(cfg, capacity=2, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap, score_scratch=True)
+        eng = IPPEngine(cfg, capacity=2 + STATE_SLOTS, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap,
+                        score_scratch=True)
         _ENGINES[key] = eng
+        _STORES[id(eng)] = SlotStore(eng, 2, STATE_SLOTS)
     return eng
+
+
+def state_store(eng: IPPEngine) -> "SlotStore":
+    return _STORES[id(eng)]
+
+
+def on_device(eng: IPPEngine, state) -> DeviceCov:
+    """`state` as a DeviceCov of `eng` with a live slot: DeviceCov objects of this engine are used where they are, anything
+    else (plain float64 matrices, states of another engine) is uploaded into a fresh slot."""
+    store = state_store(eng)
+    if isinstance(state, DeviceCov) and state.device_slot(store) is not None:
+        return state
+    host = np.ascontiguousarray(np.asarray(state), dtype=np.float64)
+    obj = DeviceCov(store, host.shape[0], host=host)
+    obj.device_slot(store)
+    return obj
 
 
 def engine_config_from(grid_map, sensor, signal_variance: float, length_scale: float, cluster_radius=None) -> EngineConfig:

@@ -2,9 +2,10 @@
 Mapping: drop-in for the reference's mapping/mappings.py (Mapping.update_grid_map, init_priors,
 kalman_filter_update) with the arithmetic on the GPU.
 
-  * update_grid_map -> one fused HIP step on a dense 2-slot engine (include/ipp_engine.h: ipp_step with
-    IPP_GIVEN_OBSERVATION / IPP_COV_ONLY), fp32 state on the device, fp64 arrays at the API
-    (results agree with the reference within 1e-5, tests/test_hip_classes.py).
+  * update_grid_map -> one fused HIP step on the dense compat engine (include/ipp_engine.h: ipp_step with
+    IPP_GIVEN_OBSERVATION / IPP_COV_ONLY, out of place into a new state slot), fp32 state on the device; covariances
+    are returned as DeviceCov (_device_array.py): array-likes that stay on the GPU until a caller looks at the whole
+    matrix (results agree with the reference within 1e-5, tests/test_hip_classes.py).
   * init_priors GP branch -> ipp_reset (analytic Matern-3/2 == the unfitted GPR the reference builds,
     mapping/mappings.py:242-258); the shuffle_prior_cov draws stay on NumPy's legacy stream (:239-240).
   * the non-GP prior (:219-233) and the generic dense-H kalman_filter_update (:156-215, no caller in the
@@ -16,6 +17,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from .. import _runtime
+from .._device_array import DeviceCov
 from .grid_maps import GridMap, _require
 
 logger = logging.getLogger(__name__)
@@ -74,9 +76,10 @@ class Mapping:
             ls = np.random.uniform(low=0.8 * self.length_scale, high=1.2 * self.length_scale)
         self._prior_scale = (float(sv), float(ls))
         eng, _ = self._engine()
-        eng.reset(env_ids=[1], prior_scale=np.array([[sv, ls]]))
+        prior = DeviceCov.new_on_device(_runtime.state_store(eng), n)  # the prior is built in its slot and stays there
+        eng.reset(env_ids=[prior.device_slot(_runtime.state_store(eng))], prior_scale=np.array([[sv, ls]]))
         gm.mean = 0.5 * np.ones((gm.y_dim, gm.x_dim))
-        gm.cov_matrix = _runtime.to_host64(eng.read_cov(1))
+        gm.cov_matrix = prior
 
     def update_grid_map(
         self,
@@ -97,22 +100,28 @@ class Mapping:
         if want_mean and measurement_data is None:
             raise AttributeError("measurement_data is required unless cov_only=True")  # reference: None.flatten()
         eng, _ = self._engine()
-        eng.write_cov(0, P_in)
-        if want_mean:
-            eng.write_mean(0, gm.mean)
-        pos = np.asarray(measurement_position, dtype=np.float64).reshape(1, 3)
-        z = None if not want_mean else np.asarray(measurement_data, dtype=np.float64).reshape(1, -1)
-        _, status = eng.step(pos, pos, env_ids=[0], meas_noise=z, cov_only=not want_mean, adaptive=False,
-                             use_flight_time=False, given_observation=want_mean)
-        st = int(status[0])
+        store = _runtime.state_store(eng)
+        src = _runtime.on_device(eng, P_in)  # states this layer handed out are still on the device: no upload
+        src._pinned = True
+        try:
+            P_new = DeviceCov.new_on_device(store, src.shape[0])  # P' is a new array in the reference too (:190)
+            s_slot, d_slot = src.device_slot(store), P_new.device_slot(store)
+            if want_mean:
+                eng.write_mean(s_slot, gm.mean)
+            pos = np.asarray(measurement_position, dtype=np.float64).reshape(1, 3)
+            z = None if not want_mean else np.asarray(measurement_data, dtype=np.float64).reshape(1, -1)
+            _, status = eng.step(pos, pos, env_ids=[s_slot], dst_ids=[d_slot], meas_noise=z, cov_only=not want_mean,
+                                 adaptive=False, use_flight_time=False, given_observation=want_mean)
+            st = int(status[0])
+        finally:
+            src._pinned = False
         if st == 1:
             logger.error("Cholesky decomposition failed: S is not positive definite")
             logger.info("Fallback to classical matrix inversion")
         elif st != 0:
             logger.error(f"HIP step rejected the measurement footprint (status {st})")
             raise ValueError
-        P_new = _runtime.to_host64(eng.read_cov(0))
-        x_new = _runtime.to_host64(eng.read_mean(0)) if want_mean else None
+        x_new = _runtime.to_host64(eng.read_mean(d_slot)) if want_mean else None
         if predict_only:
             return (None, P_new) if cov_only else (x_new.reshape(gm.mean.shape), P_new)
         gm.mean = x_new.reshape(gm.mean.shape)  # reference fails here too when cov_only and not predict_only

@@ -11,6 +11,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
+from ... import _runtime
 from ..._runtime import to_host64
 from .actions import action_costs, enumerate_actions
 from .rewards import compute_adaptive_msk
@@ -80,13 +81,17 @@ def generate_fov_feature_plane(mapping, position: np.array) -> np.array:
 
 
 def _state_plane(mapping, state: np.ndarray, adaptive_info: Dict = None) -> np.ndarray:
-    """One N x N state plane on the device (slot 1 of the compat engine)."""
+    """One N x N state plane on the device (the state's own slot, or slot 1 of the compat engine for host matrices)."""
     eng, _ = mapping._engine()
-    eng.write_cov(1, state)
+    if hasattr(state, "device_slot") and state.device_slot(_runtime.state_store(eng)) is not None:
+        slot = state.device_slot(_runtime.state_store(eng))  # a state this layer returned: already on the device
+    else:
+        slot = 1
+        eng.write_cov(1, state)
     if adaptive_info is None:
-        return to_host64(eng.state_plane(1, adaptive=False))
+        return to_host64(eng.state_plane(slot, adaptive=False))
     eng.set_adaptive(adaptive_info["value_threshold"], adaptive_info["interval_factor"])
-    plane = to_host64(eng.state_plane(1, mean_for_mask=np.asarray(adaptive_info["mean"], dtype=np.float32).ravel(), adaptive=True))
+    plane = to_host64(eng.state_plane(slot, mean_for_mask=np.asarray(adaptive_info["mean"], dtype=np.float32).ravel(), adaptive=True))
     msk = compute_adaptive_msk(adaptive_info["mean"], state, adaptive_info["value_threshold"], adaptive_info["interval_factor"])
     state[~msk, :] = 0  # the reference leaves the history masked (features.py:98-99)
     state[:, ~msk] = 0

@@ -12,15 +12,22 @@ from .actions import action_costs
 ArrayOrFloat = Union[float, np.ndarray]
 
 
+def _diagonal(matrix) -> np.ndarray:
+    """diag(P): from the engine's cached diagonal when the state lives on the device (_device_array.DeviceCov)."""
+    if hasattr(matrix, "device_slot"):
+        return matrix.diagonal()
+    return np.einsum("ii->i", matrix)
+
+
 def compute_adaptive_msk(grid_mean: np.ndarray, grid_covariance: np.ndarray, value_threshold: float,
                          interval_factor: float) -> np.ndarray:
     """Cells whose upper confidence bound mean + k * var reaches the threshold (flat, row-major)."""
-    upper_bound = np.ravel(grid_mean) + interval_factor * np.einsum("ii->i", grid_covariance)
+    upper_bound = np.ravel(grid_mean) + interval_factor * _diagonal(grid_covariance)
     return upper_bound >= value_threshold
 
 
 def _trace(matrix: np.ndarray, mask: Optional[np.ndarray]) -> float:
-    diagonal = np.einsum("ii->i", matrix)
+    diagonal = _diagonal(matrix)
     return float(diagonal.sum() if mask is None else diagonal[mask].sum())
 
 

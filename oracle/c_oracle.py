@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "libipp_oracle.so")
+LIB = os.environ.get("IPP_ORACLE_LIB") or os.path.join(_HERE, "libipp_oracle.so")  # override: `make -C oracle asan`
 OC_MAX_M = 25
 COV_ONLY, PREDICT_ONLY, ADAPTIVE, USE_FLIGHT_TIME = 1, 2, 4, 8
 

@@ -221,3 +221,55 @@ def test_forked_child_abandons_inherited_engines_and_refuses_new_ones():
     assert os.waitpid(pid, 0)[1] == 0
     assert live._h == 123 and not engine.forked_with_gpu()  # the parent is unaffected
     engine._LIVE.discard(live)
+
+
+def test_device_cov_semantics_without_a_gpu():
+    """DeviceCov / SlotStore (ipp_rl_amd/_device_array.py) against a stand-in engine: diag / trace from the 'device',
+    arithmetic and indexing materialise once, LRU eviction to the host, write-through detaches and re-uploads, pickling
+    and deepcopy give plain ndarrays, garbage collection returns the slot."""
+    import copy
+    import gc
+    import pickle
+
+    from ipp_rl_amd._device_array import DeviceCov, SlotStore
+
+    class T:
+        def __init__(self, a): self.a = a
+        def detach(self): return self
+        def cpu(self): return self
+        def numpy(self): return self.a
+        def double(self): return T(self.a.astype(np.float64))
+        def numel(self): return self.a.size
+
+    class FakeEngine:
+        def __init__(self): self.slots = {}
+        def read_cov(self, slot): return T(self.slots[slot].astype(np.float32))
+        def read_diag(self, slot): return T(np.diag(self.slots[slot]).astype(np.float32))
+        def write_cov(self, slot, P): self.slots[slot] = np.array(P, dtype=np.float64)
+
+    eng = FakeEngine()
+    store = SlotStore(eng, 2, 3)
+    A = np.arange(16.0).reshape(4, 4)
+    a = DeviceCov(store, 4, host=A.copy())
+    assert a.device_slot(store) == 2 and store.uploads == 1
+    b = DeviceCov.new_on_device(store, 4)
+    eng.slots[b._slot] = A * 2
+    assert np.array_equal(np.diag(b), np.diag(A * 2)) and np.trace(b) == 60.0 and store.downloads == 0
+    assert np.array_equal(b - a, A) and np.array_equal(np.asarray(b), A * 2) and b.shape == (4, 4) and len(b) == 4
+    assert store.downloads == 1 and np.array_equal(b[1], 2 * A[1]) and store.downloads == 1  # materialised once
+    c = DeviceCov.new_on_device(store, 4)
+    eng.slots[c._slot] = A * 3
+    store.touch(b._slot)
+    d = DeviceCov.new_on_device(store, 4)  # no free slot: the least recently used state (a) is parked on the host
+    assert store.evictions == 1 and a._slot is None and np.array_equal(np.asarray(a), A)
+    eng.slots[d._slot] = A * 4
+    c[0, :] = 0
+    assert c._slot is None and np.asarray(c)[0].sum() == 0 and np.asarray(c)[1, 1] == 15
+    s2 = c.device_slot(store)
+    assert eng.slots[s2][0].sum() == 0 and eng.slots[s2][1, 1] == 15  # the modified matrix went back up
+    assert isinstance(pickle.loads(pickle.dumps(d)), np.ndarray) and isinstance(copy.deepcopy(d), np.ndarray)
+    n_free = len(store.free)
+    del d
+    gc.collect()
+    assert len(store.free) == n_free + 1
+    assert DeviceCov(SlotStore(FakeEngine(), 0, 1), 4, host=A).device_slot(store) is None  # another engine's state

@@ -24,6 +24,18 @@ for a in acts[:20]:
     r, _, Pn = simulate_prediction_step(P, prev, a, mapping, uav, info)
 dt = (time.perf_counter() - t0) / 20
 print("simulate_prediction_step (drop-in, 50x50): %.2f ms/call = %.0f calls/s" % (dt*1e3, 1/dt))
+# chained, the way the tree searches use it (mcts.py:239, mcts_mission.py:228-246): next_state feeds the next call, the
+# planner reads np.diag(state) of every node
+Pc, pv = P, prev
+t0 = time.perf_counter()
+for a in acts[:20]:
+    r, _, Pc = simulate_prediction_step(Pc, pv, a, mapping, uav, info)
+    d = np.diag(Pc)
+    pv = a
+dt = (time.perf_counter() - t0) / 20
+print("chained simulate_prediction_step + np.diag(next_state): %.2f ms/call" % (dt*1e3))
+t0 = time.perf_counter(); full = np.asarray(Pc); dt = time.perf_counter() - t0
+print("materialising one state on the host (np.asarray): %.1f ms, trace %.4f vs diag sum %.4f" % (dt*1e3, np.trace(full), d.sum()))
 t0 = time.perf_counter()
 for a in acts[:10]:
     z = sensor.take_measurement(a, verbose=False); mapping.update_grid_map(a, z)
