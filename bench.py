@@ -418,6 +418,51 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
             "launch_items": n_items, "all_status_ok": ok}
 
 
+def run_mcts_driver(torch, device, *, grid=200, roots=256, sims=64, in_flight=4, root_steps=3):
+    """The batched tree-search DRIVER (ipp_rl_amd/planning/mcts_zero/mcts.py: PUCT selection, valid-action mask, forced
+    playouts, Dirichlet noise, backup; reference planning/mcts_zero/mcts.py:83-296) on the configs[4] grid with a stubbed
+    network (uniform priors, constant value).  Selection and bookkeeping run on the host in NumPy, every covariance step on
+    the device in per-level ipp_tree_step launches shared by all roots: the figure is host-bound and reported as such."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.mcts_zero.mcts import BatchedMCTS
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    cfg = EngineConfig(x_dim=grid, y_dim=grid)
+    horizon = 5
+    eng = IPPEngine(cfg, capacity=roots, state="factor", rank_cap=9 * (root_steps + horizon + 2), window_rows=-1, fixed_prior=True,
+                    node_capacity=roots * (sims + in_flight), max_batch=roots * in_flight, device=device)
+    white = torch.empty((roots, cfg.n_cells), dtype=torch.float32, device=device)
+    eng.normal_rows(white, cfg.n_cells, 9, 1 << 40)
+    eng.reset(white_noise=white)
+    prev = np.tile([2.0, 2.0, 14.0], (roots, 1))
+    noise = torch.empty((root_steps, roots, eng.meas_cap), dtype=torch.float32, device=device)
+    eng.normal_rows(noise, eng.meas_cap, 9, 2 << 40)
+    for t in range(root_steps):
+        a = cell_centre_actions(cfg, t, 0, roots, roots, [8.0, 14.0])
+        eng.step(a, prev, meas_noise=noise[t])
+        prev = a
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+                 dirichlet_alpha=1.0, dirichlet_eps=0.25, num_mcts_simulations=sims)
+    meta = {"budget": 100.0, "initial_budget": 100.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
+            "altitude_spacing": 6.0, "uav_specifications": {"max_v": 2.0, "max_a": 2.0},
+            "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
+    mcts = BatchedMCTS(eng, hyper, meta, lambda reqs: [(None, 0.3)] * len(reqs), sims_in_flight=in_flight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = all(o is not None and abs(sum(o[0]) - 1.0) < 1e-9 for o in out)
+    st = dict(mcts.stats)
+    eng.close()
+    del eng, mcts
+    torch.cuda.empty_cache()
+    return {"name": f"tree-search driver on the configs[4] grid: {roots} roots x {sims} simulations ({in_flight} in flight per root), "
+                    f"{grid}x{grid}, horizon {horizon}, stubbed network; host-side PUCT / backup in NumPy (host-bound)",
+            "value": roots * sims / dt, "unit": "simulations/s", "seconds_per_search": dt, "device_tree_steps": st["device_steps"],
+            "launches": st["launches"], "nodes": st["nodes"], "inferences": st["inferences"], "all_policies_valid": ok}
+
+
 def extra_record(name, rec, total_envs):
     return {"name": name, "value": aggregate_rate(total_envs, rec["steps"], rec["elapsed_max_s"]), "unit": "env-steps/s",
             "ms_per_step": 1e3 * rec["elapsed_max_s"] / rec["steps"], "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"],
@@ -519,6 +564,10 @@ def main(argv=None):
             extra.append(run_tree_wave(torch, device))
         except Exception as exc:
             extra.append({"name": "BASELINE configs[4] tree wave", "error": repr(exc)})
+        try:
+            extra.append(run_mcts_driver(torch, device))
+        except Exception as exc:
+            extra.append({"name": "tree-search driver", "error": repr(exc)})
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)

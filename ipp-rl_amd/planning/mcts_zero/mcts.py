@@ -94,6 +94,7 @@ class BatchedMCTS:
         if self.horizon + 1 > engine.TREE_DEPTH:
             raise ValueError(f"episode_horizon {self.horizon} needs paths of {self.horizon + 1} steps; the engine holds {engine.TREE_DEPTH}")
         self.stats = dict(device_steps=0, launches=0, inferences=0, revisits=0, new_visits=0, nodes=0)
+        self._cell_index = None
 
     @property
     def num_actions(self) -> int:
@@ -104,6 +105,35 @@ class BatchedMCTS:
         """mcts.py:148-158 as simulate() calls it (no UAV argument: distance-based)."""
         d = np.linalg.norm(self.actions_np - position, ord=2, axis=1)
         return (d > 0) & (d <= budget) & (d < self.max_dist)
+
+    DENSE_ACTIONS = 4096  # up to this many actions the reference's num_actions-long arrays are used as they are
+
+    def _valid_idx(self, position, budget):
+        """Ascending indices of the valid actions and (small action sets only) the dense mask.  Large maps: only the
+        actions in the cells within max_valid_action_distance of the position are looked at (the reference evaluates the
+        distance to all num_actions actions for every leaf: 80 000 at 200x200 with two altitude levels)."""
+        if self.num_actions <= self.DENSE_ACTIONS:
+            mask = self.next_actions_mask(position, budget)
+            return np.nonzero(mask)[0], mask
+        if self._cell_index is None:
+            res = self.engine.cfg.resolution
+            cx = np.floor(self.actions_np[:, 0] / res).astype(np.int64)
+            cy = np.floor(self.actions_np[:, 1] / res).astype(np.int64)
+            W, H = int(cx.max()) + 1, int(cy.max()) + 1
+            order = np.argsort(cy * W + cx, kind="stable")
+            counts = np.bincount((cy * W + cx)[order], minlength=W * H)
+            self._cell_index = (W, H, order, np.concatenate([[0], np.cumsum(counts)]))
+        W, H, order, start = self._cell_index
+        res = self.engine.cfg.resolution
+        k = int(np.ceil(self.max_dist / res)) + 1
+        px, py = int(np.floor(position[0] / res)), int(np.floor(position[1] / res))
+        x0, x1 = max(px - k, 0), min(px + k, W - 1)
+        rows = range(max(py - k, 0), min(py + k, H - 1) + 1)
+        if x0 > x1 or len(rows) == 0:
+            return np.zeros(0, dtype=np.int64), None
+        cand = np.concatenate([order[start[y * W + x0]:start[y * W + x1 + 1]] for y in rows])  # cells of a row are adjacent
+        d = np.linalg.norm(self.actions_np[cand] - position, ord=2, axis=1)
+        return np.sort(cand[(d > 0) & (d <= budget) & (d < self.max_dist)]), None
 
     @staticmethod
     def _normalize_q(q: np.ndarray, has_outside: bool) -> np.ndarray:
@@ -179,11 +209,12 @@ class BatchedMCTS:
                 seen[id(nd)] = len(todo)
                 todo.append(s)
         if todo:
-            replies = self.infer([dict(root=int(roots[s["j"]]), path=list(s["leaf"].key), action_msk=s["mask"], depth=s["depth"],
-                                       previous_action=s["prev"], budget=s["budget"]) for s in todo])
+            # action_msk: the reference's dense mask (None on large maps, where valid_idx lists the valid actions)
+            replies = self.infer([dict(root=int(roots[s["j"]]), path=list(s["leaf"].key), action_msk=s["mask"], valid_idx=s["idx"],
+                                       depth=s["depth"], previous_action=s["prev"], budget=s["budget"]) for s in todo])
             self.stats["inferences"] += len(todo)
             for s, (policy, value) in zip(todo, replies):
-                self._expand_leaf(s["leaf"], s["mask"], policy, float(value), s["depth"] == 0 and s["sim"] == 0, rngs[s["j"]])
+                self._expand_leaf(s["leaf"], s["idx"], s["mask"], policy, float(value), s["depth"] == 0 and s["sim"] == 0, rngs[s["j"]])
         # ---- backups, in simulation order
         for s in sims:
             if s["terminal"] == "leaf":
@@ -214,10 +245,10 @@ class BatchedMCTS:
             if depth > self.horizon or budget <= 0:  # mcts.py:175-176
                 return out
             if not node.expanded:
-                mask = self.next_actions_mask(prev, budget)
-                if mask.sum() == 0:  # mcts.py:201-202
+                idx, mask = self._valid_idx(prev, budget)
+                if len(idx) == 0:  # mcts.py:201-202
                     return out
-                out.update(terminal="leaf", leaf=node, mask=mask, depth=depth, prev=prev.copy(), budget=budget)
+                out.update(terminal="leaf", leaf=node, idx=idx, mask=mask, depth=depth, prev=prev.copy(), budget=budget)
                 return out
             uct = self._uct(node, force_playouts=(depth == 0))
             ties = (uct == np.max(uct)).nonzero()[0]
@@ -277,12 +308,14 @@ class BatchedMCTS:
                 child.dev = int(new_ids[i])
                 child.dev_path = nd.dev_path + [child.dev]
 
-    def _expand_leaf(self, nd: _Node, mask, policy, value, noise: bool, rng):
+    def _expand_leaf(self, nd: _Node, idx, mask, policy, value, noise: bool, rng):
         """mcts.py:204-233: priors masked, Dirichlet noise at the root of the first simulation, normalised."""
         A = self.num_actions
-        idx = np.nonzero(mask)[0]
-        dense = noise or policy is not None or A <= 4096  # small action sets: the reference's array arithmetic to the last bit
+        dense = noise or policy is not None or mask is not None  # small action sets: the reference's array arithmetic to the last bit
         if dense:
+            if mask is None:
+                mask = np.zeros(A, dtype=bool)
+                mask[idx] = True
             full = (np.ones(A) / A if policy is None else np.asarray(policy, dtype=np.float64)) * mask
             if noise:  # add_exploration_noise works on the num_actions-long vector (invalid actions receive noise too)
                 full = (1 - self.eps) * full + self.eps * rng.dirichlet([self.alpha] * A)

@@ -256,4 +256,4 @@ def test_reference_callers_reach_the_inverse_fallback(caplog):
     assert any("Cholesky decomposition failed" in r.message for r in caplog.records)
     assert any("Fallback to classical matrix inversion" in r.message for r in caplog.records)
     assert np.max(np.abs(gm.cov_matrix - P_ref)) < 1e-4 * max(1.0, np.abs(P_ref).max())
-    assert np.max(np.abs(gm.mean.ravel() - x_ref)) < 1e-4 * max(1.0, np.abs(x_ref).max())
+    assert np.max(np.abs(gm.mean.ravel() - np.ravel(x_ref))) < 1e-4 * max(1.0, np.abs(x_ref).max())

@@ -17,7 +17,7 @@ fi
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o pmc -- python3 bench.py --no-cpu-baseline "$@" > "$out/pass$i.log" 2>&1
+  rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o pmc -- python3 bench.py --no-cpu-baseline --no-extra "$@" > "$out/pass$i.log" 2>&1
   tail -1 "$out/pass$i.log" | cut -c1-200
 done
 find "$out" -name "*.csv" | head -20
