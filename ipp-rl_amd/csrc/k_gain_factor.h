@@ -363,15 +363,31 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         if (commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
             if (LMASK) {
-                // in place (dst == env): diag -= |Wc_i|^2, mean += Wc_i y as read-modify-writes at L2
-                float* dg = (CHAIN ? diag_rw : v.diag + (size_t)h.dst * npad) + cell0;
-                float* mu = v.mean + (size_t)h.dst * npad + cell0;
+                // in place (dst == env): diag -= |Wc_i|^2, mean += Wc_i y as read-modify-writes at L2.
+                // TRANSPOSED first: a lane holds VEC consecutive cells, so "atomic add of component c" put 64 lanes at a
+                // 16-byte stride over the whole 1-KiB tile, and every 64-byte segment was written VEC times: WRITE_SIZE
+                // counted 4.0x the bytes for that pattern and it ran 4.3x slower than one atomic per consecutive cell
+                // (tools/probes/write_probe.hip, profiles/r02_write_probe_calibration.txt).  Four cross-lane moves per
+                // value (ds_bpermute, no LDS memory) make instruction c cover cells 64 c .. 64 c + 63 of the tile.
+                float* dg = (CHAIN ? diag_rw : v.diag + (size_t)h.dst * npad) + (size_t)tile * kWaveTile;
+                float* mu = v.mean + (size_t)h.dst * npad + (size_t)tile * kWaveTile;
+                const bool no_atomics = (IPP_GF_ABLATE & 16) && acc[0][0] != 12345.f;
+                const int comp = lane & (VEC - 1);
 #pragma unroll
-                for (int c = 0; c < VEC; ++c)
-                    if (cell0 + c < v.N && !((IPP_GF_ABLATE & 16) && acc[0][0] != 12345.f)) {
-                        unsafeAtomicAdd(dg + c, -dred[c]);
-                        if (!(flags & IPP_COV_ONLY)) unsafeAtomicAdd(mu + c, dmean[c]);
+                for (int c = 0; c < VEC; ++c) {
+                    const int src = (kWave / VEC) * c + lane / VEC;  // lane that holds cell 64 c + lane of the tile
+                    float d_t = 0.f, m_t = 0.f;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float dq = __shfl(dred[q], src, kWave), mq = __shfl(dmean[q], src, kWave);
+                        if (comp == q) { d_t = dq; m_t = mq; }
                     }
+                    const int cell = tile * kWaveTile + kWave * c + lane;
+                    if (cell < v.N && !no_atomics) {
+                        unsafeAtomicAdd(dg + kWave * c + lane, -d_t);
+                        if (!(flags & IPP_COV_ONLY)) unsafeAtomicAdd(mu + kWave * c + lane, m_t);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
