@@ -17,6 +17,17 @@
 // per-XCD queue), against 33-38 us of streaming: about half of the resident waves had requests in flight, and achieved
 // bandwidth follows that number.  Here three of four waves stream all the time, the prologue latency is hidden behind the
 // previous item's stream, and nothing is dispatched after the launch.
+//
+// STATUS: correct (tests/test_hip_sharding.py::test_pipelined_step_kernel_matches_default_and_oracle) but NOT faster, and
+// therefore opt-in (IPP_PIPE=1).  Measured at 4096 items of 50x50 (tools/timeline.py marks): the single producer wave
+// needs ~50 us per item (inputs 5, observation + tables + mask 17, gather of HT 13, m x m algebra + Q rows 16) against
+// ~37 us that its three consumers need to stream the item, so the pipeline is producer-bound: 0.357 ms per launch
+// against 0.313 ms for k_step_factor.  What was tried on the producer: the m x m algebra in registers (30 -> 16 us),
+// INTER_AREA weights one per lane, the producer as an out-of-line function with its own register allocation (the inlined
+// kernel spills 60-150 VGPRs; out of line the argument copies through scratch made it slower: 58 us).  What it would
+// take: <= 35 us per item, i.e. the next item's inputs prefetched under the current item and one gather pass for
+// ranks up to ~120 (7 x 9 lanes instead of 4 x 16).  A persistent grid also keeps every CU busy until it ends, so the
+// side-stream ground-truth kernels of VecIPPEnv cannot overlap with it (configs[2]: +0.6 ms per step).
 #pragma once
 #include "ipp_common.h"
 #include "k_gain_factor.h"
