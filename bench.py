@@ -407,15 +407,25 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
     ok = int(status.abs().sum().item()) == 0 and bool(torch.isfinite(reward).all().item())
     root_rank = float(eng.ranks().float().mean().item())
     n_steps = roots * sims * depth
-    # bytes one tree step streams (SURVEY 8(d) cfg 5: 4 N (r_root + 9 k + 9) with N -> the window's cells): not counted on
-    # the device for tree steps; report the rate
+    # roofline of the tree kernel: bytes counted on the device (stored rows of the chained state + the m new columns + the
+    # node's diagonal per touched cell, SURVEY 8(d) cfg 5) / HIP-event duration of its launches, over 8 more waves
+    eng.profile(True)
+    eng.streamed_bytes(reset=True)
+    for _ in range(8):
+        one_wave()
+    torch.cuda.synchronize()
+    counted, _ = eng.streamed_bytes_detail(reset=True)
+    k_ms, k_n = eng.profile_read(0)
+    eng.profile(False)
+    gbs = (counted / max(k_n, 1)) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     eng.close()
     del eng
     torch.cuda.empty_cache()
     return {"name": f"BASELINE configs[4]: {roots} roots x {sims} sims, {grid}x{grid} grid, depth {depth}, GRF ground truth "
                     f"(predict steps at tree nodes, ipp_tree_step; {wave} simulations per root per launch)",
             "value": n_steps / dt, "unit": "tree-steps/s", "ms_per_search": dt * 1e3, "root_rank": root_rank,
-            "launch_items": n_items, "all_status_ok": ok}
+            "launch_items": n_items, "all_status_ok": ok, "kernel": "k_tree_step", "kernel_ms_avg": k_ms, "achieved_gbs": gbs,
+            "frac": gbs / HBM_PEAK_GBS}
 
 
 def run_mcts_driver(torch, device, *, grid=200, roots=256, sims=64, in_flight=4, root_steps=3):

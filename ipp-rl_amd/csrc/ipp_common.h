@@ -81,17 +81,21 @@ struct ChainCols {
     const float* root;        // root slab: columns 0 .. r_root-1
     const int* root_spans;    // tile spans of the root's columns
     int r_root, depth;
-    const float* node[kTreeDepth];  // column block of path node j
+    // column block of path node j.  A node stores its columns on its own tile span only (stride nstride = win_tiles tiles
+    // per column); the pointer is pre-shifted by -t_lo tiles so that it is indexed with the ABSOLUTE cell like the root's
+    // rows.  Cells outside the span are never read (every consumer tests span(k) first).
+    const float* node[kTreeDepth];
     int off[kTreeDepth];            // index of its first column in the chained state
     int nspan[kTreeDepth];          // its tile span (lo | hi << 16)
-    size_t npad;
+    size_t npad, nstride;
     __device__ __forceinline__ const float* row(int k) const {
         const float* b = root;
         int kk = k;
+        size_t st = npad;
 #pragma unroll
         for (int j = 0; j < kTreeDepth; ++j)
-            if (j < depth && k >= off[j]) { b = node[j]; kk = k - off[j]; }
-        return b + (size_t)kk * npad;
+            if (j < depth && k >= off[j]) { b = node[j]; kk = k - off[j]; st = nstride; }
+        return b + (size_t)kk * st;
     }
     __device__ __forceinline__ int span(int k) const {
         int s = (r_root > 0) ? root_spans[min(k, r_root - 1)] : 0;

@@ -67,6 +67,7 @@ struct Engine {
     size_t gain_lds;
     int q_chunk;
     TreeView tv = {};      // node pool of ipp_tree_step (node_cap == 0: none)
+    float* node_diag_scratch = nullptr;  // [Npad] assembled diagonal of a node state (ipp_tree_score_actions)
     bool scoring = false;  // arena holds the ipp_score_actions scratch
     ScoreView sv = {};
     bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
@@ -88,9 +89,9 @@ struct Engine {
 };
 
 struct Layout {
-    int N, Npad, T, n_tiles, MC, FC, QS, q_rows, VEC;
+    int N, Npad, T, n_tiles, win_tiles, MC, FC, QS, q_rows, VEC;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
-        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, total, cov_slot_floats;
+        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
 };
 
 uint64_t q_item_floats(const Layout& L) {
@@ -166,6 +167,12 @@ int plan(const ipp_config& c, Layout& L) {
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;
     }
+    L.win_tiles = L.n_tiles;
+    if (c.state_repr == IPP_FACTOR && c.window_rows > 0) {
+        // rows a step can touch: the footprint (ny <= m <= MC blocks of rf <= 2 rows) + window_rows on both sides
+        const long rows = std::min<long>(c.y_dim, 2L * c.window_rows + 2L * L.MC);
+        L.win_tiles = (int)std::min<long>(L.n_tiles, (rows * c.x_dim + 64 * L.VEC - 1) / (64 * L.VEC) + 1);
+    }
     L.q_rows = (c.state_repr == IPP_FACTOR) ? c.rank_cap : L.FC;
     L.cov_slot_floats = (c.state_repr == IPP_FACTOR) ? (uint64_t)c.rank_cap * L.Npad : (uint64_t)L.N * L.Npad;
     uint64_t o = 0;
@@ -199,13 +206,14 @@ int plan(const ipp_config& c, Layout& L) {
         L.off_sc_G = o; o += up((uint64_t)kScoreSplit * L.N * kScoreBandCap * 8);
         L.off_sc_P = o; o += (c.state_repr == IPP_FACTOR) ? up((uint64_t)L.N * np * 4) : 0;
     }
-    L.off_tr_cov = L.off_tr_diag = L.off_tr_meta = o;
+    L.off_tr_cov = L.off_tr_diag = L.off_tr_meta = L.off_sc_ndiag = o;
     if (c.node_capacity > 0) {  // ipp_tree_step (k_tree.h)
         if (c.state_repr != IPP_FACTOR) return fail(-1, "node_capacity needs IPP_FACTOR");
-        const uint64_t nc = c.node_capacity;
-        L.off_tr_cov = o; o += up(nc * L.MC * np * 4);
-        L.off_tr_diag = o; o += up(nc * np * 4);
-        L.off_tr_meta = o; o += up(nc * 2 * 4);
+        const uint64_t nc = c.node_capacity, wc = (uint64_t)L.win_tiles * 64 * L.VEC;  // a node lives on its step's tile span
+        L.off_tr_cov = o; o += up(nc * L.MC * wc * 4 + 4096);
+        L.off_tr_diag = o; o += up(nc * wc * 4 + 4096);
+        L.off_tr_meta = o; o += up(nc * 4 * 4);
+        L.off_sc_ndiag = o; o += c.score_scratch ? up(np * 4) : 0;
     }
     L.total = o;
     return 0;
@@ -523,12 +531,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
     v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
-    v.win_tiles = v.n_tiles;
-    if (v.window_rows > 0) {
-        // rows a step can touch: the footprint (ny <= m <= MC blocks of rf <= 2 rows) + window_rows on both sides
-        const long rows = std::min<long>(v.H, 2L * v.window_rows + 2L * L.MC);
-        v.win_tiles = (int)std::min<long>(v.n_tiles, (rows * v.W + v.tile_cells - 1) / v.tile_cells + 1);
-    }
+    v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;
     v.hdr = reinterpret_cast<ItemHdr*>(base + L.off_hdr);
@@ -548,6 +551,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         e->tv.node_cov = reinterpret_cast<float*>(base + L.off_tr_cov);
         e->tv.node_diag = reinterpret_cast<float*>(base + L.off_tr_diag);
         e->tv.node_meta = reinterpret_cast<int*>(base + L.off_tr_meta);
+        e->tv.win_cells = L.win_tiles * 64 * L.VEC;
+        e->node_diag_scratch = cfg->score_scratch ? reinterpret_cast<float*>(base + L.off_sc_ndiag) : nullptr;
     }
     e->scoring = cfg->score_scratch != 0;
     if (e->scoring) {
@@ -862,9 +867,9 @@ static int score_actions_impl(void* engine, int32_t env_id, const ScorePath& pat
     if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_hdr<9>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status, node_diag);
     else                 hipLaunchKernelGGL((k_score_hdr<25>), dim3(hdr_blocks), dim3(256), 0, s, v, sv, env_id, actions, n, pa, flags, reward, status, node_diag);
     if (v.mode == IPP_FACTOR && path.depth > 0)
-        hipLaunchKernelGGL(k_score_densify<true>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, path, e->tv.node_cov, e->tv.node_meta);
+        hipLaunchKernelGGL(k_score_densify<true>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, path, e->tv.node_cov, e->tv.node_meta, e->tv.win_cells);
     else if (v.mode == IPP_FACTOR)
-        hipLaunchKernelGGL(k_score_densify<false>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, path, nullptr, nullptr);
+        hipLaunchKernelGGL(k_score_densify<false>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, path, nullptr, nullptr, 0);
     hipLaunchKernelGGL(k_score_band, dim3(v.H, kScoreDCap + 1, kScoreSplit), dim3(256), band_lds, s, v, sv, band_kc);
     if (v.meas_cap == 9) hipLaunchKernelGGL((k_score_eval<9>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
     else                 hipLaunchKernelGGL((k_score_eval<25>), dim3((n + 3) / 4), dim3(256), 0, s, v, sv, n, reward);
@@ -887,11 +892,11 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     e->last_n = n;
     const View& v = e->v;
     if (v.meas_cap == 9)
-        hipLaunchKernelGGL((k_tree_step<9, 4>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
-                           action, prev_action, flags, e->lut_rows, status, reward);
+        timed_launch(e, 0, k_tree_step<9, 4>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
+                     action, prev_action, flags, e->lut_rows, status, reward);
     else
-        hipLaunchKernelGGL((k_tree_step<25, 2>), dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
-                           action, prev_action, flags, e->lut_rows, status, reward);
+        timed_launch(e, 0, k_tree_step<25, 2>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
+                     action, prev_action, flags, e->lut_rows, status, reward);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -901,8 +906,9 @@ int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream) 
     if (!e || !out) return fail(-1, "null argument");
     if (node_id < 0 || node_id >= e->tv.node_cap) return fail(-1, "node_id %d outside [0, %d)", node_id, e->tv.node_cap);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpyAsync(out, e->tv.node_diag + (size_t)node_id * e->v.Npad, (size_t)e->v.N * 4, hipMemcpyDeviceToDevice,
-                           reinterpret_cast<hipStream_t>(stream)));
+    hipLaunchKernelGGL(k_tree_read_diag, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
+                       node_id, out);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -919,7 +925,7 @@ int ipp_state_plane(void* engine, int32_t env_id, const float* mean_for_mask, ui
     if (v.mode == IPP_DENSE) sv.P = v.cov + (size_t)env_id * v.cov_slot;
     hipLaunchKernelGGL(k_plane_mask, dim3((v.Npad + 255) / 256), dim3(256), 0, s, v, env_id, mean_for_mask, flags, sv.mask, sv.extent);
     if (v.mode == IPP_FACTOR)
-        hipLaunchKernelGGL(k_score_densify<false>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, ScorePath{}, nullptr, nullptr);
+        hipLaunchKernelGGL(k_score_densify<false>, dim3(v.Npad / 64, (v.N + 63) / 64), dim3(256), 0, s, v, sv, env_id, ScorePath{}, nullptr, nullptr, 0);
     const int blocks = std::min(v.N, 1024);
     hipLaunchKernelGGL(k_plane_minmax, dim3(blocks), dim3(256), 0, s, v, sv.P, sv.mask, sv.extent);
     hipLaunchKernelGGL(k_plane_write, dim3(blocks), dim3(256), 0, s, v, sv.P, sv.mask, sv.extent, out);
@@ -944,7 +950,14 @@ int ipp_tree_score_actions(void* engine, int32_t root_id, const int32_t* path_id
         if (id >= e->tv.node_cap) return fail(-1, "node id %d outside [0, %d)", id, e->tv.node_cap);
         path.ids[path.depth++] = id;
     }
-    const float* node_diag = path.depth ? e->tv.node_diag + (size_t)path.ids[path.depth - 1] * e->v.Npad : nullptr;
+    const float* node_diag = nullptr;
+    if (path.depth) {  // the node's diagonal lives on its span only: assemble the whole one along the parent chain
+        if (!e->node_diag_scratch) return fail(-1, "ipp_tree_score_actions needs ipp_config.score_scratch = 1");
+        HIP_TRY(hipSetDevice(e->device));
+        hipLaunchKernelGGL(k_tree_read_diag, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
+                           path.ids[path.depth - 1], e->node_diag_scratch);
+        node_diag = e->node_diag_scratch;
+    }
     return score_actions_impl(engine, root_id, path, node_diag, actions, n, prev_action, flags, reward, status, stream);
 }
 

@@ -111,7 +111,8 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // updated with no-return float atomics (one add per cell, bit-identical to load + add + store): the tile loop has no
 // mean / diag loads, whose latency sat in front of every tile's stream.
 // CHAIN (ipp_tree_step): the streamed columns come from a chained tree state (cc), the m new columns go to the new
-// node's block, diag_rw is the new node's diagonal (initialised as a copy of its parent's), and instead of the env's
+// node's block (stride cc->nstride, pointer pre-shifted to absolute cells), diag_rw is the new node's diagonal on its
+// span (pre-shifted too, initialised by phase A as a copy of the parent state's), and instead of the env's
 // rank / spans the node's (m, span) record is written; nothing of the root env slot is modified.
 // QCONST: qrows is read through the constant address space (scalar loads whatever the compiler can prove about
 // aliasing); the caller guarantees the rows are complete and visible before the call and unchanged during it.
@@ -403,7 +404,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 if (j < m && !((IPP_GF_ABLATE & 32) && acc[0][0] != 12345.f)) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
-                    store_stream<VEC>((CHAIN ? new_cols + (size_t)j * npad : cov_dst + (size_t)(r + j) * npad) + cell0, outv);
+                    store_stream<VEC>((CHAIN ? new_cols + (size_t)j * cc->nstride : cov_dst + (size_t)(r + j) * npad) + cell0, outv);
                 }
         }
         __builtin_amdgcn_wave_barrier();

@@ -101,7 +101,7 @@ struct ScorePath { int depth; int ids[kTreeDepth]; };
 
 template <bool CHAIN>
 __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int env, ScorePath path, const float* __restrict__ node_cov,
-                                                       const int* __restrict__ node_meta) {
+                                                       const int* __restrict__ node_meta, int win_cells) {
     constexpr int TB = 64, KC = 32;
     __shared__ float ui[KC][TB + 1], uj[KC][TB + 1];
     const int i0 = blockIdx.y * TB, j0 = blockIdx.x * TB;
@@ -111,17 +111,17 @@ __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int
     const int* span = v.colspan + (size_t)env * v.rank_cap;
     ChainCols cc;
     if (CHAIN) {
-        cc.root = U; cc.root_spans = span; cc.r_root = r; cc.depth = 0; cc.npad = (size_t)v.Npad;
+        cc.root = U; cc.root_spans = span; cc.r_root = r; cc.depth = 0; cc.npad = (size_t)v.Npad; cc.nstride = (size_t)win_cells;
 #pragma unroll
         for (int j = 0; j < kTreeDepth; ++j) { cc.node[j] = U; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0; }
 #pragma unroll
         for (int j = 0; j < kTreeDepth; ++j)
             if (j < path.depth) {
                 const int id = path.ids[j];
-                cc.node[j] = node_cov + (size_t)id * v.meas_cap * v.Npad;
+                cc.nspan[j] = node_meta[4 * id + 1];
+                cc.node[j] = node_cov + (size_t)id * v.meas_cap * win_cells - (size_t)(cc.nspan[j] & 0xffff) * v.tile_cells;
                 cc.off[j] = r;
-                cc.nspan[j] = node_meta[2 * id + 1];
-                r += node_meta[2 * id];
+                r += node_meta[4 * id];
             }
         cc.depth = path.depth;
     }

@@ -2,8 +2,8 @@
 // <= episode_horizon levels per simulation, every level one covariance-only predict step from the parent's state,
 // and keeps the child's covariance as the new node's state).
 //
-// A node does not copy its parent: it stores only the m <= MC columns its own step appended (on their tile span)
-// and its diagonal.  The state of a node is  P_root - sum over the path's nodes of C_n C_n^T, so a step streams the
+// A node does not copy its parent: it stores only the m <= MC columns its own step appended and its diagonal, both on
+// the tile span of its step only (TreeView).  The state of a node is  P_root - sum over the path's nodes of C_n C_n^T, so a step streams the
 // root env's columns followed by the column blocks of the path (ChainCols) -- the root slab is shared by all the
 // simulations below it (L2 hits), a node costs (MC + 1) rows instead of a slot copy.
 // Same phases as k_step_factor (k_step_factor.h); the root env slot is never written.
@@ -12,11 +12,31 @@
 
 namespace ipp {
 
+// Node storage is COMPACT: a node's step changes the state only on the tiles [t_lo, t_hi] of its window (at most
+// View::win_tiles of them), so the node keeps its <= MC columns and its diagonal on those tiles only -- 0.32 MB instead of
+// 1.6 MB per node at 200x200.  The diagonal of a node's state on any other tile is that of the nearest ancestor whose
+// span covers the tile, or the root env's (diag_source below).
 struct TreeView {
-    float* node_cov;   // [node_cap][MC][Npad] columns appended by the node's step
-    float* node_diag;  // [node_cap][Npad]     diag of the node's state
-    int* node_meta;    // [node_cap][2]        m, tile span (lo | hi << 16)
+    float* node_cov;   // [node_cap][MC][win_cells] columns appended by the node's step, cell c at index c - t_lo * tile_cells
+    float* node_diag;  // [node_cap][win_cells]     diag of the node's state on its span
+    int* node_meta;    // [node_cap][4]             m, tile span (lo | hi << 16), parent node (-1: child of the root env), root env
     int node_cap;
+    int win_cells;     // View::win_tiles * View::tile_cells
+};
+
+// Pointer (indexed with the absolute cell) to the diagonal of the state (root env `root_diag` + path nodes) on `tile`.
+struct DiagChain {
+    const float* root_diag;
+    const float* node[kTreeDepth];  // pre-shifted by -t_lo tiles like ChainCols::node
+    int nspan[kTreeDepth];
+    int depth;
+    __device__ __forceinline__ const float* source(int tile) const {
+        const float* p = root_diag;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < depth && tile >= (nspan[j] & 0xffff) && tile <= (nspan[j] >> 16)) p = node[j];  // deeper nodes override
+        return p;
+    }
 };
 
 template <int MC, int VEC>
@@ -41,64 +61,70 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     cc.r_root = uni(v.rank[root]);
     cc.depth = 0;
     cc.npad = (size_t)v.Npad;
+    cc.nstride = (size_t)tv.win_cells;
     int n_cols = cc.r_root;
-    const float* parent_diag = v.diag + (size_t)root * v.Npad;
+    DiagChain dc;
+    dc.root_diag = v.diag + (size_t)root * v.Npad;
+    dc.depth = 0;
+    int parent_id = -1;
 #pragma unroll
     for (int j = 0; j < kTreeDepth; ++j) {
         cc.node[j] = cc.root; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0;
+        dc.node[j] = dc.root_diag; dc.nspan[j] = 0xffff;  // (lo 0xffff > hi 0: covers nothing)
     }
 #pragma unroll
     for (int j = 0; j < kTreeDepth; ++j) {
         const int id = uni(path_ids[(size_t)item * kTreeDepth + j]);
         if (id >= 0 && id < tv.node_cap) {
+            const int sp = uni(tv.node_meta[4 * id + 1]);
+            const size_t shift = (size_t)(sp & 0xffff) * v.tile_cells;  // first cell of the node's span
 #pragma unroll
-            for (int d = 0; d < kTreeDepth; ++d)  // (static indices only: cc lives in registers)
+            for (int d = 0; d < kTreeDepth; ++d)  // (static indices only: cc / dc live in registers)
                 if (d == cc.depth) {
-                    cc.node[d] = tv.node_cov + (size_t)id * MC * v.Npad;
+                    cc.node[d] = tv.node_cov + (size_t)id * MC * tv.win_cells - shift;
                     cc.off[d] = n_cols;
-                    cc.nspan[d] = uni(tv.node_meta[2 * id + 1]);
+                    cc.nspan[d] = sp;
+                    dc.node[d] = tv.node_diag + (size_t)id * tv.win_cells - shift;
+                    dc.nspan[d] = sp;
                 }
-            n_cols += uni(tv.node_meta[2 * id]);
+            n_cols += uni(tv.node_meta[4 * id]);
             cc.depth += 1;
-            parent_diag = tv.node_diag + (size_t)id * v.Npad;
+            dc.depth += 1;
+            parent_id = id;
         }
     }
     const int new_id = new_ids ? uni(new_ids[item]) : -1;
     const bool expand = new_id >= 0 && new_id < tv.node_cap && !(flags & IPP_PREDICT_ONLY);
     const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
-    float* new_cols = expand ? tv.node_cov + (size_t)new_id * MC * v.Npad : nullptr;
-    float* new_diag = expand ? tv.node_diag + (size_t)new_id * v.Npad : nullptr;
-    int* new_meta = expand ? tv.node_meta + 2 * new_id : nullptr;
+    // (shifted by the new node's own t_lo once the header is known: in `mid` below / after the prologue)
+    float* new_cols0 = expand ? tv.node_cov + (size_t)new_id * MC * tv.win_cells : nullptr;
+    float* new_diag0 = expand ? tv.node_diag + (size_t)new_id * tv.win_cells : nullptr;
+    int* new_meta = expand ? tv.node_meta + 4 * new_id : nullptr;
 
-    // ---- phase A; under the footprint-dependent loads: tables, mask bits of the touched tiles (root mean, parent
-    // diag), and the new node's diagonal starts as a copy of its parent's (the tile epilogues subtract from it)
+    // ---- phase A; under the footprint-dependent loads: tables, mask bits of the touched tiles (root mean, diagonal of
+    // the parent state through the chain), and the new node's diagonal on ITS span starts as a copy of the parent
+    // state's (the tile epilogues subtract from it).  Round 1 copied the whole N-cell diagonal per new node: 320 KB of
+    // traffic per item at 200x200, as much as the step streamed.
     auto mid = [&](const ItemHdr& hh) {
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
         typedef float cellv __attribute__((ext_vector_type(VEC)));
         const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
-        const cellv* diag_v = reinterpret_cast<const cellv*>(parent_diag);
         const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
+        float* new_diag_sh = expand ? new_diag0 - (size_t)hh.t_lo * v.tile_cells : nullptr;
         for (int q = hh.t_lo * kWave + tid; q < (hh.t_hi + 1) * kWave; q += kStepThreads) {
             unsigned bits = (1u << VEC) - 1u;
-            if (adaptive) {
-                const cellv mu = mean_v[q], dg = diag_v[q];
-                bits = 0;
+            if (adaptive || expand) {
+                const cellv dg = reinterpret_cast<const cellv*>(dc.source(q / kWave))[q];  // (kWave groups of VEC cells per tile)
+                if (expand) reinterpret_cast<cellv*>(new_diag_sh)[q] = dg;
+                if (adaptive) {
+                    const cellv mu = mean_v[q];
+                    bits = 0;
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) bits |= (((double)mu[c] + v.kf * (double)dg[c] >= v.thr) ? 1u : 0u) << c;
+                    for (int c = 0; c < VEC; ++c) bits |= (((double)mu[c] + v.kf * (double)dg[c] >= v.thr) ? 1u : 0u) << c;
+                }
             }
             lds.mask4[q - hh.t_lo * kWave] = (unsigned char)bits;
-        }
-        if (expand) {
-            const float4* src = reinterpret_cast<const float4*>(parent_diag);
-            float4* dst = reinterpret_cast<float4*>(new_diag);
-            for (int q0 = tid; q0 < v.Npad / 4; q0 += 4 * kStepThreads) {
-                float4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int q = q0 + u * kStepThreads; t[u] = (q < v.Npad / 4) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int q = q0 + u * kStepThreads; if (q < v.Npad / 4) dst[q] = t[u]; }
-            }
         }
         const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
         for (int i = tid; i < lut_rows * v.W; i += kStepThreads) {
@@ -136,8 +162,33 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // the new node's blocks, indexed with absolute cells from here on
+    float* new_cols = expand ? new_cols0 - (size_t)h.t_lo * v.tile_cells : nullptr;
+    float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
+    if (expand && tid == 0) { new_meta[2] = parent_id; new_meta[3] = root; }
     gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
                                                          reward_out, &cc, new_cols, new_diag, new_meta);
+}
+
+// diag of a node's state, assembled along its parent chain: out[c] = diagonal of the deepest node (from `node` upwards)
+// whose span covers c's tile, else the root env's.
+__global__ void k_tree_read_diag(View v, TreeView tv, int node, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= v.N) return;
+    const int tile = c / v.tile_cells;
+    int cur = node, root = tv.node_meta[4 * node + 3];
+    float val = 0.f;
+    bool found = false;
+    for (int hops = 0; hops <= kTreeDepth && cur >= 0; ++hops) {
+        const int sp = tv.node_meta[4 * cur + 1], lo = sp & 0xffff, hi = sp >> 16;
+        if (tile >= lo && tile <= hi) {
+            val = tv.node_diag[(size_t)cur * tv.win_cells + (c - lo * v.tile_cells)];
+            found = true;
+            break;
+        }
+        cur = tv.node_meta[4 * cur + 2];
+    }
+    out[c] = found ? val : v.diag[(size_t)root * v.Npad + c];
 }
 
 }  // namespace ipp
