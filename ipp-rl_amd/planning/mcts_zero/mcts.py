@@ -371,5 +371,5 @@ class BatchedMCTS:
             policy = [0] * A
             policy[best] = 1
             return policy, visits
-        vt = np.array([v ** (1.0 / temperature) for v in visits])
+        vt = visits ** (1.0 / temperature)  # (the reference loops over the actions: same IEEE pow per element)
         return (vt / np.sum(vt)).tolist(), self.next_actions_mask(prev, budget)
