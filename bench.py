@@ -492,9 +492,14 @@ def main(argv=None):
     import torch
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
-    ranks = Ranks("nccl", device=device)
+    # Test hook for single-GPU boxes (tests/test_hip_bench_launcher.py): IPP_BENCH_SHARE_GPU=1 puts every rank on cuda:0
+    # and uses gloo (RCCL refuses two ranks on one device), so that the launcher, the rank plumbing, the shard offsets and
+    # the aggregation run end to end; the numbers of such a run mean nothing.
+    share = os.environ.get("IPP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
+    ranks = Ranks("gloo" if share else "nccl", device=None if share else device)
     rank, world = ranks.rank, ranks.world
     lo, hi, total_envs, scaling = shard_plan(args, rank, world)
     B, T = hi - lo, args.episode_steps

@@ -1,0 +1,42 @@
+"""
+`python bench.py --gpus 2` end to end on the one GPU of the test box: the parent process (which never touches the GPU)
+starts two ranks through torch.distributed.run, each builds its shard's batched env at its global env-id offset, the
+timed region is bracketed by barriers, rank 0 prints ONE JSON line with n_gpus = 2 and per-rank rates.  Both ranks share
+cuda:0 and talk over gloo (IPP_BENCH_SHARE_GPU: RCCL refuses two ranks on one device), so only the plumbing is under
+test here -- the RCCL path itself differs by the backend string.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_whole_job():
+    env = dict(os.environ, IPP_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "256", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6 and d["warmup"] == 2
+    cfg = d["config"]
+    assert cfg["envs_per_gpu"] == 256 and cfg["envs_total"] == 512
+    assert len(cfg["per_rank_ms_per_step"]) == 2 and len(cfg["per_rank_env_steps_per_s"]) == 2
+    assert cfg["items_with_nonzero_status"] == 0 and cfg["non_finite_rewards"] == 0
+    # value = envs of ALL ranks x steps / the slowest rank's time
+    assert abs(d["value"] - 512 * 6 / (max(cfg["per_rank_ms_per_step"]) * 6e-3)) / d["value"] < 1e-6
+    assert d["roofline"]["kernel"] == "k_step_factor" and d["roofline"]["achieved"] > 0
+    # strong scaling: the total split into contiguous ranges
+    cmd = cmd[:2] + ["--gpus", "2", "--envs-total", "384", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["envs_total"] == 384 and d["config"]["envs_per_gpu"] == 192
