@@ -25,8 +25,9 @@
 // against 0.313 ms for k_step_factor.  What was tried on the producer: the m x m algebra in registers (30 -> 16 us),
 // INTER_AREA weights one per lane, the producer as an out-of-line function with its own register allocation (the inlined
 // kernel spills 60-150 VGPRs; out of line the argument copies through scratch made it slower: 58 us).  What it would
-// take: <= 35 us per item, i.e. the next item's inputs prefetched under the current item and one gather pass for
-// ranks up to ~120 (7 x 9 lanes instead of 4 x 16).  A persistent grid also keeps every CU busy until it ends, so the
+// take: <= 35 us per item, i.e. the next item's inputs prefetched under the current item and fewer registers in the
+// producer path (a 7 x 9 lane gather with 112 rows per pass cut the gather 13 -> 11 us but the extra live registers
+// cost as much in the table phase: 52 us).  A persistent grid also keeps every CU busy until it ends, so the
 // side-stream ground-truth kernels of VecIPPEnv cannot overlap with it (configs[2]: +0.6 ms per step).
 #pragma once
 #include "ipp_common.h"
