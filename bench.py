@@ -428,13 +428,15 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
             "frac": gbs / HBM_PEAK_GBS}
 
 
-def run_mcts_driver(torch, device, *, grid=200, roots=256, sims=64, in_flight=4, root_steps=3):
-    """The batched tree-search DRIVER (ipp_rl_amd/planning/mcts_zero/mcts.py: PUCT selection, valid-action mask, forced
-    playouts, Dirichlet noise, backup; reference planning/mcts_zero/mcts.py:83-296) on the configs[4] grid with a stubbed
-    network (uniform priors, constant value).  Selection and bookkeeping run on the host in NumPy, every covariance step on
-    the device in per-level ipp_tree_step launches shared by all roots: the figure is host-bound and reported as such."""
+def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=4, root_steps=3):
+    """BASELINE configs[4] through the tree-search DRIVER (ipp_rl_amd/planning/mcts_zero/vector_mcts.py: PUCT selection,
+    valid-action mask, forced playouts, Dirichlet noise, transposition-aware backup; reference
+    planning/mcts_zero/mcts.py:83-296) with a stubbed network (uniform priors, constant value): 1024 roots x 256
+    simulations on 200x200.  Selection and bookkeeping run on the host, vectorised over the roots in NumPy; every
+    covariance step runs on the device in per-level ipp_tree_step launches shared by all roots.  Host-bound, reported as
+    such (the device part of the same search is the tree wave above)."""
     from ipp_rl_amd import EngineConfig, IPPEngine
-    from ipp_rl_amd.planning.mcts_zero.mcts import BatchedMCTS
+    from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS as BatchedMCTS
     from ipp_rl_amd.vec_env import cell_centre_actions
 
     cfg = EngineConfig(x_dim=grid, y_dim=grid)
@@ -462,13 +464,14 @@ def run_mcts_driver(torch, device, *, grid=200, roots=256, sims=64, in_flight=4,
     out = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ok = all(o is not None and abs(sum(o[0]) - 1.0) < 1e-9 for o in out)
+    ok = all(o is not None and abs(sum(o[0].values() if isinstance(o[0], dict) else o[0]) - 1.0) < 1e-9 for o in out)
     st = dict(mcts.stats)
     eng.close()
     del eng, mcts
     torch.cuda.empty_cache()
-    return {"name": f"tree-search driver on the configs[4] grid: {roots} roots x {sims} simulations ({in_flight} in flight per root), "
-                    f"{grid}x{grid}, horizon {horizon}, stubbed network; host-side PUCT / backup in NumPy (host-bound)",
+    return {"name": f"BASELINE configs[4] through the tree-search driver: {roots} roots x {sims} simulations ({in_flight} in flight per "
+                    f"root), {grid}x{grid}, horizon {horizon}, stubbed network; PUCT / backup on the host, vectorised over the roots "
+                    f"(host-bound)",
             "value": roots * sims / dt, "unit": "simulations/s", "seconds_per_search": dt, "device_tree_steps": st["device_steps"],
             "launches": st["launches"], "nodes": st["nodes"], "inferences": st["inferences"], "all_policies_valid": ok}
 

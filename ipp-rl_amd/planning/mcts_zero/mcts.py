@@ -68,9 +68,13 @@ class _Node:
 
 class BatchedMCTS:
     def __init__(self, engine, hyper_params: Dict, meta_data: Dict, infer: Callable, node_capacity: Optional[int] = None,
-                 sims_in_flight: int = 1):
+                 sims_in_flight: int = 1, tie_break: str = "reference", row_costs: bool = False):
         """engine: factor-state IPPEngine with window_rows > 0 and node_capacity > 0 whose env slots hold the roots.
-        hyper_params / meta_data: the reference's dictionaries (mcts.py:25-49)."""
+        hyper_params / meta_data: the reference's dictionaries (mcts.py:25-49).
+        tie_break: "reference" = np.random.choice among equal PUCT scores (mcts.py:237); "first" = the lowest action index
+        (deterministic; what VectorMCTS is compared with).  row_costs: travel costs by the array formula of VectorMCTS
+        (same value up to the last bit of a 3-term sum) instead of actions.action_costs."""
+        self.tie_break, self.row_costs = tie_break, row_costs
         self.engine = engine
         self.hp, self.meta = hyper_params, meta_data
         self.infer = infer
@@ -134,6 +138,16 @@ class BatchedMCTS:
         cand = np.concatenate([order[start[y * W + x0]:start[y * W + x1 + 1]] for y in rows])  # cells of a row are adjacent
         d = np.linalg.norm(self.actions_np[cand] - position, ord=2, axis=1)
         return np.sort(cand[(d > 0) & (d <= budget) & (d < self.max_dist)]), None
+
+    def row_cost(self, actions: np.ndarray, prevs: np.ndarray) -> np.ndarray:
+        """actions.py:8-41 for rows of (action, previous waypoint) pairs."""
+        diff = actions - prevs
+        dist = np.sqrt((diff * diff).sum(axis=1))
+        if self.uav is None:
+            return dist
+        v, a = float(self.uav["max_v"]), float(self.uav["max_a"])
+        ramp = np.minimum(0.5 * dist, np.square(v) / (2 * a))
+        return (dist - 2 * ramp) / v + 2 * np.sqrt(2 * ramp / a)
 
     @staticmethod
     def _normalize_q(q: np.ndarray, has_outside: bool) -> np.ndarray:
@@ -252,10 +266,10 @@ class BatchedMCTS:
                 return out
             uct = self._uct(node, force_playouts=(depth == 0))
             ties = (uct == np.max(uct)).nonzero()[0]
-            k = int(rng.choice(ties))  # mcts.py:237
+            k = int(ties[0]) if self.tie_break == "first" else int(rng.choice(ties))  # mcts.py:237
             a_idx = int(node.idx[k])
             action = self.actions_np[a_idx]
-            cost = float(action_costs(action, prev, self.uav))
+            cost = float(self.row_cost(action[None], prev[None])[0]) if self.row_costs else float(action_costs(action, prev, self.uav))
             child = node.child[k]
             if child is None:
                 key = tuple(sorted(node.key + (a_idx,)))

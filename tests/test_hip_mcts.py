@@ -190,3 +190,44 @@ def test_rollout_policies_vs_oracle():
     assert np.array_equal(act, cands[int(np.argmax(want))] if u > 0.5 else cands[explore_idx])
     assert RolloutPolicy.widen(0, 0, 3, 0.5, 10) and RolloutPolicy.widen(3, 4, 3, 0.5, 10) and not RolloutPolicy.widen(7, 4, 3, 0.5, 10)
     assert not RolloutPolicy.widen(5, 100, 3, 0.5, 5)
+
+
+def test_vector_driver_on_the_device_equals_the_per_root_driver():
+    """VectorMCTS (host side vectorised over the roots) against BatchedMCTS on real device states: identical trees with
+    lowest-index tie-breaking, 16 roots x 48 simulations, 4 simulations in flight per root."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.mcts_zero.mcts import BatchedMCTS
+    from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    dim, R, sims, horizon = 20, 16, 48, 4
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    eng = IPPEngine(cfg, capacity=R, state="factor", rank_cap=9 * (3 + horizon + 2), window_rows=-1, fixed_prior=True,
+                    node_capacity=R * (sims + 8), max_batch=4 * R)
+    rs = np.random.RandomState(2)
+    eng.reset(white_noise=rs.normal(size=(R, dim, dim)))
+    prev = np.tile([2.0, 2.0, 14.0], (R, 1))
+    for t in range(3):
+        acts = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
+        eng.step(acts, prev, meas_noise=rs.normal(size=(R, 9)))
+        prev = acts
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+                 dirichlet_alpha=1.0, dirichlet_eps=0.25, num_mcts_simulations=sims)
+    meta = {"budget": 60.0, "initial_budget": 60.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
+            "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
+    roots = list(range(R))
+
+    def infer(reqs):
+        return [(None, stub_value(np.isin(np.arange(2 * dim * dim), r["valid_idx"]))) for r in reqs]
+
+    a = BatchedMCTS(eng, hyper, meta, infer, sims_in_flight=4, tie_break="first", row_costs=True)
+    out_a = a.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
+    b = VectorMCTS(eng, hyper, meta, infer, sims_in_flight=4, tie_break="first")
+    out_b = b.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
+    for j in roots:
+        nd, rt = a.last_roots[j], int(b.root_ids[j])
+        K = int(b.n_K[rt])
+        assert np.array_equal(nd.idx, b.t_idx[rt, :K]) and np.array_equal(nd.Nsa, b.t_Nsa[rt, :K])
+        assert np.max(np.abs(nd.Qsa - b.t_Qsa[rt, :K])) < 1e-6  # (device rewards are recomputed: fp32, bit-identical in practice)
+        assert np.allclose(out_a[j][0], out_b[j][0], atol=1e-9)
+    assert a.stats["nodes"] == b.stats["nodes"] and a.stats["device_steps"] == b.stats["device_steps"]
