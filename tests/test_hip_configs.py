@@ -263,3 +263,53 @@ def test_fullsize_tree_wave_1024_roots_256_sims_200x200():
     # the whole search again: identical bits
     r2 = search()
     assert torch.equal(r1, r2)
+
+
+def test_fullsize_search_through_the_driver_1024_roots_256_sims_200x200():
+    """configs[4] through the real search driver (VectorMCTS: PUCT, valid-action mask, forced playouts, Dirichlet noise,
+    transposition-aware backup; stub network): 1024 roots x 256 simulations on 200x200, 4 simulations in flight per root.
+    Invariants on every root and every node; the root env slots stay untouched."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    fresh_gpu()
+    grid, roots, sims, W, horizon, root_steps = 200, 1024, 256, 4, 5, 3
+    cfg = EngineConfig(x_dim=grid, y_dim=grid)
+    eng = IPPEngine(cfg, capacity=roots, state="factor", rank_cap=9 * (root_steps + horizon + 2), window_rows=-1, fixed_prior=True,
+                    node_capacity=roots * (sims + W), max_batch=roots * W)
+    white = torch.empty((roots, cfg.n_cells), dtype=torch.float32, device="cuda")
+    eng.normal_rows(white, cfg.n_cells, 9, 1 << 40)
+    eng.reset(white_noise=white)
+    noise = torch.empty((root_steps, roots, 9), dtype=torch.float32, device="cuda")
+    eng.normal_rows(noise, 9, 9, 2 << 40)
+    prev = np.tile([2.0, 2.0, 14.0], (roots, 1))
+    for t in range(root_steps):
+        a = cell_centre_actions(cfg, t, 0, roots, roots, [8.0, 14.0])
+        _, s = eng.step(a, prev, meas_noise=noise[t])
+        assert int(s.abs().sum()) == 0
+        prev = a
+    ranks0 = eng.ranks().clone()
+    diag0 = eng.read_diag(roots - 1).clone()
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+                 dirichlet_alpha=1.0, dirichlet_eps=0.25, num_mcts_simulations=sims)
+    meta = {"budget": 100.0, "initial_budget": 100.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
+            "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
+    mcts = VectorMCTS(eng, hyper, meta, lambda reqs: [(None, 0.3)] * len(reqs), sims_in_flight=W, seed=1)
+    out = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
+    n = mcts.n_count
+    print(f"[configs[4] driver] {mcts.stats['nodes']} nodes, {mcts.stats['device_steps']} device steps in {mcts.stats['launches']} launches")
+    for j in range(roots):
+        rt = int(mcts.root_ids[j])
+        K = int(mcts.n_K[rt])
+        assert mcts.n_Ns[rt] == sims - W == mcts.t_Nsa[rt, :K].sum()  # the first wave of W simulations expands the root
+        policy, valid = out[j]
+        assert abs(sum(policy.values()) - 1.0) < 1e-9 and set(policy) <= set(int(i) for i in valid)
+    assert np.all(mcts.t_Nsa[:n].sum(axis=1) == mcts.n_Ns[:n]) and np.all(mcts.t_Nsa[:n] >= 0)  # virtual visits undone
+    num = mcts.t_num[:n]
+    assert not np.any(np.isinf(num)) and np.all(num[~np.isnan(num)] > 0)  # every traversed edge has its (positive) trace reduction
+    q = mcts.t_Qsa[:n]
+    assert np.all(np.isfinite(q)) and np.all(q >= 0)
+    assert mcts.stats["launches"] <= (sims // W) * (horizon + 1)  # one launch per level and wave, shared by all roots
+    assert torch.equal(eng.ranks(), ranks0) and torch.equal(eng.read_diag(roots - 1), diag0)
