@@ -354,7 +354,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     return rec, cfg
 
 
-def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, root_steps=5, reps=4):
+def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, root_steps=5, reps=4, wave=4):
     """BASELINE configs[4]: `roots` root states x `sims` simulations on a grid x grid map, every simulation descending
     `depth` levels with one covariance-only predict step per level (planning/mcts_zero/mcts.py:166-265), batched as
     one ipp_tree_step launch per level over (roots x sims-in-flight) items; node storage is recycled between waves.
@@ -363,7 +363,7 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
     from ipp_rl_amd.vec_env import cell_centre_actions
 
     cfg = EngineConfig(x_dim=grid, y_dim=grid)
-    wave = 4  # simulations of one root in flight per launch (virtual-loss style batching): 4096 items per level
+    # wave: simulations of one root in flight per launch (virtual-loss style batching): 4096 items per level
     n_items = roots * wave
     eng = IPPEngine(cfg, capacity=roots, state="factor", rank_cap=9 * (root_steps + depth + 1), window_rows=-1, fixed_prior=True,
                     node_capacity=n_items * depth, max_batch=n_items, device=device)
@@ -416,15 +416,18 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
     torch.cuda.synchronize()
     counted, _ = eng.streamed_bytes_detail(reset=True)
     k_ms, k_n = eng.profile_read(0)
+    p_ms, p_n = eng.profile_read(2)  # launches >= 2048 items run as k_tree_prepare + k_tree_gain (else the fused k_tree_step)
     eng.profile(False)
-    gbs = (counted / max(k_n, 1)) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    split = p_n > 0
+    gbs = (counted / max(k_n, 1)) / ((k_ms + (p_ms if split else 0.0)) * 1e-3) / 1e9 if k_ms > 0 else 0.0
     eng.close()
     del eng
     torch.cuda.empty_cache()
     return {"name": f"BASELINE configs[4]: {roots} roots x {sims} sims, {grid}x{grid} grid, depth {depth}, GRF ground truth "
                     f"(predict steps at tree nodes, ipp_tree_step; {wave} simulations per root per launch)",
             "value": n_steps / dt, "unit": "tree-steps/s", "ms_per_search": dt * 1e3, "root_rank": root_rank,
-            "launch_items": n_items, "all_status_ok": ok, "kernel": "k_tree_step", "kernel_ms_avg": k_ms, "achieved_gbs": gbs,
+            "launch_items": n_items, "all_status_ok": ok, "kernel": "k_tree_prepare + k_tree_gain" if split else "k_tree_step",
+            "kernel_ms_avg": k_ms + (p_ms if split else 0.0), "prepare_ms_avg": p_ms if split else None, "achieved_gbs": gbs,
             "frac": gbs / HBM_PEAK_GBS}
 
 

@@ -78,6 +78,10 @@ struct Engine {
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
+    int tree_split_min = 0;   // ipp_tree_step: launches of at least this many items run k_tree_prepare + k_tree_gain (0: never)
+    int tree_T = kStepThreads;  // workgroup size of k_tree_gain
+    size_t tree_step_lds = 0;   // k_tree_step: the fused kernel's LDS + the column-pointer table
+    size_t tree_gain_lds = 0;
     size_t pipe_lds = 0;
     int pipe_grid = 0;    // resident workgroups of k_step_pipe on this device
     unsigned launch_seq = 0;
@@ -632,8 +636,19 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         if (e->pipe_grid <= 0) e->pipe = false;
         (void)hipGetLastError();
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    e->tree_step_lds = (e->gain_lds + (size_t)v.rank_cap * 8 + 15) & ~(size_t)15;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
+    if (e->fused && e->tv.node_cap > 0 && v.meas_cap == 9) {
+        // Split tree steps: worth it once the launch fills the device several times over (below that the second launch
+        // and the scratch round trip of L^-1 | Q cost more than the occupancy gains); IPP_TREE_SPLIT=<min items> / 0
+        if (const char* tt = getenv("IPP_TREE_T")) e->tree_T = (atoi(tt) == 128) ? 128 : kStepThreads;
+        e->tree_gain_lds = (GainLds<9>::bytes(v.rank_cap, 0, e->lut_rows * v.W, 0, e->tree_T / kWave, v.win_tiles, 0, v.rank_cap) + 15) & ~(size_t)15;
+        e->tree_split_min = 2048;
+        if (const char* ts = getenv("IPP_TREE_SPLIT")) e->tree_split_min = atoi(ts);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_prepare<9>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -891,11 +906,16 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     HIP_TRY(hipSetDevice(e->device));
     e->last_n = n;
     const View& v = e->v;
-    if (v.meas_cap == 9)
-        timed_launch(e, 0, k_tree_step<9, 4>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
+    if (v.meas_cap == 9 && e->tree_split_min > 0 && n >= e->tree_split_min) {
+        timed_launch(e, 2, k_tree_prepare<9>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action,
+                     prev_action, flags, status);
+        timed_launch(e, 0, k_tree_gain<9, 4>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
+                     new_ids, n, flags, e->lut_rows, reward);
+    } else if (v.meas_cap == 9)
+        timed_launch(e, 0, k_tree_step<9, 4>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                      action, prev_action, flags, e->lut_rows, status, reward);
     else
-        timed_launch(e, 0, k_tree_step<25, 2>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
+        timed_launch(e, 0, k_tree_step<25, 2>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                      action, prev_action, flags, e->lut_rows, status, reward);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -45,12 +45,13 @@ struct GainLds {
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
     int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
     double* tile_red;  // [win_tiles] masked trace reduction of every touched tile (summed in tile order at the end)
+    const float** rowp;  // [chain_rows] tree steps: pointer to every column of the chained state (ChainCols::row, evaluated once)
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
-                                            int n_tiles, int mask_bytes = 0) {
+                                            int n_tiles, int mask_bytes = 0, int chain_rows = 0) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
         b += (size_t)((rank_cap + 3) & ~3) * 4 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
         b = ((b + 15) & ~(size_t)15) + (size_t)mask_bytes;
-        b = ((b + 15) & ~(size_t)15) + (size_t)n_tiles * 8;
+        b = ((b + 15) & ~(size_t)15) + (size_t)n_tiles * 8 + (size_t)chain_rows * 8;
         return (b + 15) & ~(size_t)15;
     }
     // work: HT staging rows of the fused prologue (0 floats for the stand-alone kernel); lut: prior table;
@@ -78,6 +79,7 @@ struct GainLds {
         // adaptive-mask bits of the whole env, one byte per VEC cells (fused kernel), behind the per-wave index lists
         mask4 = reinterpret_cast<unsigned char*>(ridx_all + (((size_t)waves * (rank_cap + 8) + 7) & ~(size_t)7));
         tile_red = reinterpret_cast<double*>(mask4 + (((size_t)mask_bytes + 15) & ~(size_t)15));
+        rowp = reinterpret_cast<const float**>(tile_red + n_tiles);
     }
 };
 
@@ -96,6 +98,21 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
     }
 }
 
+// Pointer (indexed with the absolute cell) to the diagonal of the state (root env `root_diag` + path nodes) on `tile`.
+struct DiagChain {
+    const float* root_diag;
+    const float* node[kTreeDepth];  // pre-shifted by -t_lo tiles like ChainCols::node
+    int nspan[kTreeDepth];
+    int depth;
+    __device__ __forceinline__ const float* source(int tile) const {
+        const float* p = root_diag;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < depth && tile >= (nspan[j] & 0xffff) && tile <= (nspan[j] >> 16)) p = node[j];  // deeper nodes override
+        return p;
+    }
+};
+
 // Tile loop + per-item results; expects Ls / ys, the block tables, the prior table P0(|drow| < lut_rows, |dcol|)
 // (row distances beyond it fall back to sqrt / exp), span_s[0..r)
 // and the two counters (zeroed) in LDS, visible to the whole workgroup.
@@ -112,8 +129,9 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
 // mean / diag loads, whose latency sat in front of every tile's stream.
 // CHAIN (ipp_tree_step): the streamed columns come from a chained tree state (cc), the m new columns go to the new
 // node's block (stride cc->nstride, pointer pre-shifted to absolute cells), diag_rw is the new node's diagonal on its
-// span (pre-shifted too, initialised by phase A as a copy of the parent state's), and instead of the env's
-// rank / spans the node's (m, span) record is written; nothing of the root env slot is modified.
+// span (pre-shifted too; LMASK: initialised by phase A as a copy of the parent state's; else written here from the
+// parent state's diagonal, read through dch), and instead of the env's rank / spans the node's (m, span) record is
+// written; nothing of the root env slot is modified.
 // QCONST: qrows is read through the constant address space (scalar loads whatever the compiler can prove about
 // aliasing); the caller guarantees the rows are complete and visible before the call and unchanged during it.
 // RESET (ipp_step_autoreset): an item with ar->src[item] >= 0 resets its env once its step is complete: every wave
@@ -124,7 +142,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out, const ChainCols* cc = nullptr,
                                            float* new_cols = nullptr, float* diag_rw = nullptr, int* node_meta = nullptr,
-                                           const AutoReset* ar = nullptr) {
+                                           const AutoReset* ar = nullptr, const DiagChain* dch = nullptr) {
     constexpr int kWaveTile = VEC * kWave;  // cells per wave tile
     constexpr int QS = (MC + 3) & ~3;
     const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut; double* red = lds.red;
@@ -165,7 +183,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         float md_in[2][VEC];
         if (!LMASK) {
             load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, md_in[0]);
-            load_vec<VEC>(v.diag + (size_t)h.env * npad + cell0, md_in[1]);
+            load_vec<VEC>((CHAIN ? dch->source(tile) : v.diag + (size_t)h.env * npad) + cell0, md_in[1]);  // (CHAIN: the parent state's)
         }
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
@@ -219,7 +237,8 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) {
                         const int dr = abs(crow[c] - fy), dc = abs(ccol[c] - fx);
-                        const float p0 = tile_lut ? lut[dr * v.W + dc] : matern_f(dr, dc, s3, h.sv);
+                        // (24-bit multiply-add: v_mul_lo_u32 runs at quarter rate, and there are up to 36 VEC of these per tile)
+                        const float p0 = tile_lut ? lut[__umul24(dr, v.W) + dc] : matern_f(dr, dc, s3, h.sv);
                         cb[c] = fmaf(wa, p0, cb[c]);
                     }
                 }
@@ -235,14 +254,19 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     }
                 }
             } else {
-                for (int b = 0; b < ((IPP_GF_ABLATE & 1) ? 0 : m); ++b) {
-                    float cb[VEC];
-                    block_term(b, cb);
+                // L^-1 is upper triangular (solve_wave_fast: column j of inv(C^T) has rows i <= j): block b feeds the
+                // columns j >= b only, 45 instead of 81 FMAs per cell (b unrolled: acc[.][j] needs static indices)
 #pragma unroll
-                    for (int j = 0; j < MC; ++j) {
-                        const float l = Ls[b * MC + j];
+                for (int b = 0; b < MC; ++b) {
+                    if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                        float cb[VEC];
+                        block_term(b, cb);
 #pragma unroll
-                        for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                        for (int j = b; j < MC; ++j) {
+                            const float l = Ls[b * MC + j];
+#pragma unroll
+                            for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                        }
                     }
                 }
             }
@@ -272,7 +296,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     // padding entries (kk == r, zero Q row) read a column that IS stored on this tile: a column that is
                     // not stored here holds uninitialised memory, and NaN * 0 would poison the accumulators
                     const int ku = kk[i] < r ? kk[i] : safe_k;
-                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>((CHAIN ? cc->row(ku) : cov_src + (size_t)ku * npad) + cell0));
+                    // (CHAIN: the column's pointer from the LDS table; evaluating ChainCols::row here cost ~40 scalar
+                    // instructions per column and spilled SGPRs: the tile loop was issue-bound, not memory-bound)
+                    const float* rowk = CHAIN ? uni_ptr(lds.rowp[ku]) : cov_src + (size_t)ku * npad;
+                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk + cell0));
                 }
                 __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
 #pragma unroll
@@ -392,7 +419,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             } else {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
-                store_vec<VEC>(v.diag + (size_t)h.dst * npad + cell0, outv);
+                store_vec<VEC>((CHAIN ? diag_rw : v.diag + (size_t)h.dst * npad) + cell0, outv);
                 if (!(flags & IPP_COV_ONLY)) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) outv[c] = mean_in[c] + dmean[c];
@@ -429,13 +456,13 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     int arrived = 0;
     if (lane == 0) arrived = atomicAdd(done_waves, 1);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if (!CHAIN && arrived == 0 && lane == 0) IPP_MARK(item, 6);  // first wave out
+    if (arrived == 0 && lane == 0) IPP_MARK(item, 6);  // first wave out
     if (arrived != nw - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (PRE) dead = __hip_atomic_load(lds.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without tiles never looked)
     const bool commit_item = h.commit && !dead;
     if (lane == 0) {
-        if (!CHAIN) IPP_MARK(item, 2);
+        IPP_MARK(item, 2);
         double tot = 0.0;
         for (int t = 0; t <= h.t_hi - h.t_lo; ++t) tot += lds.tile_red[t];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31

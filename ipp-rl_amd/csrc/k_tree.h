@@ -24,20 +24,95 @@ struct TreeView {
     int win_cells;     // View::win_tiles * View::tile_cells
 };
 
-// Pointer (indexed with the absolute cell) to the diagonal of the state (root env `root_diag` + path nodes) on `tile`.
-struct DiagChain {
-    const float* root_diag;
-    const float* node[kTreeDepth];  // pre-shifted by -t_lo tiles like ChainCols::node
-    int nspan[kTreeDepth];
-    int depth;
-    __device__ __forceinline__ const float* source(int tile) const {
-        const float* p = root_diag;
+// The chained state of an item (every thread builds the same, wave-uniform description): column blocks and diagonal
+// sources of the path's nodes behind the root env's.  Returns the column count of the state; parent_id = the deepest
+// path node (-1: the item steps from the root env itself).
+template <int MC>
+__device__ __forceinline__ int tree_chain(const View& v, const TreeView& tv, const int item, const int* __restrict__ root_ids,
+                                          const int* __restrict__ path_ids, ChainCols& cc, DiagChain& dc, int& root, int& parent_id) {
+    root = min(max(root_ids[item], 0), v.cap - 1);  // (a bad id is reported by the prologue's slot check)
+    cc.root = v.cov + (size_t)root * v.cov_slot;
+    cc.root_spans = v.colspan + (size_t)root * v.rank_cap;
+    cc.r_root = uni(v.rank[root]);
+    cc.depth = 0;
+    cc.npad = (size_t)v.Npad;
+    cc.nstride = (size_t)tv.win_cells;
+    int n_cols = cc.r_root;
+    dc.root_diag = v.diag + (size_t)root * v.Npad;
+    dc.depth = 0;
+    parent_id = -1;
 #pragma unroll
-        for (int j = 0; j < kTreeDepth; ++j)
-            if (j < depth && tile >= (nspan[j] & 0xffff) && tile <= (nspan[j] >> 16)) p = node[j];  // deeper nodes override
-        return p;
+    for (int j = 0; j < kTreeDepth; ++j) {
+        cc.node[j] = cc.root; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0;
+        dc.node[j] = dc.root_diag; dc.nspan[j] = 0xffff;  // (lo 0xffff > hi 0: covers nothing)
     }
-};
+    // Two rounds of loads (all the path ids, then all the nodes' records) in front of branch-free bookkeeping: behind
+    // a per-level `if (id valid)` they are 2 kTreeDepth dependent scalar round trips.
+    int pid[kTreeDepth], pm[kTreeDepth], psp[kTreeDepth];
+#pragma unroll
+    for (int j = 0; j < kTreeDepth; ++j) pid[j] = uni(path_ids[(size_t)item * kTreeDepth + j]);
+#pragma unroll
+    for (int j = 0; j < kTreeDepth; ++j) {
+        const int idc = min(max(pid[j], 0), tv.node_cap - 1);
+        pm[j] = uni(tv.node_meta[4 * idc]);
+        psp[j] = uni(tv.node_meta[4 * idc + 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < kTreeDepth; ++j) {
+        const int id = pid[j];
+        if (id >= 0 && id < tv.node_cap) {
+            const int sp = psp[j];
+            const size_t shift = (size_t)(sp & 0xffff) * v.tile_cells;  // first cell of the node's span
+#pragma unroll
+            for (int d = 0; d < kTreeDepth; ++d)  // (static indices only: cc / dc live in registers)
+                if (d == cc.depth) {
+                    cc.node[d] = tv.node_cov + (size_t)id * MC * tv.win_cells - shift;
+                    cc.off[d] = n_cols;
+                    cc.nspan[d] = sp;
+                    dc.node[d] = tv.node_diag + (size_t)id * tv.win_cells - shift;
+                    dc.nspan[d] = sp;
+                }
+            n_cols += pm[j];
+            cc.depth += 1;
+            dc.depth += 1;
+            parent_id = id;
+        }
+    }
+    return n_cols;
+}
+
+// Phase-A work of a tree step on the tiles [t_lo, t_hi] of its window: the adaptive-mask bits (root mean, diagonal of
+// the parent state through the chain) and the new node's diagonal on ITS span, which starts as a copy of the parent
+// state's (the tile epilogues subtract from it); then the prior table.  Round 1 copied the whole N-cell diagonal per new
+// node: 320 KB of traffic per item at 200x200, as much as the step streamed.
+template <int MC, int VEC>
+__device__ __forceinline__ void tree_mid(const View& v, const ItemHdr& hh, const DiagChain& dc, const GainLds<MC>& lds, unsigned flags,
+                                         bool expand, float* new_diag0, int lut_rows) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    typedef float cellv __attribute__((ext_vector_type(VEC)));
+    const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
+    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
+    float* new_diag_sh = expand ? new_diag0 - (size_t)hh.t_lo * v.tile_cells : nullptr;
+    for (int q = hh.t_lo * kWave + tid; q < (hh.t_hi + 1) * kWave; q += T) {
+        unsigned bits = (1u << VEC) - 1u;
+        if (adaptive || expand) {
+            const cellv dg = reinterpret_cast<const cellv*>(dc.source(q / kWave))[q];  // (kWave groups of VEC cells per tile)
+            if (expand) reinterpret_cast<cellv*>(new_diag_sh)[q] = dg;
+            if (adaptive) {
+                const cellv mu = mean_v[q];
+                bits = 0;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) bits |= (((double)mu[c] + v.kf * (double)dg[c] >= v.thr) ? 1u : 0u) << c;
+            }
+        }
+        lds.mask4[q - hh.t_lo * kWave] = (unsigned char)bits;
+    }
+    const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
+    for (int i = tid; i < lut_rows * v.W; i += T) {
+        const int dr = i / v.W, dc2 = i - dr * v.W;
+        lds.lut[i] = matern_f(dr, dc2, s3, hh.sv);
+    }
+}
 
 template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
@@ -52,47 +127,13 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
+    if (tid == 0) IPP_MARK(item, 0);
 
-    // ---- the chained state of this item (every thread builds the same, wave-uniform description)
-    const int root = min(max(root_ids[item], 0), v.cap - 1);  // (a bad id is reported by the prologue's slot check)
     ChainCols cc;
-    cc.root = v.cov + (size_t)root * v.cov_slot;
-    cc.root_spans = v.colspan + (size_t)root * v.rank_cap;
-    cc.r_root = uni(v.rank[root]);
-    cc.depth = 0;
-    cc.npad = (size_t)v.Npad;
-    cc.nstride = (size_t)tv.win_cells;
-    int n_cols = cc.r_root;
     DiagChain dc;
-    dc.root_diag = v.diag + (size_t)root * v.Npad;
-    dc.depth = 0;
-    int parent_id = -1;
-#pragma unroll
-    for (int j = 0; j < kTreeDepth; ++j) {
-        cc.node[j] = cc.root; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0;
-        dc.node[j] = dc.root_diag; dc.nspan[j] = 0xffff;  // (lo 0xffff > hi 0: covers nothing)
-    }
-#pragma unroll
-    for (int j = 0; j < kTreeDepth; ++j) {
-        const int id = uni(path_ids[(size_t)item * kTreeDepth + j]);
-        if (id >= 0 && id < tv.node_cap) {
-            const int sp = uni(tv.node_meta[4 * id + 1]);
-            const size_t shift = (size_t)(sp & 0xffff) * v.tile_cells;  // first cell of the node's span
-#pragma unroll
-            for (int d = 0; d < kTreeDepth; ++d)  // (static indices only: cc / dc live in registers)
-                if (d == cc.depth) {
-                    cc.node[d] = tv.node_cov + (size_t)id * MC * tv.win_cells - shift;
-                    cc.off[d] = n_cols;
-                    cc.nspan[d] = sp;
-                    dc.node[d] = tv.node_diag + (size_t)id * tv.win_cells - shift;
-                    dc.nspan[d] = sp;
-                }
-            n_cols += uni(tv.node_meta[4 * id]);
-            cc.depth += 1;
-            dc.depth += 1;
-            parent_id = id;
-        }
-    }
+    int root, parent_id;
+    const int n_cols = tree_chain<MC>(v, tv, item, root_ids, path_ids, cc, dc, root, parent_id);
+    for (int k = tid; k < min(n_cols, v.rank_cap); k += kStepThreads) lds.rowp[k] = cc.row(k);  // (published by the prologue's barriers)
     const int new_id = new_ids ? uni(new_ids[item]) : -1;
     const bool expand = new_id >= 0 && new_id < tv.node_cap && !(flags & IPP_PREDICT_ONLY);
     const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
@@ -101,36 +142,11 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     float* new_diag0 = expand ? tv.node_diag + (size_t)new_id * tv.win_cells : nullptr;
     int* new_meta = expand ? tv.node_meta + 4 * new_id : nullptr;
 
-    // ---- phase A; under the footprint-dependent loads: tables, mask bits of the touched tiles (root mean, diagonal of
-    // the parent state through the chain), and the new node's diagonal on ITS span starts as a copy of the parent
-    // state's (the tile epilogues subtract from it).  Round 1 copied the whole N-cell diagonal per new node: 320 KB of
-    // traffic per item at 200x200, as much as the step streamed.
+    // ---- phase A; under the footprint-dependent loads: tables, mask bits and the new node's diagonal (tree_mid)
     auto mid = [&](const ItemHdr& hh) {
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
-        typedef float cellv __attribute__((ext_vector_type(VEC)));
-        const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
-        const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
-        float* new_diag_sh = expand ? new_diag0 - (size_t)hh.t_lo * v.tile_cells : nullptr;
-        for (int q = hh.t_lo * kWave + tid; q < (hh.t_hi + 1) * kWave; q += kStepThreads) {
-            unsigned bits = (1u << VEC) - 1u;
-            if (adaptive || expand) {
-                const cellv dg = reinterpret_cast<const cellv*>(dc.source(q / kWave))[q];  // (kWave groups of VEC cells per tile)
-                if (expand) reinterpret_cast<cellv*>(new_diag_sh)[q] = dg;
-                if (adaptive) {
-                    const cellv mu = mean_v[q];
-                    bits = 0;
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) bits |= (((double)mu[c] + v.kf * (double)dg[c] >= v.thr) ? 1u : 0u) << c;
-                }
-            }
-            lds.mask4[q - hh.t_lo * kWave] = (unsigned char)bits;
-        }
-        const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
-        for (int i = tid; i < lut_rows * v.W; i += kStepThreads) {
-            const int dr = i / v.W, dc = i - dr * v.W;
-            lds.lut[i] = matern_f(dr, dc, s3, hh.sv);
-        }
+        tree_mid<MC, VEC>(v, hh, dc, lds, flags, expand, new_diag0, lut_rows);
     };
     ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true, decltype(mid), true>(
         v, item, root_ids, nullptr, action, prev_action, nullptr, flags_eff, status_out, nullptr, nullptr, nullptr, lds.small,
@@ -155,10 +171,12 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();
+    if (tid == 0) IPP_MARK(item, 1);
     if (tid < kWave) {
         int status;
         if constexpr (MC == 9) status = solve_wave_fast<MC>(v, h, item, flags_eff, lds.small, lds.work, 1, QS, lds.Ls, lds.ys, nullptr, status_out);
         else status = solve_wave<MC>(v, h, item, flags_eff, lds.small, lds.work, lds.Ls, lds.ys, status_out);
+        if (tid == 0) IPP_MARK(item, 7);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -168,6 +186,96 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     if (expand && tid == 0) { new_meta[2] = parent_id; new_meta[3] = root; }
     gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
                                                          reward_out, &cc, new_cols, new_diag, new_meta);
+}
+
+// ---- the same step as two launches (configs[4]-sized waves): in k_tree_step about 40 % of a workgroup's life is the
+// latency-bound prologue, during which its registers and LDS hold no stream.  k_tree_prepare runs the prologue and the
+// m x m algebra for all items at the prologue's own (higher) occupancy and leaves header | L^-1 | Q rows in the item
+// scratch; k_tree_gain streams.  Same arithmetic as the fused kernel except that L^-1 is folded into Q before the
+// stream (like k_prepare / k_gain_factor) instead of applied per tile: results agree to fp32 rounding, not bit for bit.
+template <int MC>
+__global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_tree_prepare(
+    View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
+    int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
+    int* __restrict__ status_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tp[];
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
+    constexpr int LQ = (MC * MC + MC + 3) & ~3;
+    ChainCols cc;
+    DiagChain dc;
+    int root, parent_id;
+    const int n_cols = tree_chain<MC>(v, tv, item, root_ids, path_ids, cc, dc, root, parent_id);
+    const int new_id = new_ids ? uni(new_ids[item]) : -1;
+    const bool expand = new_id >= 0 && new_id < tv.node_cap && !(flags & IPP_PREDICT_ONLY);
+    const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
+    float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]
+    float* big = reinterpret_cast<float*>(smem_tp + ((prep_small_bytes<MC>() + 15) & ~(size_t)15));
+    ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kPrepThreads, true, NoMidWork, true>(
+        v, item, root_ids, nullptr, action, prev_action, nullptr, flags_eff, status_out, nullptr, nullptr, nullptr, smem_tp, big, 0, 1,
+        nullptr, v.linv + (size_t)item * MC * MC, blk_out, v.yv + (size_t)item * MC, blk_out + MC * MC, nullptr, NoMidWork(), &cc,
+        n_cols);
+    if (threadIdx.x >= kWave) return;
+    const ItemHdr h = uniform_hdr(*hs);
+    if (h.m == 0) return;
+    const PrepLds<MC> pl(smem_tp);
+    float* Ls = reinterpret_cast<float*>(pl.L);  // (the L scratch is free: 90 doubles >= 81 + 9 floats)
+    float* ys = Ls + MC * MC;
+    solve_wave_fast<MC>(v, h, item, flags_eff, smem_tp, big, (h.rank + 3) & ~3, 1, Ls, ys, blk_out + LQ, status_out);
+    wave_lds_sync();
+    const int lane = threadIdx.x;
+    for (int i = lane; i < MC * MC; i += kWave) blk_out[i] = Ls[i];
+    if (lane < MC) blk_out[MC * MC + lane] = ys[lane];
+}
+
+template <int MC, int VEC>
+__global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
+    View v, TreeView tv, const float* __restrict__ q_all, const int* __restrict__ root_ids, const int* __restrict__ path_ids,
+    const int* __restrict__ new_ids, int n_items, unsigned flags, int lut_rows, float* __restrict__ reward_out) {
+    constexpr int LQ = (MC * MC + MC + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tg[];
+    const GainLds<MC> lds(smem_tg, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles);
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
+    const int tid = threadIdx.x, T = blockDim.x;
+    __builtin_amdgcn_s_dcache_inv();  // (Q through the non-coherent scalar cache: nothing of an earlier launch may be served)
+    const ItemHdr h = uniform_hdr(v.hdr[item]);
+    const int r = h.rank;
+    if (h.m == 0 || h.status == IPP_STATUS_NOT_PD) {
+        if (tid == 0) reward_out[item] = (h.status == IPP_STATUS_NOT_PD) ? NAN : 0.f;
+        return;
+    }
+    ChainCols cc;
+    DiagChain dc;
+    int root, parent_id;
+    tree_chain<MC>(v, tv, item, root_ids, path_ids, cc, dc, root, parent_id);
+    const int new_id = new_ids ? uni(new_ids[item]) : -1;
+    const bool expand = new_id >= 0 && new_id < tv.node_cap && !(flags & IPP_PREDICT_ONLY);
+    const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
+    float* new_cols0 = expand ? tv.node_cov + (size_t)new_id * MC * tv.win_cells : nullptr;
+    float* new_diag0 = expand ? tv.node_diag + (size_t)new_id * tv.win_cells : nullptr;
+    int* new_meta = expand ? tv.node_meta + 4 * new_id : nullptr;
+
+    const float* __restrict__ blk = q_all + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]
+    for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
+    if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
+    for (int k = tid; k < r; k += T) { lds.span_s[k] = cc.span(k); lds.rowp[k] = cc.row(k); }
+    fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
+    {
+        const float s3 = (float)(kSqrt3 * v.res) / h.ls;
+        for (int i = tid; i < lut_rows * v.W; i += T) {
+            const int dr = i / v.W, dc2 = i - dr * v.W;
+            lds.lut[i] = matern_f(dr, dc2, s3, h.sv);
+        }
+    }
+    if (expand && tid == 0) { new_meta[2] = parent_id; new_meta[3] = root; }
+    __syncthreads();
+    float* new_cols = expand ? new_cols0 - (size_t)h.t_lo * v.tile_cells : nullptr;
+    float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
+    // (mask and the new node's diagonal per tile, from the parent state's diagonal read under the tile's stream: no
+    // phase-A pass over the span)
+    gain_tiles<MC, VEC, IPP_GF_PIPE, false, false, true>(v, h, item, flags_eff, lut_rows, lds, blk + LQ, reward_out, &cc, new_cols,
+                                                       new_diag, new_meta, nullptr, &dc);
 }
 
 // diag of a node's state, assembled along its parent chain: out[c] = diagonal of the deepest node (from `node` upwards)
