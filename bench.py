@@ -431,15 +431,17 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
             "frac": gbs / HBM_PEAK_GBS}
 
 
-def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=4, root_steps=3):
+def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=4, root_steps=3, driver="device"):
     """BASELINE configs[4] through the tree-search DRIVER (ipp_rl_amd/planning/mcts_zero/vector_mcts.py: PUCT selection,
     valid-action mask, forced playouts, Dirichlet noise, transposition-aware backup; reference
     planning/mcts_zero/mcts.py:83-296) with a stubbed network (uniform priors, constant value): 1024 roots x 256
-    simulations on 200x200.  Selection and bookkeeping run on the host, vectorised over the roots in NumPy; every
-    covariance step runs on the device in per-level ipp_tree_step launches shared by all roots.  Host-bound, reported as
-    such (the device part of the same search is the tree wave above)."""
+    simulations on 200x200.  driver="device": selection, valid sets, expansion and backup in csrc/k_mcts.h (DeviceMCTS, one
+    wavefront per root); driver="host": the same search with selection and bookkeeping in NumPy, vectorised over the roots
+    (VectorMCTS; host-bound, kept for comparison).  Either way every covariance step runs on the device in per-level
+    ipp_tree_step launches shared by all roots."""
     from ipp_rl_amd import EngineConfig, IPPEngine
-    from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS as BatchedMCTS
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+    from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS
     from ipp_rl_amd.vec_env import cell_centre_actions
 
     cfg = EngineConfig(x_dim=grid, y_dim=grid)
@@ -461,7 +463,12 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
     meta = {"budget": 100.0, "initial_budget": 100.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
             "altitude_spacing": 6.0, "uav_specifications": {"max_v": 2.0, "max_a": 2.0},
             "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
-    mcts = BatchedMCTS(eng, hyper, meta, lambda reqs: [(None, 0.3)] * len(reqs), sims_in_flight=in_flight)
+    if driver == "device":
+        mcts = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=in_flight, tie_break="random", leaf_value=0.3)
+        mcts.get_policy(list(range(roots)), prev, [100.0] * roots)  # (first call allocates the search tables)
+        mcts.stats.update(device_steps=0, launches=0, inferences=0)
+    else:
+        mcts = VectorMCTS(eng, hyper, meta, lambda reqs: [(None, 0.3)] * len(reqs), sims_in_flight=in_flight)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
@@ -472,9 +479,10 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
     eng.close()
     del eng, mcts
     torch.cuda.empty_cache()
+    where = "PUCT / valid sets / expansion / backup on the device (k_mcts.h)" if driver == "device" else \
+        "PUCT / backup on the host, vectorised over the roots (host-bound)"
     return {"name": f"BASELINE configs[4] through the tree-search driver: {roots} roots x {sims} simulations ({in_flight} in flight per "
-                    f"root), {grid}x{grid}, horizon {horizon}, stubbed network; PUCT / backup on the host, vectorised over the roots "
-                    f"(host-bound)",
+                    f"root), {grid}x{grid}, horizon {horizon}, stubbed network; {where}",
             "value": roots * sims / dt, "unit": "simulations/s", "seconds_per_search": dt, "device_tree_steps": st["device_steps"],
             "launches": st["launches"], "nodes": st["nodes"], "inferences": st["inferences"], "all_policies_valid": ok}
 
@@ -585,10 +593,11 @@ def main(argv=None):
             extra.append(run_tree_wave(torch, device))
         except Exception as exc:
             extra.append({"name": "BASELINE configs[4] tree wave", "error": repr(exc)})
-        try:
-            extra.append(run_mcts_driver(torch, device))
-        except Exception as exc:
-            extra.append({"name": "tree-search driver", "error": repr(exc)})
+        for drv in ("device", "host"):
+            try:
+                extra.append(run_mcts_driver(torch, device, driver=drv))
+            except Exception as exc:
+                extra.append({"name": f"tree-search driver ({drv})", "error": repr(exc)})
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 6
+#define IPP_ABI_VERSION 7
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -227,6 +227,74 @@ int ipp_tree_score_actions(void* engine, int32_t root_id, const int32_t* path_id
                            const double* prev_action, uint32_t flags, float* reward, int32_t* status, void* stream);
 /* diag of a node's state, float[N] */
 int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream);
+
+/*
+ * Device-side tree search (csrc/k_mcts.h).  Replaces the per-simulation Python of planning/mcts_zero/mcts.py:
+ * simulate (:166-265), compute_uct with forced playouts (:280-296), get_next_actions_mask (:148-158),
+ * add_exploration_noise (:160-164) and the value backup (:255-265) for MANY roots at once; get_policy (:83-143) reads
+ * the root rows back.  The caller owns every buffer ([dev] pointers below; the host side in
+ * planning/mcts_zero/device_mcts.py allocates them as torch tensors) and keeps them alive for the search.
+ * One wave owns one root: root j uses the node ids [j nodes_per_root, (j+1) nodes_per_root) (the first is the root node),
+ * the device-node ids [j dev_per_root, (j+1) dev_per_root) of the engine's node pool and its own hash table.
+ * Before a search: n_flags = 0 except the root nodes (2 = stored), n_value = 0, n_devpath = -1, n_hash[root node] = any
+ * distinct non-zero key, root_count = 1, dev_count = 0, h_keys = 0, err = 0; before every wave: pend_count = rq_count = 0.
+ */
+typedef struct ipp_mcts_tables {
+    int32_t roots;            /* R */
+    int32_t kmax;             /* width of the padded valid-action rows */
+    int32_t nodes_per_root;
+    int32_t dev_per_root;
+    int32_t table_size;       /* hash slots per root, a power of two >= 2 nodes_per_root */
+    int32_t max_depth;        /* path steps recorded per descent: >= episode_horizon + 1 - depth */
+    int32_t wave;             /* most simulations in flight per root (buffer dimension W) */
+    int32_t horizon;          /* episode_horizon (mcts.py:36) */
+    int32_t grid_w, grid_h;   /* cells along the first / second waypoint coordinate */
+    int32_t n_levels, n_off;  /* altitude levels; candidate cell offsets around a position */
+    int32_t num_actions;      /* A = n_levels grid_w grid_h */
+    int32_t use_flight_time;  /* cost = trapezoidal flight time (actions.py:32-41) instead of the distance */
+    int32_t tie_break;        /* 0 = lowest action index among equal PUCT scores, 1 = counter-based uniform draw */
+    int32_t device;
+    double res, max_dist;     /* cell size; max_valid_action_distance */
+    double gamma, puct_init, puct_base, fpf;  /* mcts.py:25-33 */
+    double vmax, amax;
+    /* geometry [dev] */
+    const double* actions;       /* [A][3] waypoints in the reference's enumeration (actions.py:73-82) */
+    const int32_t* cell_action;  /* [grid_w][grid_h] level-0 action index of a cell */
+    const int32_t* off_x;        /* [n_off] cell offsets, ordered so that the action index ascends within a level */
+    const int32_t* off_y;
+    const uint64_t* zkey;        /* [A] per-action hash keys (node key = root key + sum over the measurements taken) */
+    const double* uniform_ps;    /* [kmax + 1] prior of each of K equally likely valid actions (summed like NumPy sums) */
+    /* edge tables [R nodes_per_root][kmax] */
+    int32_t* t_idx; double* t_ps; double* t_nsa; double* t_qsa; double* t_num; int32_t* t_child;
+    /* node tables [R nodes_per_root] */
+    int32_t* n_k; double* n_ns; uint8_t* n_flags; uint64_t* n_hash; double* n_value;
+    int32_t* n_devpath;          /* [..][6] device nodes from the root env slot to this node's state, -1 padded */
+    int32_t* root_count; int32_t* dev_count;  /* [R] ids used */
+    uint64_t* h_keys; int32_t* h_vals;        /* [R][table_size] */
+    /* per wave: recorded descents [W][R][max_depth] / [W][R], pending leaves [R][W] */
+    int32_t* p_node; int32_t* p_k; double* p_cost; int32_t* p_len; int32_t* leaf;
+    int32_t* pend_node; int32_t* pend_depth; int32_t* pend_sim; double* pend_prev; double* pend_budget; int32_t* pend_count;
+    /* covariance steps requested per tree level [max_depth][R W]: these are the argument arrays of ipp_tree_step */
+    int32_t* rq_root; int32_t* rq_parent; int32_t* rq_k; int32_t* rq_child; int32_t* rq_newdev;
+    double* rq_cost; double* rq_prev; double* rq_action; int32_t* rq_count;  /* rq_count [max_depth] */
+    int32_t* ts_paths; float* ts_reward; int32_t* ts_status;
+    int32_t* err;                /* [4] node range / device-node range exhausted, tree-step status, kmax too small */
+} ipp_mcts_tables;
+
+/* W descents per root (virtual visits between them), from waypoint prev0[j] with budget0[j] at tree depth `depth`;
+ * sim0 = index of the first of these simulations in the search.  Fills p_*, leaf, pend_*, rq_*. */
+int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env /*[dev] R env slots*/, const double* prev0 /*[dev] R x 3*/,
+                    const double* budget0 /*[dev] R*/, int32_t depth, int32_t sim0, int32_t wave, uint64_t seed, void* stream);
+/* The n covariance steps requested at `level` (= tree depth - depth of the select call): parents' device paths,
+ * ipp_tree_step, edge numerators and the new nodes' device paths.  flags as for ipp_tree_step. */
+int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, int32_t n, uint32_t flags, void* stream);
+/* Pending leaves: valid-action sets (sets_only = 1: only those, so that the caller can ask its network with them) and
+ * priors / value: prior [dev] [R W][kmax] on the valid sets or NULL = uniform; value [dev] [R W] or NULL = value_const;
+ * Dirichlet(alpha) noise of weight eps on the root of simulation 0. */
+int ipp_mcts_expand(const ipp_mcts_tables* t, const double* prior, const double* value, double value_const, int32_t sets_only,
+                    double alpha, double eps, uint64_t seed, void* stream);
+/* Values back along the `wave` recorded descents of every root. */
+int ipp_mcts_backup(const ipp_mcts_tables* t, int32_t wave, void* stream);
 
 /*
  * NN input state plane of one env slot: the N x N covariance with the rows / columns outside the adaptive mask

@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class IppConfig(C.Structure):
@@ -55,6 +55,31 @@ class IppStepItem(C.Structure):
 
 
 _P = C.c_void_p
+
+
+class IppMctsTables(C.Structure):
+    """ipp_mcts_tables (include/ipp_engine.h): dimensions, search constants and the [dev] buffers of a device-side tree search."""
+    _fields_ = [
+        ("roots", C.c_int32), ("kmax", C.c_int32), ("nodes_per_root", C.c_int32), ("dev_per_root", C.c_int32),
+        ("table_size", C.c_int32), ("max_depth", C.c_int32), ("wave", C.c_int32), ("horizon", C.c_int32),
+        ("grid_w", C.c_int32), ("grid_h", C.c_int32), ("n_levels", C.c_int32), ("n_off", C.c_int32),
+        ("num_actions", C.c_int32), ("use_flight_time", C.c_int32), ("tie_break", C.c_int32), ("device", C.c_int32),
+        ("res", C.c_double), ("max_dist", C.c_double), ("gamma", C.c_double), ("puct_init", C.c_double),
+        ("puct_base", C.c_double), ("fpf", C.c_double), ("vmax", C.c_double), ("amax", C.c_double),
+        ("actions", _P), ("cell_action", _P), ("off_x", _P), ("off_y", _P),
+        ("zkey", _P), ("uniform_ps", _P), ("t_idx", _P), ("t_ps", _P),
+        ("t_nsa", _P), ("t_qsa", _P), ("t_num", _P), ("t_child", _P),
+        ("n_k", _P), ("n_ns", _P), ("n_flags", _P), ("n_hash", _P),
+        ("n_value", _P), ("n_devpath", _P), ("root_count", _P), ("dev_count", _P),
+        ("h_keys", _P), ("h_vals", _P), ("p_node", _P), ("p_k", _P),
+        ("p_cost", _P), ("p_len", _P), ("leaf", _P), ("pend_node", _P),
+        ("pend_depth", _P), ("pend_sim", _P), ("pend_prev", _P), ("pend_budget", _P),
+        ("pend_count", _P), ("rq_root", _P), ("rq_parent", _P), ("rq_k", _P),
+        ("rq_child", _P), ("rq_newdev", _P), ("rq_cost", _P), ("rq_prev", _P),
+        ("rq_action", _P), ("rq_count", _P), ("ts_paths", _P), ("ts_reward", _P),
+        ("ts_status", _P), ("err", _P),
+    ]
+
 # name -> (restype, argtypes); exactly the symbols include/ipp_engine.h declares
 PROTOTYPES = {
     "ipp_abi_version": (C.c_int, []),
@@ -70,6 +95,10 @@ PROTOTYPES = {
     "ipp_state_plane": (C.c_int, [_P, C.c_int32, _P, C.c_uint32, _P, _P]),
     "ipp_tree_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_tree_read_diag": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "ipp_mcts_select": (C.c_int, [C.POINTER(IppMctsTables), _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _P]),
+    "ipp_mcts_level_steps": (C.c_int, [_P, C.POINTER(IppMctsTables), C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "ipp_mcts_expand": (C.c_int, [C.POINTER(IppMctsTables), _P, _P, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint64, _P]),
+    "ipp_mcts_backup": (C.c_int, [C.POINTER(IppMctsTables), C.c_int32, _P]),
     "ipp_tree_score_actions": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),

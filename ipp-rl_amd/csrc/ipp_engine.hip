@@ -24,6 +24,7 @@
 #include "k_score.h"
 #include "k_plane.h"
 #include "k_tree.h"
+#include "k_mcts.h"
 #include "k_prepare.h"
 
 using namespace ipp;
@@ -917,6 +918,81 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     else
         timed_launch(e, 0, k_tree_step<25, 2>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                      action, prev_action, flags, e->lut_rows, status, reward);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- device-side tree search (k_mcts.h)
+static int mcts_check(const ipp_mcts_tables* t) {
+    if (!t) return fail(-1, "null tables");
+    if (t->roots <= 0 || t->kmax <= 0 || t->nodes_per_root <= 1 || t->dev_per_root <= 0 || t->wave <= 0 || t->max_depth <= 0)
+        return fail(-1, "ipp_mcts_tables: roots, kmax, nodes_per_root, dev_per_root, wave and max_depth must be positive");
+    if (t->table_size < 2 * t->nodes_per_root || (t->table_size & (t->table_size - 1)))
+        return fail(-1, "ipp_mcts_tables.table_size = %d must be a power of two >= 2 nodes_per_root", t->table_size);
+    if (t->max_depth > 8 || t->horizon + 1 > kMctsPath) return fail(-1, "ipp_mcts_tables: horizon %d exceeds the path length %d", t->horizon, kMctsPath - 1);
+    if (!t->actions || !t->cell_action || !t->off_x || !t->off_y || !t->zkey || !t->uniform_ps || !t->t_idx || !t->t_ps || !t->t_nsa ||
+        !t->t_qsa || !t->t_num || !t->t_child || !t->n_k || !t->n_ns || !t->n_flags || !t->n_hash || !t->n_value || !t->n_devpath ||
+        !t->root_count || !t->dev_count || !t->h_keys || !t->h_vals || !t->p_node || !t->p_k || !t->p_cost || !t->p_len || !t->leaf ||
+        !t->pend_node || !t->pend_depth || !t->pend_sim || !t->pend_prev || !t->pend_budget || !t->pend_count || !t->rq_root ||
+        !t->rq_parent || !t->rq_k || !t->rq_child || !t->rq_newdev || !t->rq_cost || !t->rq_prev || !t->rq_action || !t->rq_count ||
+        !t->ts_paths || !t->ts_reward || !t->ts_status || !t->err)
+        return fail(-1, "ipp_mcts_tables: null buffer");
+    return 0;
+}
+
+int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env, const double* prev0, const double* budget0, int32_t depth,
+                    int32_t sim0, int32_t wave, uint64_t seed, void* stream) {
+    if (int rc = mcts_check(t)) return rc;
+    if (!root_env || !prev0 || !budget0) return fail(-1, "null argument");
+    if (wave <= 0 || wave > t->wave) return fail(-1, "wave = %d outside [1, %d]", wave, t->wave);
+    if (depth < 0 || t->horizon + 1 - depth > t->max_depth) return fail(-1, "depth %d: the descents need %d steps, max_depth = %d", depth, t->horizon + 1 - depth, t->max_depth);
+    HIP_TRY(hipSetDevice(t->device));
+    const int blocks = (t->roots * kWave + 255) / 256;
+    hipLaunchKernelGGL(k_mcts_select, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *t, root_env, prev0, budget0,
+                       (int)depth, (int)sim0, (int)wave, seed);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, int32_t n, uint32_t flags, void* stream) {
+    if (int rc = mcts_check(t)) return rc;
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (level < 0 || level >= t->max_depth) return fail(-1, "level %d outside [0, %d)", level, t->max_depth);
+    const int rw = t->roots * t->wave;
+    if (n < 0 || n > rw) return fail(-1, "n = %d outside [0, roots x wave = %d]", n, rw);
+    if (n == 0) return 0;
+    if ((int64_t)t->roots * t->dev_per_root > e->tv.node_cap)
+        return fail(-1, "roots x dev_per_root = %lld device nodes exceed ipp_config.node_capacity = %d", (long long)t->roots * t->dev_per_root, e->tv.node_cap);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t o = (size_t)level * rw;
+    hipLaunchKernelGGL(k_mcts_level_paths, dim3((n + 255) / 256), dim3(256), 0, s, *t, (int)level, (int)n);
+    if (int rc = ipp_tree_step(engine, t->rq_root + o, t->ts_paths + kMctsPath * o, t->rq_newdev + o, n, t->rq_action + 3 * o, t->rq_prev + 3 * o,
+                               flags, t->ts_reward + o, t->ts_status + o, stream))
+        return rc;
+    hipLaunchKernelGGL(k_mcts_apply, dim3((n + 255) / 256), dim3(256), 0, s, *t, (int)level, (int)n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_mcts_expand(const ipp_mcts_tables* t, const double* prior, const double* value, double value_const, int32_t sets_only,
+                    double alpha, double eps, uint64_t seed, void* stream) {
+    if (int rc = mcts_check(t)) return rc;
+    if (!(alpha > 0.0) || eps < 0.0 || eps > 1.0) return fail(-1, "Dirichlet alpha must be > 0 and eps in [0, 1]");
+    HIP_TRY(hipSetDevice(t->device));
+    const int waves = t->roots * t->wave;
+    hipLaunchKernelGGL(k_mcts_expand, dim3((waves * kWave + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *t, prior, value,
+                       value_const, (int)sets_only, alpha, eps, seed);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ipp_mcts_backup(const ipp_mcts_tables* t, int32_t wave, void* stream) {
+    if (int rc = mcts_check(t)) return rc;
+    if (wave <= 0 || wave > t->wave) return fail(-1, "wave = %d outside [1, %d]", wave, t->wave);
+    HIP_TRY(hipSetDevice(t->device));
+    hipLaunchKernelGGL(k_mcts_backup, dim3((t->roots + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *t, (int)wave);
     HIP_TRY(hipGetLastError());
     return 0;
 }

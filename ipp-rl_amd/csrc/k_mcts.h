@@ -1,0 +1,412 @@
+// Device-side tree search for the MCTS-zero planner (planning/mcts_zero/mcts.py of the reference):
+// PUCT selection with forced playouts (:280-296), valid-action sets (:148-158), transposition-aware child lookup (the
+// reference keys nodes by hash(str(P)): states reached by the same measurements in any order are one node), expansion
+// with uniform or network priors and Dirichlet noise at the root (:160-164, 204-233), value backup (:255-265).
+//
+// The host drivers (planning/mcts_zero/mcts.py, vector_mcts.py) spend 95 % of a configs[4] search in NumPy: 5 s per
+// 1024 roots x 256 simulations around 0.1 s of device work.  Here the search tables live in HBM and one WAVE owns one
+// root: everything of a root (its node range, its hash table, its device-node range, the simulations in flight) is
+// touched by that wave only and in program order, so there are no atomics except the per-level request counters, and
+// the search is deterministic.  Per wave of W simulations in flight per root:
+//   k_mcts_select   all roots: W descents each (virtual visits keep them apart), recording paths, pending leaves and,
+//                   per tree level, the covariance steps of edges traversed for the first time (request lists that ARE
+//                   the argument arrays of ipp_tree_step)
+//   per level:      k_mcts_level_paths, ipp_tree_step (k_tree.h), k_mcts_apply (edge numerators, device paths of the
+//                   new nodes)
+//   k_mcts_expand   valid-action sets and priors of the pending leaves (network replies optional)
+//   k_mcts_backup   values back along the recorded paths
+// Arithmetic is fp64 with contraction off and in the operand order of the NumPy driver (vector_mcts.py), which builds the
+// same trees when ties are broken by the lowest action index (tests/test_hip_mcts.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ipp_engine.h"
+
+namespace ipp {
+
+constexpr int kMctsPath = 6;  // == kTreeDepth: device nodes on a path
+constexpr unsigned char kNodeExpanded = 1, kNodeStored = 2;
+
+__device__ __forceinline__ double mc_bcast(double x, int src) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double mc_first(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double mc_shfl_xor(double x, int m) { return __shfl_xor(x, m, 64); }
+
+// splitmix64: tie-break draws and the Dirichlet noise (counter-based: a draw depends on (seed, root, simulation, ...) only)
+__device__ __forceinline__ uint64_t mc_mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ double mc_u01(uint64_t h) { return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+// actions.py:8-41 (Euclidean distance or the trapezoidal flight time), operand order of BatchedMCTS.row_cost
+__device__ __forceinline__ double mc_distance(const double* a, const double* p) {
+#pragma clang fp contract(off)
+    const double d0 = a[0] - p[0], d1 = a[1] - p[1], d2 = a[2] - p[2];
+    return sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+}
+__device__ __forceinline__ double mc_cost(const ipp_mcts_tables& m, const double* a, const double* p) {
+#pragma clang fp contract(off)
+    const double dist = mc_distance(a, p);
+    if (!m.use_flight_time) return dist;
+    const double ramp = fmin(0.5 * dist, (m.vmax * m.vmax) / (2 * m.amax));
+    return (dist - 2 * ramp) / m.vmax + 2 * sqrt(2 * ramp / m.amax);
+}
+
+// ---------------------------------------------------------------------------------------------------- selection
+// One wave per root, W descents one after the other.
+__global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const int32_t* __restrict__ root_env,
+                                                     const double* __restrict__ prev0, const double* __restrict__ budget0,
+                                                     int depth0, int sim0, int W, uint64_t seed) {
+#pragma clang fp contract(off)
+    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (j >= m.roots) return;
+    const int base = j * m.nodes_per_root;
+    const int RW = m.roots * m.wave;
+    const bool virt = W > 1;
+    uint64_t* hk = m.h_keys + (size_t)j * m.table_size;
+    int32_t* hv = m.h_vals + (size_t)j * m.table_size;
+    for (int w = 0; w < W; ++w) {
+        int cur = base, plen = 0, leafnode = -1;
+        double prev[3] = {prev0[3 * j], prev0[3 * j + 1], prev0[3 * j + 2]};
+        double budget = budget0[j];
+        for (int d = depth0; d <= m.horizon; ++d) {
+            if (!(budget > 0)) break;  // mcts.py:175-176
+            const unsigned char fl = m.n_flags[cur];
+            if (!(fl & kNodeExpanded)) {
+                // ---- leaf: evaluated (once per wave of simulations) by k_mcts_expand
+                leafnode = cur;
+                if (lane == 0) {
+                    const int cnt = m.pend_count[j];
+                    bool seen = false;
+                    for (int s = 0; s < cnt; ++s) seen |= m.pend_node[j * m.wave + s] == cur;
+                    if (!seen) {
+                        const int s = j * m.wave + cnt;
+                        m.pend_node[s] = cur;
+                        m.pend_depth[s] = d;
+                        m.pend_sim[s] = sim0 + w;
+                        m.pend_prev[3 * s] = prev[0]; m.pend_prev[3 * s + 1] = prev[1]; m.pend_prev[3 * s + 2] = prev[2];
+                        m.pend_budget[s] = budget;
+                        m.pend_count[j] = cnt + 1;
+                    }
+                }
+                break;
+            }
+            // ---- PUCT over the node's K valid actions (mcts.py:280-296)
+            const int K = m.n_k[cur];
+            const size_t row = (size_t)cur * m.kmax;
+            const double ns = m.n_ns[cur];
+            double lo = INFINITY, hi = -INFINITY;
+            int nz = 0;
+            for (int k = lane; k < K; k += 64) {
+                const double q = m.t_qsa[row + k];
+                lo = fmin(lo, q);
+                hi = fmax(hi, q);
+                nz |= (q != 0.0) ? 1 : 0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = fmin(lo, mc_shfl_xor(lo, o));
+                hi = fmax(hi, mc_shfl_xor(hi, o));
+                nz |= __shfl_xor(nz, o, 64);
+            }
+            if (K < m.num_actions) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); }  // the zeros of the invalid actions take part (mcts.py:267-278)
+            const bool allzero = nz == 0;
+            const double pc = m.puct_init + log((ns + m.puct_base + 1) / m.puct_base);
+            const double sq = sqrt(ns + 1);
+            const bool force = d == 0;
+            double best = -INFINITY, best_u = -1.0;
+            int best_k = 0x7fffffff;
+            for (int k = lane; k < K; k += 64) {
+                const double q = m.t_qsa[row + k], nsa = m.t_nsa[row + k], ps = m.t_ps[row + k];
+                const double qn = allzero ? q : ((lo == hi) ? q / hi : (q - lo) / (hi - lo));
+                double uct = qn + pc * (ps * (sq / (1 + nsa)));
+                if (force) {
+                    double nfp = ceil(sqrt(m.fpf * ps * ns));
+                    if (nsa == 0) nfp = 0;
+                    if (nsa < nfp) uct = INFINITY;
+                }
+                const double u = m.tie_break ? mc_u01(mc_mix(seed ^ mc_mix(((uint64_t)(uint32_t)cur << 32) | (uint32_t)(k + 1)) ^ ((uint64_t)(sim0 + w) << 20))) : 0.0;
+                if (uct > best || (uct == best && (m.tie_break ? u > best_u : k < best_k))) { best = uct; best_k = k; best_u = u; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = mc_shfl_xor(best, o), ou = mc_shfl_xor(best_u, o);
+                const int ok = __shfl_xor(best_k, o, 64);
+                if (ob > best || (ob == best && (m.tie_break ? (ou > best_u || (ou == best_u && ok < best_k)) : ok < best_k))) { best = ob; best_k = ok; best_u = ou; }
+            }
+            const int k = best_k;  // (K >= 1 for an expanded node)
+            const int a_idx = m.t_idx[row + k];
+            const double action[3] = {m.actions[3 * (size_t)a_idx], m.actions[3 * (size_t)a_idx + 1], m.actions[3 * (size_t)a_idx + 2]};
+            const double cost = mc_cost(m, action, prev);
+            // ---- bookkeeping by lane 0 (program order within the wave; the fences publish it to the other lanes' loads)
+            int child = m.t_child[row + k];
+            if (lane == 0) {
+                if (child < 0) {
+                    uint64_t key = m.n_hash[cur] + m.zkey[a_idx];  // commutative: the order of the measurements is irrelevant
+                    if (key == 0) key = 1;
+                    unsigned slot = (unsigned)(mc_mix(key) & (uint64_t)(m.table_size - 1));
+                    for (;;) {
+                        const uint64_t kk = hk[slot];
+                        if (kk == key) { child = hv[slot]; break; }
+                        if (kk == 0) {
+                            const int cnt = m.root_count[j];
+                            if (cnt >= m.nodes_per_root) { m.err[0] = 1; child = base; break; }  // node range exhausted
+                            child = base + cnt;
+                            m.root_count[j] = cnt + 1;
+                            hk[slot] = key;
+                            hv[slot] = child;
+                            m.n_hash[child] = key;
+                            break;
+                        }
+                        slot = (slot + 1) & (unsigned)(m.table_size - 1);
+                    }
+                    m.t_child[row + k] = child;
+                }
+                if (isnan(m.t_num[row + k])) {  // first traversal of the edge: one device step
+                    m.t_num[row + k] = INFINITY;
+                    int newdev = -1;
+                    if (d + 1 <= m.horizon && !(m.n_flags[child] & kNodeStored)) {
+                        const int dc = m.dev_count[j];
+                        if (dc >= m.dev_per_root) m.err[1] = 1;  // device-node range exhausted: the state is not kept
+                        else {
+                            newdev = j * m.dev_per_root + dc;
+                            m.dev_count[j] = dc + 1;
+                            m.n_flags[child] |= kNodeStored;
+                        }
+                    }
+                    const int lvl = d - depth0;
+                    const int slot = atomicAdd(&m.rq_count[lvl], 1);
+                    const size_t r = (size_t)lvl * RW + slot;
+                    m.rq_root[r] = root_env[j];
+                    m.rq_parent[r] = cur;
+                    m.rq_k[r] = k;
+                    m.rq_child[r] = child;
+                    m.rq_newdev[r] = newdev;
+                    m.rq_cost[r] = cost;
+                    m.rq_prev[3 * r] = prev[0]; m.rq_prev[3 * r + 1] = prev[1]; m.rq_prev[3 * r + 2] = prev[2];
+                    m.rq_action[3 * r] = action[0]; m.rq_action[3 * r + 1] = action[1]; m.rq_action[3 * r + 2] = action[2];
+                }
+                const size_t ps = ((size_t)w * m.roots + j) * m.max_depth + plen;
+                m.p_node[ps] = cur;
+                m.p_k[ps] = k;
+                m.p_cost[ps] = cost;
+                if (virt) {
+                    m.t_nsa[row + k] += 1;
+                    m.n_ns[cur] += 1;
+                }
+            }
+            child = __builtin_amdgcn_readfirstlane(child);
+            __threadfence();
+            plen += 1;
+            budget -= cost;
+            prev[0] = action[0]; prev[1] = action[1]; prev[2] = action[2];
+            cur = child;
+        }
+        if (lane == 0) {
+            m.p_len[w * m.roots + j] = plen;
+            m.leaf[w * m.roots + j] = leafnode;
+        }
+        __threadfence();
+    }
+}
+
+// Inputs of the level's ipp_tree_step that depend on the previous level's results: the parents' device paths.
+__global__ void k_mcts_level_paths(ipp_mcts_tables m, int level, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = (size_t)level * m.roots * m.wave + i;
+    const int parent = m.rq_parent[r];
+#pragma unroll
+    for (int s = 0; s < kMctsPath; ++s) m.ts_paths[kMctsPath * r + s] = m.n_devpath[(size_t)kMctsPath * parent + s];
+}
+
+// Results of the level's ipp_tree_step: the edge's masked trace reduction (reward (cost + 1), rewards.py:31 undone: the
+// cost depends on the path that led to the node, the reduction does not) and the device path of a stored child.
+__global__ void k_mcts_apply(ipp_mcts_tables m, int level, int n) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = (size_t)level * m.roots * m.wave + i;
+    if (m.ts_status[r] != 0) m.err[2] = m.ts_status[r];
+    const int parent = m.rq_parent[r], k = m.rq_k[r];
+    m.t_num[(size_t)parent * m.kmax + k] = (double)m.ts_reward[r] * (m.rq_cost[r] + 1.0);
+    const int newdev = m.rq_newdev[r];
+    if (newdev >= 0) {
+        const int c = m.rq_child[r];
+        int depth = 0;
+#pragma unroll
+        for (int s = 0; s < kMctsPath; ++s) {
+            const int p = m.n_devpath[(size_t)kMctsPath * parent + s];
+            m.n_devpath[(size_t)kMctsPath * c + s] = p;
+            depth += p >= 0 ? 1 : 0;
+        }
+        if (depth < kMctsPath) m.n_devpath[(size_t)kMctsPath * c + depth] = newdev;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- expansion
+// Marsaglia-Tsang gamma(shape, 1) from a counter-based stream (shape < 1 through the u^(1/shape) boost)
+__device__ inline double mc_gamma(double shape, uint64_t key) {
+    double boost = 1.0;
+    uint64_t c = 0;
+    if (shape < 1.0) {
+        boost = pow(mc_u01(mc_mix(key ^ 0xA5A5A5A5ull)), 1.0 / shape);
+        shape += 1.0;
+    }
+    const double dd = shape - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+    for (int it = 0; it < 64; ++it) {
+        const double u1 = mc_u01(mc_mix(key + (++c))), u2 = mc_u01(mc_mix(key + (++c))), u3 = mc_u01(mc_mix(key + (++c)));
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);  // Box-Muller
+        const double t = 1.0 + cc * x;
+        if (t <= 0.0) continue;
+        const double v = t * t * t;
+        if (log(u3) < 0.5 * x * x + dd - dd * v + dd * log(v)) return boost * dd * v;
+    }
+    return boost * dd;
+}
+
+// One wave per pending leaf (slot s of root j): the valid-action set in ascending action index (mcts.py:148-158: every
+// action farther than 0, within the remaining budget and closer than max_valid_action_distance; only the cells within
+// that distance are looked at), priors (uniform, or the network's on the valid set), Dirichlet noise for the root of
+// the first simulation, node flags and value.
+// prior: [roots * wave][kmax] network priors on the leaf's valid set (slot order) or NULL (uniform, mcts.py:204);
+// value: [roots * wave] or NULL (value_const).
+__global__ __launch_bounds__(256) void k_mcts_expand(ipp_mcts_tables m, const double* __restrict__ prior,
+                                                     const double* __restrict__ value, double value_const, int sets_only,
+                                                     double alpha, double eps, uint64_t seed) {
+#pragma clang fp contract(off)
+    const int g = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (g >= m.roots * m.wave) return;
+    const int j = g / m.wave, s = g - j * m.wave;
+    if (s >= m.pend_count[j]) return;
+    const int nd = m.pend_node[g];
+    const size_t row = (size_t)nd * m.kmax;
+    const double pos[3] = {m.pend_prev[3 * g], m.pend_prev[3 * g + 1], m.pend_prev[3 * g + 2]};
+    const double budget = m.pend_budget[g];
+    int K = 0;
+    if (sets_only || !(m.n_flags[nd] & 4)) {
+        const int px = (int)floor(pos[0] / m.res), py = (int)floor(pos[1] / m.res);
+        const int ncell = m.grid_w * m.grid_h;
+        const int n_cand = m.n_levels * m.n_off;
+        for (int c0 = 0; c0 < n_cand; c0 += 64) {
+            const int c = c0 + lane;
+            bool ok = false;
+            int idx = -1;
+            if (c < n_cand) {
+                const int lv = c / m.n_off, o = c - lv * m.n_off;
+                const int cx = px + m.off_x[o], cy = py + m.off_y[o];
+                if (cx >= 0 && cx < m.grid_w && cy >= 0 && cy < m.grid_h) {
+                    idx = lv * ncell + m.cell_action[cx * m.grid_h + cy];
+                    const double dist = mc_distance(m.actions + 3 * (size_t)idx, pos);
+                    ok = dist > 0 && dist <= budget && dist < m.max_dist;
+                }
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (ok) {
+                const int at = K + __popcll(bal & ((1ull << lane) - 1ull));
+                if (at < m.kmax) m.t_idx[row + at] = idx;
+            }
+            K += __popcll(bal);
+        }
+        if (K > m.kmax) { if (lane == 0) m.err[3] = 1; K = m.kmax; }
+        for (int k = K + lane; k < m.kmax; k += 64) m.t_idx[row + k] = -1;
+        if (lane == 0) m.n_k[nd] = K;
+    } else {
+        K = m.n_k[nd];
+    }
+    if (sets_only) {  // (the host asks the network with the sets, then calls again)
+        if (lane == 0) m.n_flags[nd] |= 4;
+        return;
+    }
+    if (K == 0) {  // mcts.py:201-202: stays a leaf, value 0 (its set is computed again when it is reached again)
+        if (lane == 0) m.n_flags[nd] &= (unsigned char)~4;
+        return;
+    }
+    // ---- priors on the valid set
+    const bool noise = m.pend_depth[g] == 0 && m.pend_sim[g] == 0;
+    double total = 0.0;
+    if (prior) {
+        for (int k = lane; k < K; k += 64) total += prior[(size_t)g * m.kmax + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += mc_shfl_xor(total, o);
+    }
+    const double uni = m.uniform_ps[K];  // (1/A) / sum of K copies of 1/A, summed like NumPy does (host table)
+    double gsum = 0.0, rest = 0.0;
+    const uint64_t nkey = mc_mix(seed ^ ((uint64_t)(uint32_t)j << 24));
+    if (noise) {
+        // Dirichlet(alpha) over all A actions, looked at on the K valid ones: independent Gamma(alpha) draws for those, one
+        // Gamma((A - K) alpha) draw for the total of the rest (aggregation property); the reference normalises the noisy
+        // vector over ALL actions, the mass that lands on invalid actions stays there (mcts.py:160-164, 222-225)
+        for (int k = lane; k < K; k += 64) gsum += mc_gamma(alpha, nkey + ((uint64_t)(k + 1) << 32));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gsum += mc_shfl_xor(gsum, o);
+        rest = (m.num_actions > K) ? mc_first(mc_gamma(alpha * (m.num_actions - K), nkey)) : 0.0;
+    }
+    for (int k = lane; k < m.kmax; k += 64) {
+        double ps = 0.0;
+        if (k < K) {
+            if (!noise) {
+                ps = prior ? ((total > 0) ? prior[(size_t)g * m.kmax + k] / total : 1.0 / K) : uni;
+            } else {
+                const double p0 = prior ? prior[(size_t)g * m.kmax + k] : 1.0 / m.num_actions;
+                const double psum = prior ? total : (double)K / m.num_actions;
+                const double gk = mc_gamma(alpha, nkey + ((uint64_t)(k + 1) << 32));
+                ps = ((1 - eps) * p0 + eps * gk / (gsum + rest)) / ((1 - eps) * psum + eps);
+            }
+        }
+        m.t_ps[row + k] = ps;
+        m.t_nsa[row + k] = 0.0;
+        m.t_qsa[row + k] = 0.0;
+        m.t_num[row + k] = NAN;
+        m.t_child[row + k] = -1;
+    }
+    if (lane == 0) {
+        m.n_ns[nd] = 0.0;
+        m.n_value[nd] = value ? value[g] : value_const;
+        m.n_flags[nd] = (m.n_flags[nd] & ~4) | kNodeExpanded;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- backup
+// One thread per root: the W recorded descents, deepest step first (mcts.py:255-265; virtual visits taken back first).
+__global__ void k_mcts_backup(ipp_mcts_tables m, int W) {
+#pragma clang fp contract(off)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m.roots) return;
+    const bool virt = W > 1;
+    for (int w = 0; w < W; ++w) {
+        const int lf = m.leaf[w * m.roots + j];
+        double value = lf >= 0 ? m.n_value[lf] : 0.0;
+        const int plen = m.p_len[w * m.roots + j];
+        for (int stp = plen - 1; stp >= 0; --stp) {
+            const size_t ps = ((size_t)w * m.roots + j) * m.max_depth + stp;
+            const int node = m.p_node[ps], k = m.p_k[ps];
+            const double cost = m.p_cost[ps];
+            const size_t e = (size_t)node * m.kmax + k;
+            double nsa = m.t_nsa[e];
+            if (virt) {
+                nsa -= 1;
+                m.n_ns[node] -= 1;
+            }
+            const double reward = m.t_num[e] / (cost + 1.0);  // rewards.py:31
+            const double val = reward + m.gamma * value;
+            m.t_qsa[e] = (nsa > 0) ? (nsa * m.t_qsa[e] + val) / (nsa + 1) : val;
+            m.t_nsa[e] = nsa + 1;
+            m.n_ns[node] += 1;
+            value = val;
+        }
+    }
+}
+
+}  // namespace ipp

@@ -1,0 +1,235 @@
+"""
+DeviceMCTS: the tree search of mcts.py / vector_mcts.py with selection, expansion and backup ON THE GPU (csrc/k_mcts.h).
+
+VectorMCTS spends 95 % of a BASELINE configs[4] search (1024 roots x 256 simulations, 200x200) in NumPy: 5 s around 0.1 s
+of device work.  Here the node tables live in HBM (torch tensors handed to the C-ABI as ipp_mcts_tables), one wavefront
+owns one root, and the host only sequences the launches of a wave of simulations:
+
+    ipp_mcts_select            W descents per root (PUCT, forced playouts, virtual visits, transposition lookup)
+    (one small read-back: the number of covariance steps requested per tree level and whether any leaf is pending)
+    ipp_mcts_level_steps       per tree level: ipp_tree_step for all roots + edge numerators + new nodes' device paths
+    ipp_mcts_expand            valid-action sets, priors (uniform or the network's), Dirichlet noise at the root
+    ipp_mcts_backup            values back along the recorded descents
+
+Same search as VectorMCTS(sims_in_flight=W) -- same formulas in the same floating-point order, same node identity (the
+commutative 64-bit key of the action multiset), same order of simulations and backups: with tie_break="first" both build
+the same trees (tests/test_hip_mcts.py).  Differences: the Dirichlet noise and tie_break="random" draw from counter-based
+streams on the device (statistically equivalent, not NumPy's streams), and the network is asked with TENSORS:
+
+    infer(batch) -> (prior or None, value)
+        batch: dict of device tensors for the n pending leaves of this wave -- "root" (env slot), "node", "depth",
+        "previous_action" [n, 3], "budget" [n], "valid_idx" [n, kmax] (ascending action indices, -1 padded), "K" [n]
+        prior: [n, kmax] float64 probabilities on the valid sets (need not be normalised) or None = uniform
+        value: [n] float64 tensor or a float
+    infer=None: uniform priors, value `leaf_value` (the stub of the benchmarks).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional, Sequence
+
+import numpy as np
+
+from ... import _ffi
+from .vector_mcts import VectorMCTS
+
+
+class DeviceMCTS(VectorMCTS):
+    def __init__(self, engine, hyper_params: Dict, meta_data: Dict, infer: Optional[Callable] = None, sims_in_flight: int = 4,
+                 tie_break: str = "first", seed: int = 0, leaf_value: float = 0.0, nodes_per_root: Optional[int] = None,
+                 dev_per_root: Optional[int] = None):
+        super().__init__(engine, hyper_params, meta_data, infer, None, sims_in_flight, tie_break, seed)
+        self.leaf_value = float(leaf_value)
+        self.seed = int(seed)
+        S, W = self.num_simulations, self.sims_in_flight
+        # a descent passes through at most horizon + 1 edges and only its first traversal of an edge creates a node; more
+        # than one new node per simulation needs transpositions into expanded nodes, hence the slack (overflow is an error)
+        self.nodes_per_root = int(nodes_per_root or (2 * S + 2 * W + 8))
+        self.dev_per_root = int(dev_per_root or max(1, min(self.nodes_per_root, engine._c.node_capacity // max(1, engine.capacity))))
+        self._tab = None
+        self._tab_roots = 0
+
+    # ------------------------------------------------------------------ buffers
+    def _geometry(self, torch, dev):
+        if getattr(self, "_geo", None) is not None:
+            return self._geo
+        W_, H_ = self._W, self._H
+        ca = self._cell_action
+        # the action index is affine in the cell: order the offsets so that it ascends (valid sets come out sorted)
+        a = int(ca[1, 0] - ca[0, 0]) if W_ > 1 else 0
+        b = int(ca[0, 1] - ca[0, 0]) if H_ > 1 else 0
+        gx, gy = np.meshgrid(np.arange(W_), np.arange(H_), indexing="ij")
+        if not np.array_equal(ca, ca[0, 0] + a * gx + b * gy):
+            raise ValueError("action enumeration is not affine in the cell index")
+        order = np.argsort(a * self._off_x + b * self._off_y, kind="stable")
+        kmax = int(min(self.Kmax, self.num_actions))
+        x = 1.0 / self.num_actions
+        uniform = np.array([0.0] + [x / float(np.sum(np.full(k, x))) for k in range(1, kmax + 1)])
+        t = lambda arr, dt: torch.as_tensor(np.ascontiguousarray(arr), dtype=dt, device=dev)  # noqa: E731
+        self._geo = dict(
+            kmax=kmax,
+            actions=t(self.actions_np, torch.float64), cell_action=t(ca, torch.int32),
+            off_x=t(self._off_x[order], torch.int32), off_y=t(self._off_y[order], torch.int32),
+            zkey=t(self._z.view(np.int64), torch.int64), uniform=t(uniform, torch.float64))
+        return self._geo
+
+    def _alloc(self, R: int, D: int):
+        import torch
+
+        eng = self.engine
+        dev = eng.device
+        geo = self._geometry(torch, dev)
+        K, npr, W = geo["kmax"], self.nodes_per_root, self.sims_in_flight
+        if R * self.dev_per_root > eng._c.node_capacity:
+            raise ValueError(f"{R} roots x {self.dev_per_root} device nodes exceed the engine's node_capacity {eng._c.node_capacity}")
+        cap = R * npr
+        tsz = 1
+        while tsz < 2 * npr:
+            tsz *= 2
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
+        b = dict(
+            t_idx=e((cap, K), torch.int32), t_ps=e((cap, K), torch.float64), t_nsa=e((cap, K), torch.float64),
+            t_qsa=e((cap, K), torch.float64), t_num=e((cap, K), torch.float64), t_child=e((cap, K), torch.int32),
+            n_k=e((cap,), torch.int32), n_ns=e((cap,), torch.float64), n_flags=e((cap,), torch.uint8), n_hash=e((cap,), torch.int64),
+            n_value=e((cap,), torch.float64), n_devpath=e((cap, 6), torch.int32), root_count=e((R,), torch.int32),
+            dev_count=e((R,), torch.int32), h_keys=e((R, tsz), torch.int64), h_vals=e((R, tsz), torch.int32),
+            p_node=e((W, R, D), torch.int32), p_k=e((W, R, D), torch.int32), p_cost=e((W, R, D), torch.float64),
+            p_len=e((W, R), torch.int32), leaf=e((W, R), torch.int32),
+            pend_node=e((R, W), torch.int32), pend_depth=e((R, W), torch.int32), pend_sim=e((R, W), torch.int32),
+            pend_prev=e((R, W, 3), torch.float64), pend_budget=e((R, W), torch.float64),
+            # pend_count [R] and rq_count [D] share one buffer: cleared and read back together
+            counts=e((R + D,), torch.int32),
+            rq_root=e((D, R * W), torch.int32), rq_parent=e((D, R * W), torch.int32), rq_k=e((D, R * W), torch.int32),
+            rq_child=e((D, R * W), torch.int32), rq_newdev=e((D, R * W), torch.int32), rq_cost=e((D, R * W), torch.float64),
+            rq_prev=e((D, R * W, 3), torch.float64), rq_action=e((D, R * W, 3), torch.float64),
+            ts_paths=e((D, R * W, 6), torch.int32), ts_reward=e((D, R * W), torch.float32), ts_status=e((D, R * W), torch.int32),
+            err=e((4,), torch.int32),
+        )
+        uav = self.uav
+        tab = _ffi.IppMctsTables(
+            roots=R, kmax=K, nodes_per_root=npr, dev_per_root=self.dev_per_root, table_size=tsz, max_depth=D, wave=W,
+            horizon=self.horizon, grid_w=self._W, grid_h=self._H, n_levels=self._n_lv, n_off=len(self._off_x),
+            num_actions=self.num_actions, use_flight_time=1 if uav is not None else 0, tie_break=0 if self.tie_break == "first" else 1,
+            device=dev.index or 0, res=self._res, max_dist=self.max_dist, gamma=self.gamma, puct_init=self.puct_init,
+            puct_base=self.puct_base, fpf=self.fpf, vmax=float(uav["max_v"]) if uav else 1.0, amax=float(uav["max_a"]) if uav else 1.0)
+        for name in ("actions", "cell_action", "off_x", "off_y", "zkey"):
+            setattr(tab, name, geo[name].data_ptr())
+        tab.uniform_ps = geo["uniform"].data_ptr()
+        for name, buf in b.items():
+            if name != "counts":
+                setattr(tab, name, buf.data_ptr())
+        tab.pend_count = b["counts"].data_ptr()
+        tab.rq_count = b["counts"].data_ptr() + 4 * R
+        self._tab, self._buf, self._tab_roots, self._tab_depth = tab, b, R, D
+        return tab, b
+
+    # ------------------------------------------------------------------ search
+    def get_policy(self, roots: Sequence[int], previous_actions, budgets, depth: int = 0, temperature: float = 1.0,
+                   deploy_time: bool = False, rngs=None):
+        """Like VectorMCTS.get_policy: one search of num_mcts_simulations per root, policies from the roots' visit counts."""
+        import torch
+
+        eng, lib = self.engine, self.engine._lib
+        dev = eng.device
+        R = len(roots)
+        D = max(1, self.horizon + 1 - depth)
+        W = self.sims_in_flight
+        if self._tab is None or self._tab_roots != R or self._tab_depth != D:
+            self._alloc(R, D)
+        tab, b = self._tab, self._buf
+        prev0 = torch.as_tensor(np.asarray(previous_actions, dtype=np.float64).reshape(R, 3), device=dev)
+        budget0 = torch.as_tensor(np.asarray(budgets, dtype=np.float64).reshape(R), device=dev)
+        root_env = torch.as_tensor(np.asarray(roots, dtype=np.int32), device=dev)
+        npr = self.nodes_per_root
+        root_nodes = torch.arange(R, device=dev, dtype=torch.int64) * npr
+        # ---- start of a search (include/ipp_engine.h: contract of ipp_mcts_tables)
+        b["n_flags"].zero_()
+        b["n_flags"][root_nodes] = 2
+        b["n_value"].zero_()
+        b["n_devpath"].fill_(-1)
+        b["n_hash"][root_nodes] = (torch.arange(R, device=dev, dtype=torch.int64) + 1) * (-7046029254386353131)  # 0x9E3779B97F4A7C15
+        b["root_count"].fill_(1)
+        b["dev_count"].zero_()
+        b["h_keys"].zero_()
+        b["err"].zero_()
+        flags = (_ffi.IPP_ADAPTIVE if self.adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if self.uav is not None else 0)
+        stream = eng.stream
+        tp = C.byref(tab)
+        sim = 0
+        while sim < self.num_simulations:
+            w = min(W, self.num_simulations - sim)
+            b["counts"].zero_()
+            _ffi.check(lib.ipp_mcts_select(tp, root_env.data_ptr(), prev0.data_ptr(), budget0.data_ptr(), int(depth), int(sim), int(w),
+                                           C.c_uint64(self.seed & (2 ** 64 - 1)), stream))
+            counts = b["counts"].cpu().numpy()  # the one synchronisation of the wave
+            level_n, n_pending = counts[R:], int(counts[:R].sum())
+            for level in range(D):
+                n = int(level_n[level])
+                if n:
+                    _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, n, flags, stream))
+                    self.stats["device_steps"] += n
+                    self.stats["launches"] += 1
+            if n_pending:
+                self._expand(lib, tp, b, R, W, root_env, stream)
+                self.stats["inferences"] += n_pending
+            _ffi.check(lib.ipp_mcts_backup(tp, int(w), stream))
+            sim += w
+        err = b["err"].cpu().numpy()
+        if err[0] or err[1] or err[3]:
+            raise RuntimeError(f"device tree search ran out of room (nodes, device nodes, kmax) = {err[0], err[1], err[3]}: "
+                               f"raise nodes_per_root / the engine's node_capacity")
+        if err[2]:
+            raise RuntimeError(f"ipp_tree_step reported status {int(err[2])} (rank_cap / footprint)")
+        return self._policies(b, R, npr, prev0.cpu().numpy(), budget0.cpu().numpy(), temperature, deploy_time, rngs, roots)
+
+    def _expand(self, lib, tp, b, R, W, root_env, stream):
+        import torch
+
+        seed = C.c_uint64((self.seed * 0x9E3779B97F4A7C15 + 12345) & (2 ** 64 - 1))
+        if self.infer is None:
+            _ffi.check(lib.ipp_mcts_expand(tp, None, None, self.leaf_value, 0, self.alpha, self.eps, seed, stream))
+            return
+        # network: valid sets first, then the replies scattered into [R W] slot order
+        _ffi.check(lib.ipp_mcts_expand(tp, None, None, 0.0, 1, self.alpha, self.eps, seed, stream))
+        cnt = b["counts"][:R].to(torch.int64)
+        slot = torch.arange(W, device=cnt.device)[None, :] < cnt[:, None]  # [R, W] pending slots
+        g = torch.nonzero(slot.reshape(-1)).reshape(-1)
+        nodes = b["pend_node"].reshape(-1)[g].to(torch.int64)
+        batch = dict(root=root_env[(g // W)], node=nodes, depth=b["pend_depth"].reshape(-1)[g],
+                     previous_action=b["pend_prev"].reshape(-1, 3)[g], budget=b["pend_budget"].reshape(-1)[g],
+                     valid_idx=b["t_idx"][nodes], K=b["n_k"][nodes])
+        prior, value = self.infer(batch)
+        K = b["t_idx"].shape[1]
+        pr_all = None
+        if prior is not None:
+            pr_all = torch.zeros((R * W, K), dtype=torch.float64, device=cnt.device)
+            pr_all[g] = torch.as_tensor(prior, dtype=torch.float64, device=cnt.device).reshape(len(g), K)
+        if torch.is_tensor(value) or isinstance(value, np.ndarray):
+            v_all = torch.zeros((R * W,), dtype=torch.float64, device=cnt.device)
+            v_all[g] = torch.as_tensor(value, dtype=torch.float64, device=cnt.device).reshape(len(g))
+            v_ptr, v_const = v_all.data_ptr(), 0.0
+        else:
+            v_all, v_ptr, v_const = None, None, float(value)
+        _ffi.check(lib.ipp_mcts_expand(tp, pr_all.data_ptr() if pr_all is not None else None, v_ptr, v_const, 0, self.alpha, self.eps,
+                                       seed, stream))
+        self._keep_infer = (pr_all, v_all)
+
+    def _policies(self, b, R, npr, prev0, budget0, temperature, deploy_time, rngs, roots):
+        """get_policy (mcts.py:83-143) from the root rows, through VectorMCTS._policy_sparse on a table of the R roots."""
+        import torch
+
+        idx = torch.arange(R, device=b["n_k"].device, dtype=torch.int64) * npr
+        host = lambda t: t[idx].cpu().numpy()  # noqa: E731
+        self.t_idx = host(b["t_idx"]).astype(np.int64)
+        self.t_Ps, self.t_Nsa, self.t_Qsa = host(b["t_ps"]), host(b["t_nsa"]), host(b["t_qsa"])
+        self.n_K = host(b["n_k"]).astype(np.int64)
+        self.n_Ns = host(b["n_ns"])
+        self.n_expanded = (host(b["n_flags"]) & 1).astype(bool)
+        self.root_ids = np.arange(R)
+        self.stats["nodes"] = int((b["n_flags"] & 1).sum().item())
+        rngs = list(rngs) if rngs is not None else [np.random.RandomState(int(r)) for r in roots]
+        return [self._policy_sparse(j, prev0[j], float(budget0[j]), temperature, deploy_time, rngs[j]) for j in range(R)]
+
+    def root_statistics(self):
+        """(valid action indices, visit counts, Q) of every root after get_policy: arrays [R, kmax], padding idx -1."""
+        return self.t_idx, self.t_Nsa, self.t_Qsa

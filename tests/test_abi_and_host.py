@@ -49,6 +49,19 @@ def test_struct_layouts_match_header_order():
     fields = re.findall(r"(?:int32_t|double)\s+([a-z_0-9]+);", body)
     assert fields == [f[0] for f in _ffi.IppConfig._fields_]
     assert ctypes.sizeof(_ffi.IppConfig) == 8 + 13 * 8 + 10 * 4
+    # ipp_mcts_tables: same field order; int32 / double scalars, everything else a device pointer
+    body = re.search(r"typedef struct ipp_mcts_tables \{(.*?)\} ipp_mcts_tables;", txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for stmt in body.split(";"):
+        m = re.match(r"\s*(?:const\s+)?(int32_t|double|uint64_t|uint8_t|float)\s*(\*?)\s*(.*)", stmt, flags=re.S)
+        if not m or not m.group(3).strip():
+            continue
+        for name in m.group(3).split(","):
+            is_ptr = bool(m.group(2)) or name.strip().startswith("*")
+            fields.append((name.strip().lstrip("*").strip(), ctypes.c_void_p if is_ptr else {"int32_t": ctypes.c_int32, "double": ctypes.c_double}[m.group(1)]))
+    assert fields == list(_ffi.IppMctsTables._fields_)
+    assert ctypes.sizeof(_ffi.IppMctsTables) == 16 * 4 + 8 * 8 + 46 * 8
 
 
 def test_arena_sizing_and_validation_without_gpu():

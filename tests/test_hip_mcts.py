@@ -231,3 +231,105 @@ def test_vector_driver_on_the_device_equals_the_per_root_driver():
         assert np.max(np.abs(nd.Qsa - b.t_Qsa[rt, :K])) < 1e-6  # (device rewards are recomputed: fp32, bit-identical in practice)
         assert np.allclose(out_a[j][0], out_b[j][0], atol=1e-9)
     assert a.stats["nodes"] == b.stats["nodes"] and a.stats["device_steps"] == b.stats["device_steps"]
+
+
+def _search_setup(dim, R, sims, horizon, eps, node_slack=8):
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    eng = IPPEngine(cfg, capacity=R, state="factor", rank_cap=9 * (3 + horizon + 2), window_rows=-1, fixed_prior=True,
+                    node_capacity=R * (sims + node_slack), max_batch=4 * R)
+    rs = np.random.RandomState(2)
+    eng.reset(white_noise=rs.normal(size=(R, dim, dim)))
+    prev = np.tile([2.0, 2.0, 14.0], (R, 1))
+    for t in range(3):
+        acts = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
+        eng.step(acts, prev, meas_noise=rs.normal(size=(R, 9)))
+        prev = acts
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+                 dirichlet_alpha=1.0, dirichlet_eps=eps, num_mcts_simulations=sims)
+    meta = {"budget": 60.0, "initial_budget": 60.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
+            "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
+    return eng, prev, hyper, meta
+
+
+def test_device_search_builds_the_same_trees_as_the_host_driver():
+    """DeviceMCTS (selection, valid sets, expansion, backup in csrc/k_mcts.h; one wavefront per root) against VectorMCTS on
+    the same device states: identical root statistics with lowest-index tie-breaking -- 16 roots x 48 simulations, 4 in
+    flight per root, values from a 'network' that is asked with tensors (the value depends on the leaf's valid set).
+    Dirichlet weight 0: the device draws its noise from its own counter-based stream (statistics checked below)."""
+    import torch
+
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+    from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS
+
+    dim, R, sims, horizon = 20, 16, 48, 4
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.0)
+    roots = list(range(R))
+
+    def infer_host(reqs):
+        return [(None, 0.05 * float(len(r["valid_idx"]) % 7) + 0.3) for r in reqs]
+
+    asked = []
+
+    def infer_dev(batch):
+        K = batch["K"].to(torch.float64)
+        asked.append(int(K.numel()))
+        vi = batch["valid_idx"]
+        assert vi.shape[1] >= int(K.max()) and bool(((vi >= 0).sum(dim=1) == batch["K"]).all())
+        assert bool((vi[:, 1:][vi[:, 1:] >= 0] > vi[:, :-1][vi[:, 1:] >= 0]).all())  # ascending action indices
+        return None, 0.05 * torch.remainder(K, 7.0) + 0.3
+
+    a = VectorMCTS(eng, hyper, meta, infer_host, sims_in_flight=4, tie_break="first")
+    out_a = a.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
+    b = DeviceMCTS(eng, hyper, meta, infer_dev, sims_in_flight=4, tie_break="first")
+    out_b = b.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
+    idx_b, nsa_b, q_b = b.root_statistics()
+    for j in roots:
+        rt = int(a.root_ids[j])
+        K = int(a.n_K[rt])
+        assert K == int(b.n_K[j]) and np.array_equal(a.t_idx[rt, :K], idx_b[j, :K])
+        assert np.array_equal(a.t_Nsa[rt, :K], nsa_b[j, :K]), (j, a.t_Nsa[rt, :K], nsa_b[j, :K])
+        assert np.max(np.abs(a.t_Qsa[rt, :K] - q_b[j, :K])) < 1e-6
+        assert np.allclose(out_a[j][0], out_b[j][0], atol=1e-9)
+    assert a.stats["nodes"] == b.stats["nodes"] and a.stats["device_steps"] == b.stats["device_steps"]
+    assert a.stats["inferences"] == b.stats["inferences"] == sum(asked)
+    # a second search on the same object starts from clean tables and gives the same result
+    out_c = b.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
+    assert all(np.array_equal(out_b[j][0], out_c[j][0]) for j in roots)
+
+
+def test_device_search_noise_random_ties_and_stub_network():
+    """The stubbed device search (uniform priors, constant value) with Dirichlet noise and random tie-breaking: every root
+    gets a normalised policy on valid actions, all virtual visits are undone, the noisy root priors are a probability
+    vector whose spread matches Dirichlet(alpha), and two runs with one seed agree bit for bit."""
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+
+    dim, R, sims, horizon = 20, 64, 64, 4
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.25)
+    roots = list(range(R))
+    m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="random", seed=11, leaf_value=0.3)
+    out = m.get_policy(roots, prev, [60.0] * R)
+    idx, nsa, q = (x.copy() for x in m.root_statistics())
+    ps = m.t_Ps.copy()
+    for j in roots:
+        K = int(m.n_K[j])
+        assert out[j] is not None and K > 0
+        pol = np.asarray(out[j][0])
+        assert abs(pol.sum() - 1.0) < 1e-9 and np.all(pol >= 0)
+        assert np.all(pol[np.setdiff1d(np.arange(m.num_actions), idx[j, :K])] == 0)  # mass on valid actions only
+        # every simulation backed up once, virtual visits undone (the 4 simulations of the first wave all end at the unexpanded root)
+        assert m.n_Ns[j] == nsa[j, :K].sum() == sims - 4 and np.all(nsa[j, :K] >= 0)
+        assert np.all(np.isfinite(q[j, :K]))
+        # noisy priors: (1 - eps) uniform + eps Dirichlet, normalised over ALL actions (mass on invalid ones is lost)
+        assert np.all(ps[j, :K] > 0) and ps[j, :K].sum() <= 1.0 + 1e-12
+    # Dirichlet(1) marginals over A actions: a valid action's share of the noise has mean 1/A and variance ~ 1/A^2; the
+    # K x R noise shares recovered from the priors must show that spread (a constant or degenerate draw would not)
+    A, eps = m.num_actions, 0.25
+    shares = np.concatenate([(ps[j, :int(m.n_K[j])] * ((1 - eps) * int(m.n_K[j]) / A + eps) - (1 - eps) / A) / eps for j in roots])
+    assert abs(shares.mean() * A - 1.0) < 0.1 and 0.7 < shares.std() * A < 1.3
+    m2 = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="random", seed=11, leaf_value=0.3)
+    out2 = m2.get_policy(roots, prev, [60.0] * R)
+    assert all(np.array_equal(out[j][0], out2[j][0]) for j in roots)
+    assert np.array_equal(nsa, m2.t_Nsa)
