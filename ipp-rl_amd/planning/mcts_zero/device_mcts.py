@@ -228,7 +228,66 @@ class DeviceMCTS(VectorMCTS):
         self.root_ids = np.arange(R)
         self.stats["nodes"] = int((b["n_flags"] & 1).sum().item())
         rngs = list(rngs) if rngs is not None else [np.random.RandomState(int(r)) for r in roots]
-        return [self._policy_sparse(j, prev0[j], float(budget0[j]), temperature, deploy_time, rngs[j]) for j in range(R)]
+        if self.num_actions <= self.DENSE_ACTIONS or temperature == 0:
+            return [self._policy_sparse(j, prev0[j], float(budget0[j]), temperature, deploy_time, rngs[j]) for j in range(R)]
+        return self._policies_rows(R, temperature, deploy_time, rngs)
+
+    def _policies_rows(self, R, temperature, deploy_time, rngs):
+        """VectorMCTS._policy_sparse for all roots at once (large action sets, temperature > 0): the same arithmetic on
+        [R, kmax] arrays -- forced-playout pruning (mcts.py:109-131) as a masked loop over the playouts to take back -- and the
+        same draws from the per-root generators; only the Python objects are built per root."""
+        valid = self.t_idx >= 0
+        K = self.n_K
+        visits = np.where(valid, self.t_Nsa, 0.0)
+        ok_root = self.n_expanded & (K > 0)
+        if not deploy_time:
+            vmax = visits.max(axis=1)
+            best = np.full(R, -1, dtype=np.int64)
+            for j in np.nonzero(ok_root)[0]:
+                if vmax[j] > 0 or self.num_actions == K[j]:
+                    best[j] = int(rngs[j].choice((visits[j, :K[j]] == vmax[j]).nonzero()[0]))
+            ps, ns = self.t_Ps, self.n_Ns[:, None]
+            with np.errstate(invalid="ignore"):
+                nfp = np.ceil(np.sqrt(self.fpf * ps * ns))
+            nfp[(visits == 0) | ~valid] = 0
+            uct = self._uct_rows(np.arange(R), force_playouts=False)
+            max_puct = np.where(best >= 0, uct[np.arange(R), np.maximum(best, 0)], -np.inf)[:, None]
+            # Q normalised like _normalize_q (the zeros of the invalid actions take part when the set is a strict subset)
+            q = np.where(valid, self.t_Qsa, 0.0)
+            has_outside = (K < self.num_actions)[:, None]
+            lo = np.where(valid, q, np.inf).min(axis=1, keepdims=True)
+            hi = np.where(valid, q, -np.inf).max(axis=1, keepdims=True)
+            lo = np.where(has_outside, np.minimum(lo, 0.0), lo)
+            hi = np.where(has_outside, np.maximum(hi, 0.0), hi)
+            allzero = np.all(q == 0, axis=1, keepdims=True)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                qn = np.where(allzero, q, np.where(lo == hi, q / hi, (q - lo) / (hi - lo)))
+            pc = self.puct_init + np.log((ns + self.puct_base + 1) / self.puct_base)
+            live = valid & (nfp > 0) & (np.arange(visits.shape[1])[None, :] != best[:, None])
+            left = np.where(live, nfp, 0.0)
+            while live.any():  # one forced playout taken back per pass; an action leaves when its PUCT reaches the best's
+                visits = np.where(live, visits - 1, visits)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    prior = pc * (ps * (np.sqrt(ns + 1) / (1 + visits)))
+                back = live & (qn + prior >= max_puct)
+                visits = np.where(back, visits + 1, visits)
+                left = left - 1
+                live = live & ~back & (left > 0)
+            visits[visits == 1] = 0
+        out = []
+        tot = visits.sum(axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            vt = visits ** (1.0 / temperature)
+            p = vt / vt.sum(axis=1, keepdims=True)
+        for j in range(R):
+            if not ok_root[j] or tot[j] == 0:
+                out.append(None)
+                continue
+            idx = self.t_idx[j, :K[j]]
+            pj = p[j, :K[j]]
+            nz = pj > 0
+            out.append((dict(zip(idx[nz].tolist(), pj[nz].tolist())), idx))
+        return out
 
     def root_statistics(self):
         """(valid action indices, visit counts, Q) of every root after get_policy: arrays [R, kmax], padding idx -1."""

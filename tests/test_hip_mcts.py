@@ -333,3 +333,28 @@ def test_device_search_noise_random_ties_and_stub_network():
     out2 = m2.get_policy(roots, prev, [60.0] * R)
     assert all(np.array_equal(out[j][0], out2[j][0]) for j in roots)
     assert np.array_equal(nsa, m2.t_Nsa)
+
+
+def test_device_search_policies_of_a_large_action_set():
+    """50x50 x 2 levels = 5000 actions (> the dense limit): policies come back as {action: probability} built from [R, kmax]
+    arrays (DeviceMCTS._policies_rows); they must equal the per-root get_policy restatement (VectorMCTS._policy_sparse,
+    mcts.py:98-143 incl. forced-playout pruning) on the same root rows with the same generators."""
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+
+    dim, R, sims, horizon = 50, 32, 96, 4
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.25)
+    roots = list(range(R))
+    m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="random", seed=5, leaf_value=0.3)
+    assert m.num_actions > m.DENSE_ACTIONS
+    out = m.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(40 + r) for r in roots])
+    pruned = 0
+    for j in roots:
+        ref = m._policy_sparse(j, prev[j], 60.0, 1.0, False, np.random.RandomState(40 + j))
+        assert (ref is None) == (out[j] is None)
+        pol, idx = out[j]
+        assert set(pol) == set(ref[0]) and np.array_equal(idx, ref[1])
+        assert max(abs(pol[a] - ref[0][a]) for a in pol) < 1e-15
+        assert abs(sum(pol.values()) - 1.0) < 1e-9
+        K = int(m.n_K[j])
+        pruned += int((m.t_Nsa[j, :K] > 0).sum()) - len(pol)
+    assert pruned > 0  # forced playouts were actually taken back somewhere
