@@ -313,3 +313,67 @@ def test_fullsize_search_through_the_driver_1024_roots_256_sims_200x200():
     assert np.all(np.isfinite(q)) and np.all(q >= 0)
     assert mcts.stats["launches"] <= (sims // W) * (horizon + 1)  # one launch per level and wave, shared by all roots
     assert torch.equal(eng.ranks(), ranks0) and torch.equal(eng.read_diag(roots - 1), diag0)
+
+
+def test_fullsize_device_search_1024_roots_256_sims_200x200():
+    """configs[4] through the DEVICE-side search (DeviceMCTS, csrc/k_mcts.h): 1024 roots x 256 simulations on 200x200, 4 in
+    flight per root, Dirichlet noise and random tie-breaking from the counter-based device streams.  Invariants over all
+    node tables read back from the device; two searches with one seed are bit-identical; root env slots untouched."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    fresh_gpu()
+    grid, roots, sims, W, horizon, root_steps = 200, 1024, 256, 4, 5, 3
+    cfg = EngineConfig(x_dim=grid, y_dim=grid)
+    eng = IPPEngine(cfg, capacity=roots, state="factor", rank_cap=9 * (root_steps + horizon + 2), window_rows=-1, fixed_prior=True,
+                    node_capacity=roots * (sims + W), max_batch=roots * W)
+    white = torch.empty((roots, cfg.n_cells), dtype=torch.float32, device="cuda")
+    eng.normal_rows(white, cfg.n_cells, 9, 1 << 40)
+    eng.reset(white_noise=white)
+    noise = torch.empty((root_steps, roots, 9), dtype=torch.float32, device="cuda")
+    eng.normal_rows(noise, 9, 9, 2 << 40)
+    prev = np.tile([2.0, 2.0, 14.0], (roots, 1))
+    for t in range(root_steps):
+        a = cell_centre_actions(cfg, t, 0, roots, roots, [8.0, 14.0])
+        _, s = eng.step(a, prev, meas_noise=noise[t])
+        assert int(s.abs().sum()) == 0
+        prev = a
+    ranks0 = eng.ranks().clone()
+    diag0 = eng.read_diag(roots - 1).clone()
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+                 dirichlet_alpha=1.0, dirichlet_eps=0.25, num_mcts_simulations=sims)
+    meta = {"budget": 100.0, "initial_budget": 100.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
+            "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
+    mcts = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break="random", seed=1, leaf_value=0.3)
+    out = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
+    b = mcts._buf
+    used = b["root_count"].cpu().numpy()
+    npr = mcts.nodes_per_root
+    assert used.max() < npr and int(b["dev_count"].max()) <= mcts.dev_per_root and int(b["err"].abs().sum()) == 0
+    print(f"[configs[4] device search] {mcts.stats['nodes']} nodes (most per root {used.max()} of {npr}), "
+          f"{mcts.stats['device_steps']} device steps in {mcts.stats['launches']} launches")
+    live = (torch.arange(npr, device="cuda")[None, :] < b["root_count"][:, None].to(torch.int64)).reshape(-1)  # node ids in use
+    exp = ((b["n_flags"] & 1) != 0) & live
+    K = b["n_k"].to(torch.int64)
+    col = torch.arange(b["t_idx"].shape[1], device="cuda")[None, :]
+    inside = (col < K[:, None]) & exp[:, None]
+    nsa, q, num, idx = b["t_nsa"], b["t_qsa"], b["t_num"], b["t_idx"]
+    assert bool(((idx >= 0) == (col < K[:, None]))[exp].all())                                   # valid sets are exactly K long
+    assert bool((idx[:, 1:] > idx[:, :-1])[inside[:, 1:]].all())                                 # ... and ascending
+    assert bool(torch.equal(torch.where(inside, nsa, torch.zeros_like(nsa)).sum(dim=1)[exp], b["n_ns"][exp]))  # virtual visits undone
+    assert bool((nsa[inside] >= 0).all()) and bool(torch.isfinite(q[inside]).all()) and bool((q[inside] >= 0).all())
+    trav = inside & ~torch.isnan(num)
+    assert bool(torch.isfinite(num[trav]).all()) and bool((num[trav] > 0).all())                 # every traversed edge has its trace reduction
+    assert bool(((nsa > 0) & inside & torch.isnan(num)).sum() == 0)                              # no visited edge without one
+    for j in range(roots):
+        Kj = int(mcts.n_K[j])
+        assert mcts.n_Ns[j] == sims - W == mcts.t_Nsa[j, :Kj].sum()
+        policy, valid = out[j]
+        assert abs(sum(policy.values()) - 1.0) < 1e-9 and set(policy) <= set(int(i) for i in valid)
+    assert mcts.stats["launches"] <= (sims // W) * (horizon + 1)
+    assert torch.equal(eng.ranks(), ranks0) and torch.equal(eng.read_diag(roots - 1), diag0)
+    nsa1 = mcts.t_Nsa.copy()
+    out2 = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
+    assert np.array_equal(nsa1, mcts.t_Nsa) and all(out[j][0] == out2[j][0] for j in range(roots))
