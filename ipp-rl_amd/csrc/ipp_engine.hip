@@ -948,8 +948,13 @@ int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env, const dou
     if (depth < 0 || t->horizon + 1 - depth > t->max_depth) return fail(-1, "depth %d: the descents need %d steps, max_depth = %d", depth, t->horizon + 1 - depth, t->max_depth);
     HIP_TRY(hipSetDevice(t->device));
     const int blocks = (t->roots * kWave + 255) / 256;
-    hipLaunchKernelGGL(k_mcts_select, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *t, root_env, prev0, budget0,
-                       (int)depth, (int)sim0, (int)wave, seed);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int ne = (t->kmax + 63) / 64;  // edge rows in registers up to 256 valid actions per node
+    if (ne == 1)      hipLaunchKernelGGL(k_mcts_select<1>, dim3(blocks), dim3(256), 0, s, *t, root_env, prev0, budget0, (int)depth, (int)sim0, (int)wave, seed);
+    else if (ne == 2) hipLaunchKernelGGL(k_mcts_select<2>, dim3(blocks), dim3(256), 0, s, *t, root_env, prev0, budget0, (int)depth, (int)sim0, (int)wave, seed);
+    else if (ne == 3) hipLaunchKernelGGL(k_mcts_select<3>, dim3(blocks), dim3(256), 0, s, *t, root_env, prev0, budget0, (int)depth, (int)sim0, (int)wave, seed);
+    else if (ne == 4) hipLaunchKernelGGL(k_mcts_select<4>, dim3(blocks), dim3(256), 0, s, *t, root_env, prev0, budget0, (int)depth, (int)sim0, (int)wave, seed);
+    else              hipLaunchKernelGGL(k_mcts_select<0>, dim3(blocks), dim3(256), 0, s, *t, root_env, prev0, budget0, (int)depth, (int)sim0, (int)wave, seed);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -64,11 +64,16 @@ __device__ __forceinline__ double mc_cost(const ipp_mcts_tables& m, const double
 }
 
 // ---------------------------------------------------------------------------------------------------- selection
-// One wave per root, W descents one after the other.
+// One wave per root, W descents one after the other.  A descent is a chain of dependent memory round trips (node
+// record -> edge rows -> the chosen edge -> child), so the kernel's time is the number of round trips per level:
+// NE > 0 keeps the node's edge rows in registers (kmax <= 64 NE entries, all loads of a level's rows in one round trip,
+// the chosen edge's fields in a second, the child's record in a third); NE = 0 is the general form for wider rows.
+template <int NE>
 __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const int32_t* __restrict__ root_env,
                                                      const double* __restrict__ prev0, const double* __restrict__ budget0,
                                                      int depth0, int sim0, int W, uint64_t seed) {
 #pragma clang fp contract(off)
+    constexpr int NR = NE > 0 ? NE : 1;
     const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (j >= m.roots) return;
     const int base = j * m.nodes_per_root;
@@ -80,9 +85,12 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
         int cur = base, plen = 0, leafnode = -1;
         double prev[3] = {prev0[3 * j], prev0[3 * j + 1], prev0[3 * j + 2]};
         double budget = budget0[j];
+        // record of the current node (the next level's is loaded at the end of a level, next to the chosen edge)
+        unsigned char fl = m.n_flags[cur];
+        int K = m.n_k[cur];
+        double ns = m.n_ns[cur];
         for (int d = depth0; d <= m.horizon; ++d) {
             if (!(budget > 0)) break;  // mcts.py:175-176
-            const unsigned char fl = m.n_flags[cur];
             if (!(fl & kNodeExpanded)) {
                 // ---- leaf: evaluated (once per wave of simulations) by k_mcts_expand
                 leafnode = cur;
@@ -103,16 +111,29 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                 break;
             }
             // ---- PUCT over the node's K valid actions (mcts.py:280-296)
-            const int K = m.n_k[cur];
             const size_t row = (size_t)cur * m.kmax;
-            const double ns = m.n_ns[cur];
+            double rq[NR], rn[NR], rp[NR];
+            int ri[NR];
+            if (NE > 0) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int k = min(lane + 64 * i, m.kmax - 1);
+                    rq[i] = m.t_qsa[row + k]; rn[i] = m.t_nsa[row + k]; rp[i] = m.t_ps[row + k]; ri[i] = m.t_idx[row + k];
+                }
+            }
             double lo = INFINITY, hi = -INFINITY;
             int nz = 0;
-            for (int k = lane; k < K; k += 64) {
-                const double q = m.t_qsa[row + k];
-                lo = fmin(lo, q);
-                hi = fmax(hi, q);
-                nz |= (q != 0.0) ? 1 : 0;
+            if (NE > 0) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if (lane + 64 * i < K) { lo = fmin(lo, rq[i]); hi = fmax(hi, rq[i]); nz |= (rq[i] != 0.0) ? 1 : 0; }
+            } else {
+                for (int k = lane; k < K; k += 64) {
+                    const double q = m.t_qsa[row + k];
+                    lo = fmin(lo, q);
+                    hi = fmax(hi, q);
+                    nz |= (q != 0.0) ? 1 : 0;
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -125,10 +146,9 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             const double pc = m.puct_init + log((ns + m.puct_base + 1) / m.puct_base);
             const double sq = sqrt(ns + 1);
             const bool force = d == 0;
-            double best = -INFINITY, best_u = -1.0;
-            int best_k = 0x7fffffff;
-            for (int k = lane; k < K; k += 64) {
-                const double q = m.t_qsa[row + k], nsa = m.t_nsa[row + k], ps = m.t_ps[row + k];
+            double best = -INFINITY, best_u = -1.0, best_nsa = 0.0;
+            int best_k = 0x7fffffff, best_a = -1;
+            auto consider = [&](int k, double q, double nsa, double ps, int ai) {
                 const double qn = allzero ? q : ((lo == hi) ? q / hi : (q - lo) / (hi - lo));
                 double uct = qn + pc * (ps * (sq / (1 + nsa)));
                 if (force) {
@@ -137,23 +157,33 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     if (nsa < nfp) uct = INFINITY;
                 }
                 const double u = m.tie_break ? mc_u01(mc_mix(seed ^ mc_mix(((uint64_t)(uint32_t)cur << 32) | (uint32_t)(k + 1)) ^ ((uint64_t)(sim0 + w) << 20))) : 0.0;
-                if (uct > best || (uct == best && (m.tie_break ? u > best_u : k < best_k))) { best = uct; best_k = k; best_u = u; }
+                if (uct > best || (uct == best && (m.tie_break ? u > best_u : k < best_k))) { best = uct; best_k = k; best_u = u; best_nsa = nsa; best_a = ai; }
+            };
+            if (NE > 0) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if (lane + 64 * i < K) consider(lane + 64 * i, rq[i], rn[i], rp[i], ri[i]);
+            } else {
+                for (int k = lane; k < K; k += 64) consider(k, m.t_qsa[row + k], m.t_nsa[row + k], m.t_ps[row + k], m.t_idx[row + k]);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                const double ob = mc_shfl_xor(best, o), ou = mc_shfl_xor(best_u, o);
-                const int ok = __shfl_xor(best_k, o, 64);
-                if (ob > best || (ob == best && (m.tie_break ? (ou > best_u || (ou == best_u && ok < best_k)) : ok < best_k))) { best = ob; best_k = ok; best_u = ou; }
+                const double ob = mc_shfl_xor(best, o), ou = mc_shfl_xor(best_u, o), on = mc_shfl_xor(best_nsa, o);
+                const int ok = __shfl_xor(best_k, o, 64), oa = __shfl_xor(best_a, o, 64);
+                if (ob > best || (ob == best && (m.tie_break ? (ou > best_u || (ou == best_u && ok < best_k)) : ok < best_k))) {
+                    best = ob; best_k = ok; best_u = ou; best_nsa = on; best_a = oa;
+                }
             }
-            const int k = best_k;  // (K >= 1 for an expanded node)
-            const int a_idx = m.t_idx[row + k];
+            const int k = best_k, a_idx = best_a;  // (K >= 1 for an expanded node)
+            // ---- the chosen edge: everything it needs in one round trip
             const double action[3] = {m.actions[3 * (size_t)a_idx], m.actions[3 * (size_t)a_idx + 1], m.actions[3 * (size_t)a_idx + 2]};
-            const double cost = mc_cost(m, action, prev);
-            // ---- bookkeeping by lane 0 (program order within the wave; the fences publish it to the other lanes' loads)
             int child = m.t_child[row + k];
-            if (lane == 0) {
-                if (child < 0) {
-                    uint64_t key = m.n_hash[cur] + m.zkey[a_idx];  // commutative: the order of the measurements is irrelevant
+            const double num = m.t_num[row + k];
+            const uint64_t zk = m.zkey[a_idx], hcur = m.n_hash[cur];
+            const double cost = mc_cost(m, action, prev);
+            if (child < 0) {  // (wave-uniform) transposition lookup: the same measurements in any order are one node
+                if (lane == 0) {
+                    uint64_t key = hcur + zk;
                     if (key == 0) key = 1;
                     unsigned slot = (unsigned)(mc_mix(key) & (uint64_t)(m.table_size - 1));
                     for (;;) {
@@ -173,16 +203,23 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     }
                     m.t_child[row + k] = child;
                 }
-                if (isnan(m.t_num[row + k])) {  // first traversal of the edge: one device step
+                child = __builtin_amdgcn_readfirstlane(child);
+            }
+            // ---- the child's record (the next level's node) next to this level's bookkeeping
+            const unsigned char cfl = m.n_flags[child];
+            const int cK = m.n_k[child];
+            const double cns = m.n_ns[child];
+            if (lane == 0) {
+                if (isnan(num)) {  // first traversal of the edge: one device step
                     m.t_num[row + k] = INFINITY;
                     int newdev = -1;
-                    if (d + 1 <= m.horizon && !(m.n_flags[child] & kNodeStored)) {
+                    if (d + 1 <= m.horizon && !(cfl & kNodeStored)) {
                         const int dc = m.dev_count[j];
                         if (dc >= m.dev_per_root) m.err[1] = 1;  // device-node range exhausted: the state is not kept
                         else {
                             newdev = j * m.dev_per_root + dc;
                             m.dev_count[j] = dc + 1;
-                            m.n_flags[child] |= kNodeStored;
+                            m.n_flags[child] = cfl | kNodeStored;
                         }
                     }
                     const int lvl = d - depth0;
@@ -202,22 +239,21 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                 m.p_k[ps] = k;
                 m.p_cost[ps] = cost;
                 if (virt) {
-                    m.t_nsa[row + k] += 1;
-                    m.n_ns[cur] += 1;
+                    m.t_nsa[row + k] = best_nsa + 1;
+                    m.n_ns[cur] = ns + 1;
                 }
             }
-            child = __builtin_amdgcn_readfirstlane(child);
-            __threadfence();
             plen += 1;
             budget -= cost;
             prev[0] = action[0]; prev[1] = action[1]; prev[2] = action[2];
             cur = child;
+            fl = cfl; K = cK; ns = cns;  // (the expanded bit, K and Ns of the child are not written by this level)
         }
         if (lane == 0) {
             m.p_len[w * m.roots + j] = plen;
             m.leaf[w * m.roots + j] = leafnode;
         }
-        __threadfence();
+        __threadfence();  // lane 0's stores (virtual visits, children, flags) before the next descent's loads
     }
 }
 

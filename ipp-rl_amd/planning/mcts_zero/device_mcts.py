@@ -227,7 +227,11 @@ class DeviceMCTS(VectorMCTS):
         self.n_expanded = (host(b["n_flags"]) & 1).astype(bool)
         self.root_ids = np.arange(R)
         self.stats["nodes"] = int((b["n_flags"] & 1).sum().item())
-        rngs = list(rngs) if rngs is not None else [np.random.RandomState(int(r)) for r in roots]
+        if rngs is None:  # one generator for the read-out draws of all roots (1024 seeded RandomStates cost 50 ms)
+            shared = np.random.RandomState(self.seed & 0x7fffffff)
+            rngs = [shared] * R
+        else:
+            rngs = list(rngs)
         if self.num_actions <= self.DENSE_ACTIONS or temperature == 0:
             return [self._policy_sparse(j, prev0[j], float(budget0[j]), temperature, deploy_time, rngs[j]) for j in range(R)]
         return self._policies_rows(R, temperature, deploy_time, rngs)

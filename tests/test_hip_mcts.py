@@ -233,7 +233,7 @@ def test_vector_driver_on_the_device_equals_the_per_root_driver():
     assert a.stats["nodes"] == b.stats["nodes"] and a.stats["device_steps"] == b.stats["device_steps"]
 
 
-def _search_setup(dim, R, sims, horizon, eps, node_slack=8):
+def _search_setup(dim, R, sims, horizon, eps, node_slack=8, max_dist=11.5):
     from ipp_rl_amd import EngineConfig, IPPEngine
     from ipp_rl_amd.vec_env import cell_centre_actions
 
@@ -247,14 +247,15 @@ def _search_setup(dim, R, sims, horizon, eps, node_slack=8):
         acts = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
         eng.step(acts, prev, meas_noise=rs.normal(size=(R, 9)))
         prev = acts
-    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
+    hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=max_dist,
                  dirichlet_alpha=1.0, dirichlet_eps=eps, num_mcts_simulations=sims)
     meta = {"budget": 60.0, "initial_budget": 60.0, "episode_horizon": horizon, "min_altitude": 8.0, "max_altitude": 14.0,
             "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
     return eng, prev, hyper, meta
 
 
-def test_device_search_builds_the_same_trees_as_the_host_driver():
+@pytest.mark.parametrize("max_dist", [11.5, 19.5])  # rows of 162 (edge rows in registers) / 338 valid actions (general kernel)
+def test_device_search_builds_the_same_trees_as_the_host_driver(max_dist):
     """DeviceMCTS (selection, valid sets, expansion, backup in csrc/k_mcts.h; one wavefront per root) against VectorMCTS on
     the same device states: identical root statistics with lowest-index tie-breaking -- 16 roots x 48 simulations, 4 in
     flight per root, values from a 'network' that is asked with tensors (the value depends on the leaf's valid set).
@@ -265,7 +266,7 @@ def test_device_search_builds_the_same_trees_as_the_host_driver():
     from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS
 
     dim, R, sims, horizon = 20, 16, 48, 4
-    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.0)
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.0, max_dist=max_dist)
     roots = list(range(R))
 
     def infer_host(reqs):
