@@ -131,7 +131,16 @@ int plan(const ipp_config& c, Layout& L) {
     if (c.max_measurements > IPP_MAX_MEAS) return fail(-1, "max_measurements above %d is not compiled in", IPP_MAX_MEAS);
     L.FC = 4 * L.MC;
     L.QS = (L.MC + 3) & ~3;
-    L.VEC = (L.MC == 9) ? 4 : 2;  // cells per thread of the streaming kernels (register budget)
+    // cells per thread of the streaming kernels (register budget).  Windowed factor columns are stored and streamed on
+    // whole tiles of 64 VEC cells: 128-cell tiles round a step's window up by half as much as 256-cell tiles do, and the
+    // step moves 15 % fewer bytes (4096 envs of 50x50: 12.5 -> 13.8 M env-steps/s; every config gained 5-11 %)
+    // Only while a window is a few tiles: at 200x200 (20 tiles of 256 cells per step) the rounding is 2.5 % of the bytes and
+    // twice as many tiles cost more than that in per-tile work (configs[4] tree wave: 13.4 M steps/s with 256-cell tiles,
+    // 12.1 M with 128).
+    const bool windowed = c.state_repr == IPP_FACTOR && c.window_rows > 0;
+    const long window_cells = std::min<long>(c.y_dim, 2L * c.window_rows + 5) * c.x_dim;
+    L.VEC = (L.MC == 9 && !(windowed && window_cells < 16 * 256)) ? 4 : 2;
+    if (const char* ve = getenv("IPP_VEC")) { if (L.MC == 9 && (atoi(ve) == 2 || atoi(ve) == 4)) L.VEC = atoi(ve); }  // A/B experiments
     L.N = c.x_dim * c.y_dim;
     const int n4 = (L.N + L.VEC - 1) / L.VEC;
     if (c.tile_threads > 0) {
@@ -626,8 +635,11 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     if (e->pipe) {
-        const void* kfn = (v.meas_cap == 9) ? reinterpret_cast<const void*>(&k_step_pipe<9, 4>) : reinterpret_cast<const void*>(&k_step_pipe<25, 2>);
+        const void* kfn = (v.meas_cap == 9) ? (v.vec == 2 ? reinterpret_cast<const void*>(&k_step_pipe<9, 2>) : reinterpret_cast<const void*>(&k_step_pipe<9, 4>))
+                                            : reinterpret_cast<const void*>(&k_step_pipe<25, 2>);
         (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->pipe_lds);
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPipeThreads, e->pipe_lds) != hipSuccess || per_cu <= 0) per_cu = 0;
@@ -639,6 +651,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     }
     e->tree_step_lds = (e->gain_lds + (size_t)v.rank_cap * 8 + 15) & ~(size_t)15;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     if (e->fused && e->tv.node_cap > 0 && v.meas_cap == 9) {
         // Split tree steps: worth it once the launch fills the device several times over (below that the second launch
         // and the scratch round trip of L^-1 | Q cost more than the occupancy gains); IPP_TREE_SPLIT=<min items> / 0
@@ -648,6 +661,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         if (const char* ts = getenv("IPP_TREE_SPLIT")) e->tree_split_min = atoi(ts);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_prepare<9>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -778,7 +792,8 @@ static int step_impl(void* engine, const int32_t* env_ids, const int32_t* dst_id
     const AutoReset none = {nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
     int rc;
     if (e->v.meas_cap == 9)
-        rc = launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none);
+        rc = (e->v.vec == 2) ? launch_step<9, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none)
+                             : launch_step<9, 4>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none);
     else
         rc = launch_step<25, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none);
     if (rc == 0 && ar.src && !in_kernel) {
@@ -910,9 +925,16 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     if (v.meas_cap == 9 && e->tree_split_min > 0 && n >= e->tree_split_min) {
         timed_launch(e, 2, k_tree_prepare<9>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action,
                      prev_action, flags, status);
-        timed_launch(e, 0, k_tree_gain<9, 4>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
-                     new_ids, n, flags, e->lut_rows, reward);
-    } else if (v.meas_cap == 9)
+        if (v.vec == 2)
+            timed_launch(e, 0, k_tree_gain<9, 2>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
+                         new_ids, n, flags, e->lut_rows, reward);
+        else
+            timed_launch(e, 0, k_tree_gain<9, 4>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
+                         new_ids, n, flags, e->lut_rows, reward);
+    } else if (v.meas_cap == 9 && v.vec == 2)
+        timed_launch(e, 0, k_tree_step<9, 2>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
+                     action, prev_action, flags, e->lut_rows, status, reward);
+    else if (v.meas_cap == 9)
         timed_launch(e, 0, k_tree_step<9, 4>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                      action, prev_action, flags, e->lut_rows, status, reward);
     else

@@ -16,6 +16,7 @@
 // No workgroup barrier inside the tile loop; tiles outside the span of the appended columns are skipped.
 // HBM-bound: 4*MC FMAs per streamed float4; the prologue is paid once per item, not once per tile.
 #pragma once
+#include <type_traits>
 #include "ipp_common.h"
 #include "k_gain.h"
 
@@ -28,6 +29,10 @@
 #ifndef IPP_GF_ABLATE
 #define IPP_GF_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no row stream, 8 = no compaction, 16 = no mean / diag atomics, 32 = no new-row stores
 #endif
+// Rows requested per group by VEC: a row of a 64 * VEC-cell tile is 256 VEC bytes per wave, so the VEC = 2 kernels keep
+// more of them in flight for the same bytes (A/B at 4096 envs of 50x50, VEC = 2: 10 / 16 / 20 rows 13.65 / 13.85 / 13.85 M)
+template <int MC, int VEC> constexpr int sf_pipe() { return (MC == 9 && VEC <= 2) ? 16 : IPP_SF_PIPE; }
+template <int MC, int VEC> constexpr int gf_pipe() { return (MC == 9 && VEC <= 2) ? 16 : IPP_GF_PIPE; }
 #ifndef IPP_GF_MINWAVES
 #define IPP_GF_MINWAVES 4
 #endif
@@ -224,51 +229,67 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             const bool tile_lut = dmax < lut_rows;
             // rf = 1 (altitude <= rf_altitude): every measurement block is one cell, the other three table entries
             // carry weight 0: skip them (wave-uniform)
-            const int n_fc = (h.rf == 1) ? 1 : 4;
-            auto block_term = [&](int b, float (&cb)[VEC]) {
+            // The variants are chosen ONCE per tile (both wave-uniform): decided per lookup, every one of the up to 36 VEC
+            // lookup sites carried a branch around ~25 instructions of inlined sqrt / exp code -- 144 taken branches per
+            // tile and a 9 000-instruction tile body (54 KB: the instruction cache of a CU pair is 64 KB).
+            auto base_term = [&](auto lut_tag, auto nfc_tag) {
+                constexpr bool TL = decltype(lut_tag)::value;
+                constexpr int NFC = decltype(nfc_tag)::value;
+                auto block_term = [&](int b, float (&cb)[VEC]) {
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
+                    for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (a >= n_fc) break;
-                    const int yx = fb_yx[4 * b + a];
-                    const float wa = fb_w[4 * b + a];
-                    const int fy = yx >> 16, fx = yx & 0xffff;
+                    for (int a = 0; a < NFC; ++a) {
+                        const int yx = fb_yx[4 * b + a];
+                        const float wa = fb_w[4 * b + a];
+                        const int fy = yx >> 16, fx = yx & 0xffff;
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-                        const int dr = abs(crow[c] - fy), dc = abs(ccol[c] - fx);
-                        // (24-bit multiply-add: v_mul_lo_u32 runs at quarter rate, and there are up to 36 VEC of these per tile)
-                        const float p0 = tile_lut ? lut[__umul24(dr, v.W) + dc] : matern_f(dr, dc, s3, h.sv);
-                        cb[c] = fmaf(wa, p0, cb[c]);
+                        for (int c = 0; c < VEC; ++c) {
+                            const int dr = abs(crow[c] - fy), dc = abs(ccol[c] - fx);
+                            float p0;
+                            // (24-bit multiply-add: v_mul_lo_u32 runs at quarter rate)
+                            if constexpr (TL) p0 = lut[__umul24(dr, v.W) + dc];
+                            else p0 = matern_f(dr, dc, s3, h.sv);
+                            cb[c] = fmaf(wa, p0, cb[c]);
+                        }
                     }
-                }
-            };
-            if (PRE) {
+                };
+                if (PRE) {
 #pragma unroll
-                for (int b = 0; b < MC; ++b) {  // unrolled: acc[.][b] must be a static register index
-                    if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
-                        float cb[VEC];
-                        block_term(b, cb);
+                    for (int b = 0; b < MC; ++b) {  // unrolled: acc[.][b] must be a static register index
+                        if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                            float cb[VEC];
+                            block_term(b, cb);
 #pragma unroll
-                        for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
+                            for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
+                        }
                     }
-                }
-            } else {
-                // L^-1 is upper triangular (solve_wave_fast: column j of inv(C^T) has rows i <= j): block b feeds the
-                // columns j >= b only, 45 instead of 81 FMAs per cell (b unrolled: acc[.][j] needs static indices)
+                } else {
+                    // L^-1 is upper triangular (solve_wave_fast: column j of inv(C^T) has rows i <= j): block b feeds the
+                    // columns j >= b only, 45 instead of 81 FMAs per cell (b unrolled: acc[.][j] needs static indices)
 #pragma unroll
-                for (int b = 0; b < MC; ++b) {
-                    if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
-                        float cb[VEC];
-                        block_term(b, cb);
+                    for (int b = 0; b < MC; ++b) {
+                        if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                            float cb[VEC];
+                            block_term(b, cb);
 #pragma unroll
-                        for (int j = b; j < MC; ++j) {
-                            const float l = Ls[b * MC + j];
+                            for (int j = b; j < MC; ++j) {
+                                const float l = Ls[b * MC + j];
 #pragma unroll
-                            for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                                for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(cb[c], l, acc[c][j]);
+                            }
                         }
                     }
                 }
+            };
+            typedef std::integral_constant<int, 1> one_cell_t;
+            typedef std::integral_constant<int, 4> four_cells_t;
+            if (tile_lut) {
+                if (h.rf == 1) base_term(std::true_type{}, one_cell_t{});
+                else base_term(std::true_type{}, four_cells_t{});
+            } else {  // (tall footprints / tables cut at 48 KiB only)
+                if (h.rf == 1) base_term(std::false_type{}, one_cell_t{});
+                else base_term(std::false_type{}, four_cells_t{});
             }
         }
 
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
         }
     }
     __syncthreads();
-    gain_tiles<MC, VEC, IPP_GF_PIPE, false, false>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
+    gain_tiles<MC, VEC, gf_pipe<MC, VEC>(), false, false>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
 }
 
 }  // namespace ipp

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, false, true, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
+    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, true, false, true, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
                                                                 nullptr, nullptr, &ar);
 }
 

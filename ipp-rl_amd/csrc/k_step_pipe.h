@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kPipeThreads, IPP_GF_MINWAVES) void k_step_pipe(
         const GainLds<MC> g = buffer(p, hbuf, item_slot);
         const ItemHdr h = uniform_hdr(*hbuf);
         const int item = __builtin_amdgcn_readfirstlane(*item_slot);
-        gain_tiles<MC, VEC, IPP_SF_PIPE, false, true, false, true, false, kPipeConsumers>(
+        gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), false, true, false, true, false, kPipeConsumers>(
             v, h, item, flags, lut_rows, g, v.q + (size_t)item * v.q_item + LQ, reward_out);
         // this wave is done with the buffer (the last one out of gain_tiles has also written the item's results)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

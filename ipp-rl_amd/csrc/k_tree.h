@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     float* new_cols = expand ? new_cols0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     if (expand && tid == 0) { new_meta[2] = parent_id; new_meta[3] = root; }
-    gain_tiles<MC, VEC, IPP_SF_PIPE, true, true, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
+    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, true, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
                                                          reward_out, &cc, new_cols, new_diag, new_meta);
 }
 
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     // (mask and the new node's diagonal per tile, from the parent state's diagonal read under the tile's stream: no
     // phase-A pass over the span)
-    gain_tiles<MC, VEC, IPP_GF_PIPE, false, false, true>(v, h, item, flags_eff, lut_rows, lds, blk + LQ, reward_out, &cc, new_cols,
+    gain_tiles<MC, VEC, gf_pipe<MC, VEC>(), false, false, true>(v, h, item, flags_eff, lut_rows, lds, blk + LQ, reward_out, &cc, new_cols,
                                                        new_diag, new_meta, nullptr, &dc);
 }
 
