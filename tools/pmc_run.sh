@@ -1,5 +1,6 @@
 #!/bin/bash
 # Collect PMC counters for the bench kernels (separate passes; no trace domains combined with --pmc).
+# Every pass runs under `timeout`: a pass whose counter set is rejected can hang in the profiler's teardown.
 # usage (on the GPU box): [PMC_SETS=traffic] bash tools/pmc_run.sh <outdir> [bench args...]
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -17,7 +18,7 @@ fi
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o pmc -- python3 bench.py --no-cpu-baseline --no-extra "$@" > "$out/pass$i.log" 2>&1
+  timeout 900 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o pmc -- python3 bench.py --no-cpu-baseline --no-extra "$@" > "$out/pass$i.log" 2>&1
   tail -1 "$out/pass$i.log" | cut -c1-200
 done
 find "$out" -name "*.csv" | head -20

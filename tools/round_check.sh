@@ -12,10 +12,13 @@ python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut 
 grep -v amdgpu.ids $O/extras.txt | tail -12
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # kernel trace of the headline command line (no extras: one workload per trace)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o kt -- python3 bench.py --no-cpu-baseline --no-extra > $O/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o kt -- python3 bench.py --no-cpu-baseline --no-extra > $O/trace.log 2>&1
 python tools/trace_phases.py $O/trace/kt_kernel_trace.csv $O/trace.log > $O/trace_phases.txt 2>&1; cat $O/trace_phases.txt
 # and of configs[2] (the split path: k_prepare + k_gain_factor)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2 -o kt -- python3 bench.py --no-cpu-baseline --no-extra --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/trace_cfg2.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2 -o kt -- python3 bench.py --no-cpu-baseline --no-extra --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/trace_cfg2.log 2>&1
+# configs[4]: the tree wave (k_tree_prepare + k_tree_gain) and the device-side search (k_mcts_*)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tree -o kt -- python3 tools/tree_wave.py --reps 2 > $O/trace_tree.log 2>&1; tail -1 $O/trace_tree.log | cut -c1-300
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_mcts -o kt -- python3 tools/mcts_bench.py --reps 2 > $O/trace_mcts.log 2>&1; tail -1 $O/trace_mcts.log | cut -c1-300
 # PMC passes (separate runs, counters only)
 bash tools/pmc_run.sh $O/pmc > $O/pmc_run.log 2>&1
 python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json
@@ -25,7 +28,7 @@ PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --grid 100 --envs 32768 --epi
 python tools/pmc_summary.py $O/pmc_cfg2 16 > $O/pmc_summary_cfg2.json 2>>$O/pmc_summary.err
 # WRITE_SIZE / FETCH_SIZE calibration on known byte counts (tools/probes/write_probe.hip)
 for c in WRITE_SIZE FETCH_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/wp_$c -o wp -- ./tools/probes/write_probe 1024 > $O/wp_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/wp_$c -o wp -- ./tools/probes/write_probe 1024 > $O/wp_$c.log 2>&1
 done
 python - <<'PY' > $O/write_probe_calibration.txt 2>&1
 import csv, glob, collections
