@@ -191,7 +191,8 @@ def baseline_config_name(grid, envs, episode_steps, total=None):
 
 def workload_key(args):
     return {"envs": args.envs, "grid": args.grid, "state": args.state, "window_rows": args.window_rows,
-            "tile_threads": args.tile_threads, "episode_steps": args.episode_steps, "predict_only": bool(args.predict_only)}
+            "tile_threads": args.tile_threads, "episode_steps": args.episode_steps, "predict_only": bool(args.predict_only),
+            "shuffle_prior": bool(args.shuffle_prior)}
 
 
 def cpu_baseline(cfg, args):

@@ -176,7 +176,7 @@ int plan(const ipp_config& c, Layout& L) {
         // of ~20 rows per item): the per-item latency chain of the fused kernel and its workgroup-granular dispatch leave
         // the stream at 32 % of peak; the prologue as its own kernel + a 128-thread gain kernel streams at 50 % and is 15 %
         // faster per step with the two pipelined over 4 chunks.  Tree steps need the fused layout.
-        if (c.tile_threads <= 0 && c.node_capacity <= 0 && (n4 + 63) / 64 >= 24 && c.capacity >= 8192 && c.rank_cap <= 192) L.T = 128;
+        if (c.tile_threads <= 0 && c.node_capacity <= 0 && L.N >= 24 * 256 - 255 && c.capacity >= 8192 && c.rank_cap <= 192) L.T = 128;  // (>= 24 tiles of 256 cells)
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;
