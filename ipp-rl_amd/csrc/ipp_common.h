@@ -147,6 +147,8 @@ struct View {
     double* grf_h;   // [H][W] circular-convolution kernel of the GRF
     double2* grf_cs; // [W] (cos, sin)(2 pi j / W)          (k_grf_dft.h)
     double* grf_g;   // [H/2+1][W] column-convolution kernels  (k_grf_dft.h)
+    double* grf_hp;  // [NP][NP] Hartley matrix cos + sin of 2 pi j k / n, zero padded to NP = 16 ceil(n / 16)  (k_grf_hartley.h)
+    double* grf_amp; // [NP][NP] spectral amplitude, zero padded  (k_grf_hartley.h)
     float* grf_raw;  // [max_batch][Npad] un-normalised field (ipp_reset)
     float* grf_raw2; // [max_batch][Npad] un-normalised field (ipp_generate_grf, may run on a side stream)
 };

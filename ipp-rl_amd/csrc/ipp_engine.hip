@@ -21,6 +21,7 @@
 #include "k_gain_wave.h"
 #include "k_misc.h"
 #include "k_grf_dft.h"
+#include "k_grf_hartley.h"
 #include "k_score.h"
 #include "k_plane.h"
 #include "k_tree.h"
@@ -72,6 +73,7 @@ struct Engine {
     bool scoring = false;  // arena holds the ipp_score_actions scratch
     ScoreView sv = {};
     bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
+    int grf_tt = 0;        // > 0: even square grids up to 128: k_grf_hartley<grf_tt> (fp64 MFMA GEMMs)
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
     int lut_rows = 0;  // workgroup-per-item factor kernels: rows |drow| of the prior table kept in LDS
@@ -96,7 +98,7 @@ struct Engine {
 struct Layout {
     int N, Npad, T, n_tiles, win_tiles, MC, FC, QS, q_rows, VEC;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
-        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
+        off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfhp, off_grfamp, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
 };
 
 uint64_t q_item_floats(const Layout& L) {
@@ -210,6 +212,12 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_grfh = o; o += up((uint64_t)L.N * 8);
     L.off_grfcs = o; o += up((uint64_t)c.x_dim * 16);                       // (cos, sin)(2 pi j / n)
     L.off_grfg = o; o += up((uint64_t)(c.y_dim / 2 + 1) * c.x_dim * 8);    // g_k[d], k = 0 .. n/2 (k_grf_dft.h)
+    {
+        const uint64_t npad = 16 * (uint64_t)((std::max(c.x_dim, c.y_dim) + 15) / 16);
+        const uint64_t tab = (c.x_dim == c.y_dim && c.x_dim % 2 == 0 && c.x_dim <= 128) ? npad * npad * 8 : 8;
+        L.off_grfhp = o; o += up(tab);
+        L.off_grfamp = o; o += up(tab);
+    }
     L.off_grfraw = o; o += up(mb * np * 4);
     L.off_grfraw2 = o; o += up(mb * np * 4);
     L.off_sc_hdr = L.off_sc_ext = L.off_sc_mask = L.off_sc_G = L.off_sc_P = o;
@@ -445,9 +453,52 @@ void grf_dft_tables_host(int n, double c, std::vector<double>& cs, std::vector<d
     }
 }
 
+// Tables of k_grf_hartley.h, zero padded to np x np: H[j][k] = cos + sin of 2 pi j k / n; amp as ground_truths.py:20-27.
+// Returns false when the amplitude is not even in each index (then the Hartley form does not apply).
+bool grf_hartley_tables_host(int n, int np, double c, std::vector<double>& hp, std::vector<double>& amp) {
+    std::vector<int> kidx;
+    for (int i = 0; i <= n / 2; ++i) kidx.push_back(i);
+    for (int i = n / 2 - 1; i >= 1; --i) kidx.push_back(-i);  // ground_truths.py:7-11 (n entries for even n)
+    hp.assign((size_t)np * np, 0.0);
+    amp.assign((size_t)np * np, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k) {
+            const double a = 2.0 * M_PI * (double)(((long)j * k) % n) / n;
+            hp[(size_t)j * np + k] = std::cos(a) + std::sin(a);
+            const double kk = std::sqrt((double)kidx[j] * kidx[j] + (double)kidx[k] * kidx[k]);
+            amp[(size_t)j * np + k] = (kidx[j] == 0 && kidx[k] == 0) ? 0.0 : std::sqrt(std::pow(kk, -c));
+        }
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k) {
+            const int jm = (n - j) % n, km = (n - k) % n;
+            if (amp[(size_t)j * np + k] != amp[(size_t)jm * np + k] || amp[(size_t)j * np + k] != amp[(size_t)j * np + km]) return false;
+        }
+    return true;
+}
+
+template <int TT>
+void launch_grf_hartley(const View& v, int n, const float* white, const int32_t* env_ids, float* gt_out, hipStream_t s) {
+    hipLaunchKernelGGL((k_grf_hartley<TT>), dim3(n), dim3(256), grf_hartley_lds_bytes(TT), s, v, env_ids, n, white,
+                       (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
+}
+
 int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
     const View& v = e->v;
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
+    if (e->grf_tt > 0) {  // even n <= 128: four fp64 GEMMs on the matrix cores, normalisation fused (k_grf_hartley.h)
+        switch (e->grf_tt) {
+            case 1: launch_grf_hartley<1>(v, n, white, env_ids, gt_out, s); break;
+            case 2: launch_grf_hartley<2>(v, n, white, env_ids, gt_out, s); break;
+            case 3: launch_grf_hartley<3>(v, n, white, env_ids, gt_out, s); break;
+            case 4: launch_grf_hartley<4>(v, n, white, env_ids, gt_out, s); break;
+            case 5: launch_grf_hartley<5>(v, n, white, env_ids, gt_out, s); break;
+            case 6: launch_grf_hartley<6>(v, n, white, env_ids, gt_out, s); break;
+            case 7: launch_grf_hartley<7>(v, n, white, env_ids, gt_out, s); break;
+            default: launch_grf_hartley<8>(v, n, white, env_ids, gt_out, s); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (e->grf_dft) {  // even n <= 256: half-spectrum DFT, normalisation fused (k_grf_dft.h)
         const bool small = v.W <= 100;
         const int nt = small ? 256 : 1024;
@@ -558,6 +609,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.grf_h = reinterpret_cast<double*>(base + L.off_grfh);
     v.grf_cs = reinterpret_cast<double2*>(base + L.off_grfcs);
     v.grf_g = reinterpret_cast<double*>(base + L.off_grfg);
+    v.grf_hp = reinterpret_cast<double*>(base + L.off_grfhp);
+    v.grf_amp = reinterpret_cast<double*>(base + L.off_grfamp);
     v.grf_raw = reinterpret_cast<float*>(base + L.off_grfraw);
     v.grf_raw2 = reinterpret_cast<float*>(base + L.off_grfraw2);
     e->tv.node_cap = std::max(0, cfg->node_capacity);
@@ -679,6 +732,21 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         const int n = cfg->x_dim;
         e->grf_dft = (n % 2 == 0) && n >= 4 && n <= 256;  // odd n: the reference's amp is not even (ground_truths.py:8-11)
         if (const char* gc = getenv("IPP_GRF_CONV")) e->grf_dft = e->grf_dft && atoi(gc) == 0;  // A/B experiments
+        if (e->grf_dft && n <= 128) {
+            const int tt = (n + 15) / 16;
+            std::vector<double> hp, amp;
+            bool ok = grf_hartley_tables_host(n, 16 * tt, cfg->cluster_radius, hp, amp);
+            if (const char* gh = getenv("IPP_GRF_HARTLEY")) ok = ok && atoi(gh) != 0;  // A/B experiments
+            if (ok) {
+                HIP_TRY(hipMemcpy(v.grf_hp, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(v.grf_amp, amp.data(), amp.size() * sizeof(double), hipMemcpyHostToDevice));
+                e->grf_tt = tt;
+                const int hl = (int)grf_hartley_lds_bytes(tt);
+                const void* fn[] = {(const void*)&k_grf_hartley<1>, (const void*)&k_grf_hartley<2>, (const void*)&k_grf_hartley<3>, (const void*)&k_grf_hartley<4>,
+                                    (const void*)&k_grf_hartley<5>, (const void*)&k_grf_hartley<6>, (const void*)&k_grf_hartley<7>, (const void*)&k_grf_hartley<8>};
+                (void)hipFuncSetAttribute(fn[tt - 1], hipFuncAttributeMaxDynamicSharedMemorySize, hl);
+            }
+        }
         if (e->grf_dft) {
             std::vector<double> cs, g;
             grf_dft_tables_host(n, cfg->cluster_radius, cs, g);

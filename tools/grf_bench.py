@@ -33,9 +33,12 @@ def main():
             eng.generate_grf(white, out=out)
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / reps
-        fma = 3.0 * n ** 3 * fields
+        fma = 3.0 * n ** 3 * fields  # half-spectrum DFT form (k_grf_dft.h)
+        npad = 16 * ((n + 15) // 16)
+        gemm = 4.0 * npad ** 3 * fields if n % 2 == 0 and n <= 128 else 0.0  # four padded GEMMs (k_grf_hartley.h)
         print(f"[{n}x{n}, {fields} fields] {ms:.3f} ms per call, {fields / ms * 1e3:.3e} fields/s, "
-              f"{2 * fma / ms / 1e9:.1f} fp64 TFLOP/s on the 3 n^3 FMA count")
+              f"{2 * fma / ms / 1e9:.1f} fp64 TFLOP/s on the 3 n^3 FMA count"
+              + (f", {2 * gemm / ms / 1e9:.1f} TFLOP/s on the padded GEMMs" if gemm else ""))
         eng.close()
 
 
