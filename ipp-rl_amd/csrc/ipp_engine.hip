@@ -476,9 +476,12 @@ bool grf_hartley_tables_host(int n, int np, double c, std::vector<double>& hp, s
     return true;
 }
 
+// 8 waves (one owned 16-row tile each) from TT = 5: half the registers per wave of the 4-wave form, so that waves of the
+// streaming kernels still fit beside a field's workgroup on every SIMD
 template <int TT>
 void launch_grf_hartley(const View& v, int n, const float* white, const int32_t* env_ids, float* gt_out, hipStream_t s) {
-    hipLaunchKernelGGL((k_grf_hartley<TT>), dim3(n), dim3(256), grf_hartley_lds_bytes(TT), s, v, env_ids, n, white,
+    constexpr int NW = (TT > 4 && TT < 8) ? 8 : 4;  // (TT = 8 with one tile per wave spills 112 registers at the 168 it may use)
+    hipLaunchKernelGGL((k_grf_hartley<TT, NW>), dim3(n), dim3(64 * NW), grf_hartley_lds_bytes(TT), s, v, env_ids, n, white,
                        (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
 }
 
@@ -742,8 +745,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                 HIP_TRY(hipMemcpy(v.grf_amp, amp.data(), amp.size() * sizeof(double), hipMemcpyHostToDevice));
                 e->grf_tt = tt;
                 const int hl = (int)grf_hartley_lds_bytes(tt);
-                const void* fn[] = {(const void*)&k_grf_hartley<1>, (const void*)&k_grf_hartley<2>, (const void*)&k_grf_hartley<3>, (const void*)&k_grf_hartley<4>,
-                                    (const void*)&k_grf_hartley<5>, (const void*)&k_grf_hartley<6>, (const void*)&k_grf_hartley<7>, (const void*)&k_grf_hartley<8>};
+                const void* fn[] = {(const void*)&k_grf_hartley<1, 4>, (const void*)&k_grf_hartley<2, 4>, (const void*)&k_grf_hartley<3, 4>, (const void*)&k_grf_hartley<4, 4>,
+                                    (const void*)&k_grf_hartley<5, 8>, (const void*)&k_grf_hartley<6, 8>, (const void*)&k_grf_hartley<7, 8>, (const void*)&k_grf_hartley<8, 4>};
                 (void)hipFuncSetAttribute(fn[tt - 1], hipFuncAttributeMaxDynamicSharedMemorySize, hl);
             }
         }

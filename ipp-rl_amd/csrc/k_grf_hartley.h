@@ -30,22 +30,24 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline size_t grf_hartley_lds_bytes(int tt) {
     const size_t np = 16 * (size_t)tt;
-    return np * (np + 1) * 8 + 2 * 8 * 8;
+    return np * (np + 1) * 8 + 2 * 8 * 8 + 64;
 }
 
-// Y = H X for the row tiles {wave, wave + 4} of Y: hreg[o][ks] = H[16 (wave + 4 o) + (lane & 15)][4 ks + (lane >> 4)]
+// Y = H X for the row tiles {wave, wave + NW} of Y (NW waves per workgroup, OW = ceil(TT / NW) <= 2 owned tiles):
+// hreg[o][ks] = H[16 (wave + NW o) + (lane & 15)][4 ks + (lane >> 4)]
 // (A fragments; H symmetric, so loaded as row k of H at 16 consecutive columns), X in LDS with leading dimension ld.
-template <int TT>
-__device__ __forceinline__ void grf_gemm(const double (&hreg)[2][4 * TT], const double* X, int ld, int wave, int lane,
-                                         v4f64 (&acc)[2][TT]) {
+template <int TT, int NW, int OW>
+__device__ __forceinline__ void grf_gemm(const double (&hreg)[OW][4 * TT], const double* X, int ld, int wave, int lane,
+                                         v4f64 (&acc)[OW][TT]) {
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < OW; ++o)
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[o][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const bool two = wave + 4 < TT;  // second owned tile (wave-uniform)
+    const bool two = OW > 1 && wave + NW < TT;  // second owned tile (wave-uniform)
 #pragma unroll
-    for (int ks = 0; ks < 4 * TT; ++ks) {  // (fully unrolled: hreg needs static indices)
+    for (int ks = 0; ks < 4 * TT; ++ks) {  // (fully unrolled: hreg needs static indices; stopping at ceil(n / 4) steps
+                                           // with a uniform branch per step broke the schedule: 64x64 0.10 -> 0.13 ms)
         const double* xr = X + (4 * ks + l4) * ld + l15;  // B[k][col]: 4 rows x 16 consecutive columns
         double xf[TT];
 #pragma unroll
@@ -53,42 +55,44 @@ __device__ __forceinline__ void grf_gemm(const double (&hreg)[2][4 * TT], const 
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(hreg[0][ks], xf[t], acc[0][t], 0, 0, 0);
-            if (two) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(hreg[1][ks], xf[t], acc[1][t], 0, 0, 0);
+            if constexpr (OW > 1)
+                if (two) acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(hreg[1][ks], xf[t], acc[1][t], 0, 0, 0);
         }
     }
 }
 
-// X <- Y^T (.* scale): accumulator element r of tile (o, t) is Y[16 (wave + 4 o) + (lane >> 4) + 4 r][16 t + (lane & 15)]
-template <int TT>
-__device__ __forceinline__ void grf_store_t(double* X, int ld, int wave, int lane, const v4f64 (&acc)[2][TT],
+// X <- Y^T (.* scale): accumulator element r of tile (o, t) is Y[16 (wave + NW o) + (lane >> 4) + 4 r][16 t + (lane & 15)]
+template <int TT, int NW, int OW>
+__device__ __forceinline__ void grf_store_t(double* X, int ld, int wave, int lane, const v4f64 (&acc)[OW][TT],
                                             const double* __restrict__ scale) {
     constexpr int NP = 16 * TT;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        if (wave + 4 * o >= TT) break;
+    for (int o = 0; o < OW; ++o) {
+        if (wave + NW * o >= TT) break;
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * (wave + 4 * o) + (lane >> 4) + 4 * r, col = 16 * t + (lane & 15);
+                const int row = 16 * (wave + NW * o) + (lane >> 4) + 4 * r, col = 16 * t + (lane & 15);
                 X[col * ld + row] = scale ? acc[o][t][r] * scale[(size_t)col * NP + row] : acc[o][t][r];
             }
     }
 }
 
-template <int TT>
-__global__ __launch_bounds__(256) void k_grf_hartley(View v, const int* __restrict__ env_ids, int n_items,
+template <int TT, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 3 : 1))) void k_grf_hartley(View v, const int* __restrict__ env_ids, int n_items,
                                                      const float* __restrict__ white, const double* __restrict__ Hp,
                                                      const double* __restrict__ ampp, float* __restrict__ gt_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gh[];
-    constexpr int NP = 16 * TT, LD = NP + 1;
+    constexpr int NP = 16 * TT, LD = NP + 1, NT = 64 * NW, OW = (TT + NW - 1) / NW;
+    static_assert(OW <= 2, "at most two owned tiles per wave");
     const int n = v.W, N = v.N;
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
     if (env < 0 || env >= v.cap) return;
     double* X = reinterpret_cast<double*>(smem_gh);
-    double* red = X + (size_t)NP * LD;  // [2][4] min / max per wave
+    double* red = X + (size_t)NP * LD;  // [2][8] min / max per wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* __restrict__ wn = white + (size_t)item * N;
     // white noise -> fp64 in LDS: pairs of cells (n is even, so a pair never straddles a row), zero padding to NP x NP
@@ -96,53 +100,53 @@ __global__ __launch_bounds__(256) void k_grf_hartley(View v, const int* __restri
         const float2* __restrict__ w2 = reinterpret_cast<const float2*>(wn);
         const int half = n / 2, n2 = n * half;
 #pragma unroll 4
-        for (int i = tid; i < n2; i += 256) {
+        for (int i = tid; i < n2; i += NT) {
             const float2 wv = w2[i];
             const int y = i / half, x = 2 * (i - y * half);
             X[y * LD + x] = (double)wv.x;
             X[y * LD + x + 1] = (double)wv.y;
         }
         const int padc = NP - n;  // columns n .. NP-1 of the rows < n, then whole rows n .. NP-1
-        for (int i = tid; i < n * padc; i += 256) X[(i / padc) * LD + n + i % padc] = 0.0;
-        for (int i = tid; i < padc * NP; i += 256) X[(n + i / NP) * LD + i % NP] = 0.0;
+        for (int i = tid; i < n * padc; i += NT) X[(i / padc) * LD + n + i % padc] = 0.0;
+        for (int i = tid; i < padc * NP; i += NT) X[(n + i / NP) * LD + i % NP] = 0.0;
     }
     // this wave's fragments of H, once for the four GEMMs
-    double hreg[2][4 * TT];
+    double hreg[OW][4 * TT];
     {
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int c0 = 16 * min(wave, TT - 1) + l15, c1 = 16 * min(wave + 4, TT - 1) + l15;  // (waves beyond TT own nothing)
 #pragma unroll
-        for (int ks = 0; ks < 4 * TT; ++ks) {
-            hreg[0][ks] = Hp[(size_t)(4 * ks + l4) * NP + c0];
-            hreg[1][ks] = Hp[(size_t)(4 * ks + l4) * NP + c1];
+        for (int o = 0; o < OW; ++o) {
+            const int c = 16 * min(wave + NW * o, TT - 1) + l15;  // (waves beyond TT own nothing: their results are dropped)
+#pragma unroll
+            for (int ks = 0; ks < 4 * TT; ++ks) hreg[o][ks] = Hp[(size_t)(4 * ks + l4) * NP + c];
         }
     }
     __syncthreads();
-    v4f64 acc[2][TT];
-    grf_gemm<TT>(hreg, X, LD, wave, lane, acc);        // Y1 = H w
+    v4f64 acc[OW][TT];
+    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y1 = H w
     __syncthreads();
-    grf_store_t<TT>(X, LD, wave, lane, acc, nullptr);  // X = Y1^T
+    grf_store_t<TT, NW, OW>(X, LD, wave, lane, acc, nullptr);  // X = Y1^T
     __syncthreads();
-    grf_gemm<TT>(hreg, X, LD, wave, lane, acc);        // Y2 = H Y1^T = (H w H)^T
+    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y2 = H Y1^T = (H w H)^T
     __syncthreads();
-    grf_store_t<TT>(X, LD, wave, lane, acc, ampp);     // X = amp .* (H w H)
+    grf_store_t<TT, NW, OW>(X, LD, wave, lane, acc, ampp);     // X = amp .* (H w H)
     __syncthreads();
-    grf_gemm<TT>(hreg, X, LD, wave, lane, acc);        // Y3
+    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y3
     __syncthreads();
-    grf_store_t<TT>(X, LD, wave, lane, acc, nullptr);
+    grf_store_t<TT, NW, OW>(X, LD, wave, lane, acc, nullptr);
     __syncthreads();
-    grf_gemm<TT>(hreg, X, LD, wave, lane, acc);        // Y4 = field^T, in registers
+    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y4 = field^T, in registers
 
     // ---- min-max normalisation to [0, 1] (ground_truths.py:31), fp64 like the reference
     double lo = INFINITY, hi = -INFINITY;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        if (wave + 4 * o >= TT) break;
+    for (int o = 0; o < OW; ++o) {
+        if (wave + NW * o >= TT) break;
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * (wave + 4 * o) + (lane >> 4) + 4 * r, col = 16 * t + (lane & 15);
+                const int row = 16 * (wave + NW * o) + (lane >> 4) + 4 * r, col = 16 * t + (lane & 15);
                 if (row < n && col < n) { lo = fmin(lo, acc[o][t][r]); hi = fmax(hi, acc[o][t][r]); }
             }
     }
@@ -151,25 +155,26 @@ __global__ __launch_bounds__(256) void k_grf_hartley(View v, const int* __restri
         lo = fmin(lo, __shfl_xor(lo, off));
         hi = fmax(hi, __shfl_xor(hi, off));
     }
-    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    if (lane == 0) { red[wave] = lo; red[8 + wave] = hi; }
     __syncthreads();
-    const double dlo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-    const double dhi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    double dlo = red[0], dhi = red[8];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[8 + w]); }
     const double span = dhi - dlo;
     float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        if (wave + 4 * o >= TT) break;
+    for (int o = 0; o < OW; ++o) {
+        if (wave + NW * o >= TT) break;
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * (wave + 4 * o) + (lane >> 4) + 4 * r, col = 16 * t + (lane & 15);
+                const int row = 16 * (wave + NW * o) + (lane >> 4) + 4 * r, col = 16 * t + (lane & 15);
                 if (row < n && col < n) gt[col * n + row] = (float)((acc[o][t][r] - dlo) / span);  // (acc holds field^T)
             }
     }
     if (!gt_out)
-        for (int i = N + tid; i < v.Npad; i += 256) gt[i] = 0.f;
+        for (int i = N + tid; i < v.Npad; i += NT) gt[i] = 0.f;
 }
 
 }  // namespace ipp
