@@ -28,11 +28,6 @@ namespace ipp {
 constexpr int kMctsPath = 6;  // == kTreeDepth: device nodes on a path
 constexpr unsigned char kNodeExpanded = 1, kNodeStored = 2;
 
-__device__ __forceinline__ double mc_bcast(double x, int src) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 __device__ __forceinline__ double mc_first(double x) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(x);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
