@@ -116,6 +116,7 @@ struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL
     int mode, cap, rank_cap, max_batch;
     int window_rows, tile_cells;
+    int clip_cols;  // windowed factor state: new columns are zero on the grid COLUMNS farther than window_rows from the footprint too
     int win_tiles;  // windowed factor state: most tiles [t_lo, t_hi] one step can touch (n_tiles when not windowed)
     int meas_cap, fp_cap, q_stride, q_rows;
     uint64_t q_item;  // floats of Q scratch per item: (q_rows + 2*kPipe pad rows) * q_stride

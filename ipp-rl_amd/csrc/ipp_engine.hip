@@ -599,6 +599,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
     v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
+    // two-dimensional windows (k_gain_factor.h): every kernel that appends columns of a windowed state clips them (the
+    // one-wave-per-item kernel of tile_threads = 64 and the pipelined kernel do not: off for those engines)
+    v.clip_cols = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0 && L.T != 64 && cfg->x_dim > 2 * cfg->window_rows + 13) ? 1 : 0;
+    if (const char* cl = getenv("IPP_CLIP_COLS")) v.clip_cols = v.clip_cols && atoi(cl) != 0;  // A/B experiments
     v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;

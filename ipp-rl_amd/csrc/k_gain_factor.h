@@ -103,6 +103,17 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
     }
 }
 
+// Stored columns that cannot contribute to this step are taken out of the item's span table (an empty span: lo > hi):
+// a column whose row of H U^T (rows: [k][stride], m values each) is exactly zero has an exactly zero Q row, so streaming
+// it would add zeros.  With View::clip_cols that is every column whose own column range misses the footprint.
+__device__ __forceinline__ void mark_inactive_columns(int* span_s, const float* rows, int stride, int r, int m, int tid, int T) {
+    for (int k = tid; k < r; k += T) {
+        bool any = false;
+        for (int i = 0; i < m; ++i) any |= rows[(size_t)k * stride + i] != 0.f;
+        if (!any) span_s[k] = 0xffff;  // lo = 0xffff, hi = 0: covers no tile
+    }
+}
+
 // Pointer (indexed with the absolute cell) to the diagonal of the state (root env `root_diag` + path nodes) on `tile`.
 struct DiagChain {
     const float* root_diag;
@@ -173,6 +184,16 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const unsigned long long loop0_ = wall_clock64();
 #endif
 
+    // Two-dimensional windows (View::clip_cols).  The window of a step is a band of whole grid rows, but a new column
+    // decays with the distance to the footprint in BOTH directions (the criterion of window_rows is isotropic): the cells of
+    // the band whose grid column is farther than window_rows from the footprint's columns get a ZERO in the new columns
+    // (stored, so that every later reader sees zeros there) and their lanes request nothing.  The point is not the
+    // bytes (halving them alone did not change the step time: the stream is bound by latency per (tile, stored row)
+    // pair): a stored column whose own column range misses this step's FOOTPRINT has an exactly zero row of H U^T,
+    // hence an exactly zero Q row, and is dropped from the stream altogether by the callers (mark_inactive_columns).
+    const int clip_lo = v.clip_cols ? max(0, h.xl - v.window_rows) : 0;
+    const int clip_hi = v.clip_cols ? min(v.W - 1, h.xr + v.window_rows) : v.W - 1;
+
     // tiles are handed out dynamically (LDS counter): a wave that finishes a short tile takes the next one, in address
     // order.  (Handing them out from the footprint's tile outwards -- longest first -- measured 3-9 % SLOWER on every
     // config: neighbouring tiles streamed at the same time share DRAM pages of the same stored rows.)
@@ -208,6 +229,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         __builtin_amdgcn_wave_barrier();
 
         // ---- base term from the analytic prior: Wc0[i,:] = sum_b (sum_{f in block b} w_f P0[i, F_f]) L_inv[b,:]
+        unsigned inmask = (1u << VEC) - 1u;  // cells of this lane inside the column range of the step
         float acc[VEC][MC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c)
@@ -220,6 +242,11 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 const int cell = min(cell0 + c, v.N - 1);
                 crow[c] = cell / v.W;
                 ccol[c] = cell - crow[c] * v.W;
+            }
+            if (v.clip_cols) {
+                inmask = 0u;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) inmask |= ((ccol[c] >= clip_lo && ccol[c] <= clip_hi) ? 1u : 0u) << c;
             }
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
@@ -311,6 +338,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             for (int a = 0; a < nact; a += KP) {
                 rowv u[KP];
                 int kk[KP];
+                const float* rowk[KP];
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     kk[i] = col_of(a + i);
@@ -319,8 +347,14 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     const int ku = kk[i] < r ? kk[i] : safe_k;
                     // (CHAIN: the column's pointer from the LDS table; evaluating ChainCols::row here cost ~40 scalar
                     // instructions per column and spilled SGPRs: the tile loop was issue-bound, not memory-bound)
-                    const float* rowk = CHAIN ? uni_ptr(lds.rowp[ku]) : cov_src + (size_t)ku * npad;
-                    u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk + cell0));
+                    rowk[i] = CHAIN ? uni_ptr(lds.rowp[ku]) : cov_src + (size_t)ku * npad;
+                }
+                if (inmask) {  // (one exec-mask region for the whole group: clipped lanes request nothing)
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk[i] + cell0));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) u[i] = (rowv)(0.f);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
 #pragma unroll
@@ -383,7 +417,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         double part = 0.0;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            const bool valid = (cell0 + c) < v.N;
+            const bool valid = (cell0 + c) < v.N && ((inmask >> c) & 1u) != 0u;  // (clipped cells: zeros in the new columns)
             float w2 = 0.f, dm = 0.f;
 #pragma unroll
             for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
@@ -407,8 +441,14 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         // 4 N (r + m) + 16 N per committed step = (stored rows + m new rows + mean and diag read and
         // written) floats per touched cell.  LMASK: phase A also read mean / diag of this tile for the mask, which the
         // atomics then read again: those 2 extra floats per cell are traffic, not algorithm -- counted separately
-        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * valid_cells;
-        if (LMASK && commit) extra += 2ull * valid_cells;
+        int in_cells = valid_cells;
+        if (v.clip_cols) {  // stored rows, mean and diag are touched on the cells inside the column range only
+            in_cells = 0;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) in_cells += __popcll(__ballot(((inmask >> c) & 1u) != 0u && (cell0 + c) < v.N));
+        }
+        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells + (unsigned long long)(commit ? m : 0) * (valid_cells - in_cells);
+        if (LMASK && commit) extra += 2ull * in_cells;
         if (commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
             if (LMASK) {
@@ -432,7 +472,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                         if (comp == q) { d_t = dq; m_t = mq; }
                     }
                     const int cell = tile * kWaveTile + kWave * c + lane;
-                    if (cell < v.N && !no_atomics) {
+                    if (cell < v.N && !no_atomics && (d_t != 0.f || m_t != 0.f)) {  // (clipped cells add nothing)
                         unsafeAtomicAdd(dg + kWave * c + lane, -d_t);
                         if (!(flags & IPP_COV_ONLY)) unsafeAtomicAdd(mu + kWave * c + lane, m_t);
                     }
@@ -520,6 +560,10 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
+    if (v.clip_cols) {
+        __syncthreads();
+        mark_inactive_columns(lds.span_s, blk + LQ, (MC + 3) & ~3, r, h.m, tid, T);
+    }
     fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
     {
         const float s3 = (float)(kSqrt3 * v.res) / h.ls;

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     // at 4096 envs (tests/test_hip_edge_cases.py, full-size fused-vs-exact test).  So: every wave waits for its own
     // stores to be acknowledged, then the barrier, then any line of this block left in the (non-coherent) scalar
     // cache by an earlier launch is dropped.
+    if (v.clip_cols) mark_inactive_columns(lds.span_s, lds.work, QS, h.rank, h.m, tid, kStepThreads);  // (published by the barrier below)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();

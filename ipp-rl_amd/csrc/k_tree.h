@@ -168,6 +168,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     // at 4096 envs (tests/test_hip_edge_cases.py, full-size fused-vs-exact test).  So: every wave waits for its own
     // stores to be acknowledged, then the barrier, then any line of this block left in the (non-coherent) scalar
     // cache by an earlier launch is dropped.
+    if (v.clip_cols) mark_inactive_columns(lds.span_s, lds.work, QS, h.rank, h.m, tid, kStepThreads);  // (published by the barrier below)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();
@@ -260,6 +261,10 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) { lds.span_s[k] = cc.span(k); lds.rowp[k] = cc.row(k); }
+    if (v.clip_cols) {
+        __syncthreads();
+        mark_inactive_columns(lds.span_s, blk + LQ, (MC + 3) & ~3, r, h.m, tid, T);
+    }
     fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
     {
         const float s3 = (float)(kSqrt3 * v.res) / h.ls;
