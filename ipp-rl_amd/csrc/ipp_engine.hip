@@ -178,7 +178,9 @@ int plan(const ipp_config& c, Layout& L) {
         // of ~20 rows per item): the per-item latency chain of the fused kernel and its workgroup-granular dispatch leave
         // the stream at 32 % of peak; the prologue as its own kernel + a 128-thread gain kernel streams at 50 % and is 15 %
         // faster per step with the two pipelined over 4 chunks.  Tree steps need the fused layout.
-        if (c.tile_threads <= 0 && c.node_capacity <= 0 && L.N >= 24 * 256 - 255 && c.capacity >= 8192 && c.rank_cap <= 192) L.T = 128;  // (>= 24 tiles of 256 cells)
+        // With two-dimensional windows the stream of an item is short enough for that to hold at 50x50 too (32768 envs:
+        // fused 22.4 M env-steps/s, split 24.7 M, split in 2 chunks 25.6 M; at 4096 envs the fused kernel stays ahead).
+        if (c.tile_threads <= 0 && c.node_capacity <= 0 && c.capacity >= 8192) L.T = 128;
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;
@@ -386,7 +388,7 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
     int chunks = e->step_chunks;
     // measured on MI355X: at 4096 items of 50x50 no gain from 2 chunks, slower from 4; at 32768 items of 100x100 on the
     // split path 4 chunks hide most of the prologue kernel under the previous chunk's gain kernel
-    if (chunks <= 0) chunks = (!e->fused && e->v.mode == IPP_FACTOR && e->v.window_rows > 0 && e->v.T == 128 && n >= 16384) ? 4 : 1;
+    if (chunks <= 0) chunks = (!e->fused && e->v.mode == IPP_FACTOR && e->v.window_rows > 0 && e->v.T == 128 && n >= 16384) ? (e->v.N >= 6000 ? 4 : 2) : 1;
     if (e->profile) chunks = 1;  // kernels are timed alone (bench.py roofline leg)
     chunks = std::min(chunks, kMaxChunks);
     if (chunks <= 1 || !e->side) {

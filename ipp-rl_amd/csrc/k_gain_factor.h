@@ -31,8 +31,11 @@
 #endif
 // Rows requested per group by VEC: a row of a 64 * VEC-cell tile is 256 VEC bytes per wave, so the VEC = 2 kernels keep
 // more of them in flight for the same bytes (A/B at 4096 envs of 50x50, VEC = 2: 10 / 16 / 20 rows 13.65 / 13.85 / 13.85 M)
-template <int MC, int VEC> constexpr int sf_pipe() { return (MC == 9 && VEC <= 2) ? 16 : IPP_SF_PIPE; }
-template <int MC, int VEC> constexpr int gf_pipe() { return (MC == 9 && VEC <= 2) ? 16 : IPP_GF_PIPE; }
+#ifndef IPP_PIPE2
+#define IPP_PIPE2 16
+#endif
+template <int MC, int VEC> constexpr int sf_pipe() { return (MC == 9 && VEC <= 2) ? IPP_PIPE2 : IPP_SF_PIPE; }
+template <int MC, int VEC> constexpr int gf_pipe() { return (MC == 9 && VEC <= 2) ? IPP_PIPE2 : IPP_GF_PIPE; }
 #ifndef IPP_GF_MINWAVES
 #define IPP_GF_MINWAVES 4
 #endif
