@@ -557,7 +557,10 @@ def main(argv=None):
                 "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "launches": rec["launches"],
                 "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
-                "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device",
+                "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device: "
+                                                "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
+                                                "cells of the step's window within window_rows of the footprint in BOTH directions; the cells of the "
+                                                "row band outside that column range only receive the m zeros of the new columns",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],
