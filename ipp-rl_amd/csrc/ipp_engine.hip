@@ -657,10 +657,12 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         while (e->lut_rows > 0 && (size_t)e->lut_rows * v.W > 12288) --e->lut_rows;  // <= 48 KiB
         const int lutf = e->lut_rows * v.W;
         if (v.meas_cap == 9)
-            e->gain_lds = e->fused ? GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, v.win_tiles * kWave)
+            e->gain_lds = e->fused ? std::max(GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, v.win_tiles * kWave),
+                                              GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, 0))
                                    : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles);
         else
-            e->gain_lds = e->fused ? GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave)
+            e->gain_lds = e->fused ? std::max(GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave),
+                                              GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0))
                                    : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles);
         if (e->fused) {
             e->pipe_lds = (v.meas_cap == 9) ? PipeLds<9>::bytes(v.rank_cap, lutf, v.win_tiles) : PipeLds<25>::bytes(v.rank_cap, lutf, v.win_tiles);

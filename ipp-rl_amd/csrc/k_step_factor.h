@@ -11,6 +11,13 @@
 // With several workgroups resident per CU one item's prologue also runs under other items' streams, which a
 // separate prologue kernel cannot do.
 #pragma once
+#ifndef IPP_SF_LMASK
+// 1: adaptive mask of the step's window built in phase A (one pass over mean / diag of the window in front of the stream,
+// their updates as no-return atomics); 0: per tile, from the tile's mean / diag loaded under its stream and written back with
+// plain stores.  With the two-dimensional windows a tile streams ~30 rows instead of ~80 and the pass in phase A is the
+// larger cost: 17.6 -> 18.0 M env-steps/s with 0 (and no second read of mean / diag)
+#define IPP_SF_LMASK 0
+#endif
 #include "ipp_common.h"
 #include "k_gain_factor.h"
 #include "k_prepare.h"
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
     const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.win_tiles, v.win_tiles * kWave);
+                          kStepThreads / kWave, v.win_tiles, IPP_SF_LMASK ? v.win_tiles * kWave : 0);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
@@ -61,11 +68,11 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
         const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
         const cellv* diag_v = reinterpret_cast<const cellv*>(v.diag + (size_t)hh.env * v.Npad);
         const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
-        constexpr int kMaskPerThread = 4;  // groups in flight per thread and pass
+        constexpr int kMaskPerThread = IPP_SF_LMASK ? 4 : 0;  // groups in flight per thread and pass
         // only the tiles this step touches: [t_lo, t_hi] (the span of the appended columns)
         const int q_lo = hh.t_lo * kWave, q_hi = (hh.t_hi + 1) * kWave;  // groups of VEC cells
-        for (int q0 = q_lo + tid; q0 < q_hi; q0 += kMaskPerThread * kStepThreads) {
-            cellv mu[kMaskPerThread], dg[kMaskPerThread];
+        for (int q0 = q_lo + tid; IPP_SF_LMASK && q0 < q_hi; q0 += kMaskPerThread * kStepThreads) {
+            cellv mu[kMaskPerThread + 1], dg[kMaskPerThread + 1];
 #pragma unroll
             for (int u = 0; u < kMaskPerThread; ++u) {
                 const int q = q0 + u * kStepThreads;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, true, false, true, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
+    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, IPP_SF_LMASK != 0, false, true, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
                                                                 nullptr, nullptr, &ar);
 }
 
