@@ -81,39 +81,6 @@ __device__ __forceinline__ int tree_chain(const View& v, const TreeView& tv, con
     return n_cols;
 }
 
-// Phase-A work of a tree step on the tiles [t_lo, t_hi] of its window: the adaptive-mask bits (root mean, diagonal of
-// the parent state through the chain) and the new node's diagonal on ITS span, which starts as a copy of the parent
-// state's (the tile epilogues subtract from it); then the prior table.  Round 1 copied the whole N-cell diagonal per new
-// node: 320 KB of traffic per item at 200x200, as much as the step streamed.
-template <int MC, int VEC>
-__device__ __forceinline__ void tree_mid(const View& v, const ItemHdr& hh, const DiagChain& dc, const GainLds<MC>& lds, unsigned flags,
-                                         bool expand, float* new_diag0, int lut_rows) {
-    const int tid = threadIdx.x, T = blockDim.x;
-    typedef float cellv __attribute__((ext_vector_type(VEC)));
-    const cellv* mean_v = reinterpret_cast<const cellv*>(v.mean + (size_t)hh.env * v.Npad);
-    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
-    float* new_diag_sh = expand ? new_diag0 - (size_t)hh.t_lo * v.tile_cells : nullptr;
-    for (int q = hh.t_lo * kWave + tid; q < (hh.t_hi + 1) * kWave; q += T) {
-        unsigned bits = (1u << VEC) - 1u;
-        if (adaptive || expand) {
-            const cellv dg = reinterpret_cast<const cellv*>(dc.source(q / kWave))[q];  // (kWave groups of VEC cells per tile)
-            if (expand) reinterpret_cast<cellv*>(new_diag_sh)[q] = dg;
-            if (adaptive) {
-                const cellv mu = mean_v[q];
-                bits = 0;
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) bits |= (((double)mu[c] + v.kf * (double)dg[c] >= v.thr) ? 1u : 0u) << c;
-            }
-        }
-        lds.mask4[q - hh.t_lo * kWave] = (unsigned char)bits;
-    }
-    const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
-    for (int i = tid; i < lut_rows * v.W; i += T) {
-        const int dr = i / v.W, dc2 = i - dr * v.W;
-        lds.lut[i] = matern_f(dr, dc2, s3, hh.sv);
-    }
-}
-
 template <int MC, int VEC>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids,
@@ -123,7 +90,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tr[];
     const GainLds<MC> lds(smem_tr, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.win_tiles, v.win_tiles * kWave);
+                          kStepThreads / kWave, v.win_tiles, 0);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
@@ -142,11 +109,17 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     float* new_diag0 = expand ? tv.node_diag + (size_t)new_id * tv.win_cells : nullptr;
     int* new_meta = expand ? tv.node_meta + 4 * new_id : nullptr;
 
-    // ---- phase A; under the footprint-dependent loads: tables, mask bits and the new node's diagonal (tree_mid)
+    // ---- phase A; under the footprint-dependent loads: block tables and the prior table
     auto mid = [&](const ItemHdr& hh) {
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
-        tree_mid<MC, VEC>(v, hh, dc, lds, flags, expand, new_diag0, lut_rows);
+        // (mask and the new node's diagonal per tile, from the parent state's diagonal read under the tile's stream, like
+        // k_tree_gain: the pass over the span in front of the stream was 9 of the 36 us of this prologue)
+        const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
+        for (int i = tid; i < lut_rows * v.W; i += kStepThreads) {
+            const int dr = i / v.W, dc2 = i - dr * v.W;
+            lds.lut[i] = matern_f(dr, dc2, s3, hh.sv);
+        }
     };
     ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true, decltype(mid), true>(
         v, item, root_ids, nullptr, action, prev_action, nullptr, flags_eff, status_out, nullptr, nullptr, nullptr, lds.small,
@@ -185,8 +158,8 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     float* new_cols = expand ? new_cols0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     if (expand && tid == 0) { new_meta[2] = parent_id; new_meta[3] = root; }
-    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, true, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
-                                                         reward_out, &cc, new_cols, new_diag, new_meta);
+    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, false, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
+                                                          reward_out, &cc, new_cols, new_diag, new_meta, nullptr, &dc);
 }
 
 // ---- the same step as two launches (configs[4]-sized waves): in k_tree_step about 40 % of a workgroup's life is the
