@@ -306,13 +306,16 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     };
     float sacc0[UN];
     const bool gather_on = (MODE == IPP_FACTOR) && gi < m && r > 0;
-    if (gather_on) {
-        // rows past the rank clamp to r - 1: their span was read for an unused column, the value is discarded below
-        gather_rows(tid / MP, sp_pre, sacc0);
+    // rows past the rank clamp to r - 1: their span was read for an unused column, the value is discarded below.
+    // The pass stays in flight across mid_work (block tables and prior table: arithmetic on the header): its 1.5 us run
+    // under the 4 us round trip.  (While mid_work also loaded the mean / diag of the window for the mask this cost 48 live
+    // registers and 12 spills and was 4 % slower; the mask is per tile now.)
+    {
+        float l0[UN][4];
+        if (gather_on) gather_issue(tid / MP, sp_pre, l0);
+        mid_work(h);
+        if (gather_on) gather_sum(l0, sacc0);
     }
-    // (Keeping the pass's requests in flight across mid_work, so that its mask loads ride in the same memory round trip,
-    // measured 4 % SLOWER in the fused kernel: 48 more live registers across the table builds, 12 spills.)
-    mid_work(h);
 
     // ------------------------------------------------------------------ footprint tables (no divisions later)
     for (int fi = tid; fi < f; fi += kPrepThreads) {
