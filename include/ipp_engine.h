@@ -76,8 +76,9 @@ typedef struct ipp_config {
     int32_t max_measurements; /* compile-time cap on m: 9 (default config) or 25 */
     int32_t tile_threads;     /* 0 = auto; threads per streaming workgroup (multiple of 64, <= 640) */
     int32_t window_rows;      /* IPP_FACTOR: 0 = exact full columns; R > 0 = a new column of U is kept only on the
-                                 grid rows within R of its footprint (|Wc| < 3e-8 beyond 12 rows for the example
-                                 prior); streamed bytes shrink accordingly and are counted as such.
+                                 cells within R grid rows AND R grid columns of its footprint, zero elsewhere
+                                 (|Wc| < 3e-8 beyond 12 cells for the example prior); stored columns that
+                                 cannot reach the current footprint are not streamed; bytes are counted as moved.
                                  The dropped entries scale like exp(-sqrt(3) R resolution / length_scale): choose R
                                  from the prior (12 = 13 length scales for the example config), 0 when in doubt,
                                  or ask ipp_min_window_rows.  ipp_engine_create refuses an R that drops prior
