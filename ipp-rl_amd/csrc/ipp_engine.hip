@@ -81,6 +81,8 @@ struct Engine {
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
+    bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
+    bool rect_commit = false;  // ... used for committed steps too (else for predict-only calls only)
     int tree_split_min = 0;   // ipp_tree_step: launches of at least this many items run k_tree_prepare + k_tree_gain (0: never)
     int tree_T = kStepThreads;  // workgroup size of k_tree_gain
     size_t tree_step_lds = 0;   // k_tree_step: the fused kernel's LDS + the column-pointer table
@@ -347,7 +349,11 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
         return;
     }
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
-        timed_launch(e, 0, k_step_factor<MC, VEC>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev, noise,
+        if (MC == 9 && VEC == 2 && e->rect_ok && (e->rect_commit || (flags & IPP_PREDICT_ONLY)))
+            timed_launch(e, 0, k_step_factor<MC, VEC, (MC == 9 && VEC == 2)>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev, noise,
+                     flags, e->lut_rows, status, reward, ar);
+        else
+            timed_launch(e, 0, k_step_factor<MC, VEC>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev, noise,
                      flags, e->lut_rows, status, reward, ar);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
@@ -364,7 +370,10 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
         if (v.mode == IPP_FACTOR && v.window_rows > 0 && v.T == kWave)
             timed_launch(e, 0, k_gain_wave<MC, VEC>, dim3(n), dim3(kWave), e->gain_lds, s, v, v.q, n, flags, reward);
         else if (v.mode == IPP_FACTOR && v.window_rows > 0)
-            timed_launch(e, 0, k_gain_factor<MC, VEC>, dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_rows, reward);
+            if (MC == 9 && VEC == 2 && e->rect_ok && (e->rect_commit || (flags & IPP_PREDICT_ONLY)))
+                timed_launch(e, 0, k_gain_factor<MC, VEC, (MC == 9 && VEC == 2)>, dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_rows, reward);
+            else
+                timed_launch(e, 0, k_gain_factor<MC, VEC>, dim3(n), dim3(v.T), e->gain_lds, s, v, v.q, n, flags, e->lut_rows, reward);
         else if (v.mode == IPP_FACTOR)
             timed_launch(e, 0, k_gain<MC, VEC, IPP_FACTOR>, dim3(grid), dim3(v.T), e->gain_lds, s, v, n, flags, e->q_chunk, e->lut_cap, reward);
         else
@@ -605,6 +614,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     // one-wave-per-item kernel of tile_threads = 64 and the pipelined kernel do not: off for those engines)
     v.clip_cols = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0 && L.T != 64 && cfg->x_dim > 2 * cfg->window_rows + 13) ? 1 : 0;
     if (const char* cl = getenv("IPP_CLIP_COLS")) v.clip_cols = v.clip_cols && atoi(cl) != 0;  // A/B experiments
+    // rectangle tiles for committed steps where a rectangle (<= 2 R + 5 + 2 cells of alignment wide) is at most 0.4 grid rows
+    e->rect_ok = v.clip_cols && L.MC == 9 && L.VEC == 2 && cfg->x_dim % 2 == 0;
+    e->rect_commit = e->rect_ok && 5 * (2 * cfg->window_rows + 7) <= 2 * cfg->x_dim;
+    if (const char* rc = getenv("IPP_RECT")) { e->rect_commit = e->rect_ok && atoi(rc) == 2; e->rect_ok = e->rect_ok && atoi(rc) != 0; }  // A/B: 0 off, 1 predict-only, 2 always
     v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;
@@ -701,6 +714,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     if (e->pipe) {
         const void* kfn = (v.meas_cap == 9) ? (v.vec == 2 ? reinterpret_cast<const void*>(&k_step_pipe<9, 2>) : reinterpret_cast<const void*>(&k_step_pipe<9, 4>))
                                             : reinterpret_cast<const void*>(&k_step_pipe<25, 2>);

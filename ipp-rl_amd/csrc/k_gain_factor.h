@@ -156,7 +156,8 @@ struct DiagChain {
 // RESET (ipp_step_autoreset): an item with ar->src[item] >= 0 resets its env once its step is complete: every wave
 // waits for its own stores / atomics before it counts itself done, the last wave then rewrites the env's planes.
 // NW > 0: that many waves of the workgroup run the tile loop of this item (k_step_pipe: the consumer waves), else all.
-template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false, bool RESET = false, int NW = 0>
+template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false, bool RESET = false, int NW = 0,
+          bool RECT = false>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,
                                            const GainLds<MC>& lds, const float* __restrict__ qrows,
                                            float* __restrict__ reward_out, const ChainCols* cc = nullptr,
@@ -196,16 +197,61 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     // hence an exactly zero Q row, and is dropped from the stream altogether by the callers (mark_inactive_columns).
     const int clip_lo = v.clip_cols ? max(0, h.xl - v.window_rows) : 0;
     const int clip_hi = v.clip_cols ? min(v.W - 1, h.xr + v.window_rows) : v.W - 1;
+    // RECTANGLE TILES (env steps on clipped windows): the work units are not the 64 VEC-cell tiles of the row band but
+    // groups of 64 VEC cells of the rectangle rows [yu - R, yd + R] x columns [rect_lo, rect_hi] (the column range widened
+    // to whole VEC-cell groups), row by row: a lane's VEC cells are still adjacent and aligned, a wave's request covers
+    // ~5 grid rows of ~28 cells.  Half as many (tile, stored row) pairs at 50x50, a quarter at 100x100 -- that count, not
+    // the bytes, is what the stream costs.  The cells of the band outside the rectangle only get the zeros of the new
+    // columns, from a store-only pass over the band tiles (zero_fill below).  Storage and spans stay in band tiles.
+    // Used where it wins (ipp_engine.hip): rectangles at most 0.4 grid rows wide (100x100: 32768 envs 18.6 -> 21.0 M env-steps/s), and steps
+    // that store nothing (predict-only calls at 50x50: 21.6 -> 23.2 M).  Committed steps at 50x50 lose what the halved
+    // pairs save to the store-only pass and the per-lane addressing (headline +-0, 32768 envs 25.1 -> 23.4 M): band tiles.
+    // A compile-time variant (RECT; the host picks the kernel): with both tilings in one kernel the band path lost 6 %.
+    static_assert(!RECT || (!LMASK && !CHAIN), "rectangle tiles: per-tile mask, env steps only");
+    constexpr bool rect = RECT;  // (the host guarantees View::clip_cols and W % VEC == 0)
+    const int rect_lo = clip_lo & ~(VEC - 1), rect_hi = min(v.W - 1, clip_hi | (VEC - 1));
+    const int rect_row0 = max(0, h.yu - v.window_rows), rect_row1 = min(v.H - 1, h.yd + v.window_rows);
+    const int rect_gpr = (rect_hi - rect_lo + 1) / VEC;                       // groups of VEC cells per rectangle row
+    const int rect_groups = (rect_row1 - rect_row0 + 1) * rect_gpr;
+    const int n_rect_tiles = rect ? (rect_groups + kWave - 1) / kWave : 0;
+    const int n_band_tiles = h.t_hi - h.t_lo + 1;
+    constexpr int kTileShift = (kWaveTile == 64) ? 6 : (kWaveTile == 128) ? 7 : 8;
+    static_assert(kWaveTile == (1 << kTileShift), "tile size must be a power of two");
 
     // tiles are handed out dynamically (LDS counter): a wave that finishes a short tile takes the next one, in address
     // order.  (Handing them out from the footprint's tile outwards -- longest first -- measured 3-9 % SLOWER on every
     // config: neighbouring tiles streamed at the same time share DRAM pages of the same stored rows.)
     for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = h.t_lo + atomicAdd(next_tile, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile > h.t_hi) break;
-        const int cell0 = tile * kWaveTile + VEC * lane;
+        int tidx = 0;
+        if (lane == 0) tidx = atomicAdd(next_tile, 1);
+        tidx = __builtin_amdgcn_readfirstlane(tidx);
+        if (tidx >= n_rect_tiles + n_band_tiles) break;
+        if (rect && tidx >= n_rect_tiles) {
+            // ---- zero_fill: the cells of band tile (tidx - n_rect_tiles) outside the rectangle get zeros in the m new columns
+            const int zt = h.t_lo + tidx - n_rect_tiles;
+            const int zc = zt * kWaveTile + VEC * lane;
+            const int zrow = min(zc, v.N - 1) / v.W, zcol = min(zc, v.N - 1) - zrow * v.W;
+            const bool outside = zc < v.N && (zrow < rect_row0 || zrow > rect_row1 || zcol < rect_lo || zcol > rect_hi);  // (whole groups: W % VEC == 0)
+            if (h.commit && outside) {
+                float zv[VEC];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) zv[c] = 0.f;
+                for (int j = 0; j < m; ++j) store_stream<VEC>(cov_dst + (size_t)(r + j) * npad + zc, zv);
+            }
+            const int zcells = __popcll(__ballot(outside)) * VEC;
+            units += (unsigned long long)(h.commit ? m : 0) * zcells;
+            continue;
+        }
+        // band tile of this work unit (rect: of every lane's cells, and the range [bt_min, bt_max] the unit touches)
+        const int g_lane = min(tidx * kWave + lane, rect_groups - 1);  // (rect only; lanes past the last group repeat it and are masked)
+        const bool lane_valid = !rect || tidx * kWave + lane < rect_groups;
+        int rrow = 0, rcol = 0;
+        if (rect) { rrow = g_lane / rect_gpr; rcol = rect_lo + VEC * (g_lane - rrow * rect_gpr); rrow += rect_row0; }
+        const int tile = rect ? 0 : h.t_lo + tidx;
+        const int cell0 = rect ? rrow * v.W + rcol : tile * kWaveTile + VEC * lane;
+        const int bt_lane = cell0 >> kTileShift;
+        const int bt_min = rect ? __builtin_amdgcn_readfirstlane(bt_lane) : tile;
+        const int bt_max = rect ? __builtin_amdgcn_readlane(bt_lane, kWave - 1) : tile;
         // mean / diag of the tile: requested now, parked in LDS after the base term (the loads have landed by then),
         // read back in the epilogue.  Kept in registers across the stream loop they were spilled to scratch, which
         // cost 10 % of the kernel (A/B with the loads ablated).
@@ -217,13 +263,17 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
         int nact = 0;
+        bool partial = false;  // (rect: some active column covers only a part of the unit: its loads are predicated per lane)
         for (int k0 = 0; k0 < ((IPP_GF_ABLATE & 8) ? 0 : r); k0 += kWave) {
             const int k = k0 + lane;
             bool on = false;
+            bool part_k = false;
             if (k < r) {
                 const int sp = span_s[k];
-                on = tile >= (sp & 0xffff) && tile <= (sp >> 16);
+                on = bt_max >= (sp & 0xffff) && bt_min <= (sp >> 16);
+                part_k = on && !(bt_min >= (sp & 0xffff) && bt_max <= (sp >> 16));  // stored on a part of this unit's cells only
             }
+            partial |= __ballot(part_k) != 0ull;
             const unsigned long long mask = __ballot(on);
             if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)k;
             nact += __popcll(mask);
@@ -243,10 +293,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 const int cell = min(cell0 + c, v.N - 1);
-                crow[c] = cell / v.W;
-                ccol[c] = cell - crow[c] * v.W;
+                crow[c] = rect ? rrow : cell / v.W;
+                ccol[c] = rect ? rcol + c : cell - crow[c] * v.W;
             }
-            if (v.clip_cols) {
+            if (rect) {
+                inmask = lane_valid ? (1u << VEC) - 1u : 0u;
+            } else if (v.clip_cols) {
                 inmask = 0u;
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) inmask |= ((ccol[c] >= clip_lo && ccol[c] <= clip_hi) ? 1u : 0u) << c;
@@ -254,7 +306,8 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
             // the table covers |drow| < lut_rows: decided per tile (wave-uniform) from the farthest tile / footprint rows
-            const int trow0 = (tile * kWaveTile) / v.W, trow1 = min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
+            const int trow0 = rect ? __builtin_amdgcn_readfirstlane(rrow) : (tile * kWaveTile) / v.W;
+            const int trow1 = rect ? __builtin_amdgcn_readlane(rrow, kWave - 1) : min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
             const int dmax = max(max(abs(trow0 - h.yu), abs(trow0 - h.yd)), max(abs(trow1 - h.yu), abs(trow1 - h.yd)));
             const bool tile_lut = dmax < lut_rows;
             // rf = 1 (altitude <= rf_altitude): every measurement block is one cell, the other three table entries
@@ -352,7 +405,15 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     // instructions per column and spilled SGPRs: the tile loop was issue-bound, not memory-bound)
                     rowk[i] = CHAIN ? uni_ptr(lds.rowp[ku]) : cov_src + (size_t)ku * npad;
                 }
-                if (inmask) {  // (one exec-mask region for the whole group: clipped lanes request nothing)
+                if (rect && partial) {  // (units at the edge of a stored column's span: per column, only the lanes it is stored on)
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) {
+                        const int sp = span_s[kk[i] < r ? kk[i] : safe_k];
+                        u[i] = (rowv)(0.f);
+                        if (inmask && bt_lane >= (sp & 0xffff) && bt_lane <= (sp >> 16))
+                            u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk[i] + cell0));
+                    }
+                } else if (inmask) {  // (one exec-mask region for the whole group: clipped lanes request nothing)
 #pragma unroll
                     for (int i = 0; i < KP; ++i) u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk[i] + cell0));
                 } else {
@@ -439,13 +500,13 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             if (valid && in_mask) part += (double)w2;
         }
         part = wave_sum(part);
-        if (lane == 0) lds.tile_red[tile - h.t_lo] = part;
-        const int valid_cells = max(0, min(kWaveTile, v.N - tile * kWaveTile));
+        if (lane == 0) lds.tile_red[tidx] = part;
+        const int valid_cells = rect ? __popcll(__ballot(lane_valid)) * VEC : max(0, min(kWaveTile, v.N - tile * kWaveTile));
         // 4 N (r + m) + 16 N per committed step = (stored rows + m new rows + mean and diag read and
         // written) floats per touched cell.  LMASK: phase A also read mean / diag of this tile for the mask, which the
         // atomics then read again: those 2 extra floats per cell are traffic, not algorithm -- counted separately
         int in_cells = valid_cells;
-        if (v.clip_cols) {  // stored rows, mean and diag are touched on the cells inside the column range only
+        if (v.clip_cols && !rect) {  // stored rows, mean and diag are touched on the cells inside the column range only
             in_cells = 0;
 #pragma unroll
             for (int c = 0; c < VEC; ++c) in_cells += __popcll(__ballot(((inmask >> c) & 1u) != 0u && (cell0 + c) < v.N));
@@ -480,7 +541,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                         if (!(flags & IPP_COV_ONLY)) unsafeAtomicAdd(mu + kWave * c + lane, m_t);
                     }
                 }
-            } else {
+            } else if (lane_valid) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];
                 store_vec<VEC>((CHAIN ? diag_rw : v.diag + (size_t)h.dst * npad) + cell0, outv);
@@ -492,7 +553,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
 #pragma unroll
             for (int j = 0; j < MC; ++j)
-                if (j < m && !((IPP_GF_ABLATE & 32) && acc[0][0] != 12345.f)) {
+                if (j < m && lane_valid && !((IPP_GF_ABLATE & 32) && acc[0][0] != 12345.f)) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
                     store_stream<VEC>((CHAIN ? new_cols + (size_t)j * cc->nstride : cov_dst + (size_t)(r + j) * npad) + cell0, outv);
@@ -528,7 +589,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     if (lane == 0) {
         IPP_MARK(item, 2);
         double tot = 0.0;
-        for (int t = 0; t <= h.t_hi - h.t_lo; ++t) tot += lds.tile_red[t];
+        for (int t = 0; t < (rect ? n_rect_tiles : n_band_tiles); ++t) tot += lds.tile_red[t];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
         if (commit_item && !CHAIN) v.rank[h.dst] = r + m;
         if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); }
@@ -542,7 +603,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 
 // Stand-alone gain kernel (after k_prepare): stages L^-1 | y, the spans and the prior table, then gain_tiles.
 // q_all == v.q, passed separately so that it is a read-only kernel argument (scalar loads of the Q rows).
-template <int MC, int VEC>
+template <int MC, int VEC, bool RECT = false>
 __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, const float* __restrict__ q_all, int n_items,
                                                                    unsigned flags, int lut_rows,
                                                                    float* __restrict__ reward_out) {
@@ -576,7 +637,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
         }
     }
     __syncthreads();
-    gain_tiles<MC, VEC, gf_pipe<MC, VEC>(), false, false>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
+    gain_tiles<MC, VEC, gf_pipe<MC, VEC>(), false, false, false, false, false, 0, RECT>(v, h, item, flags, lut_rows, lds, blk + LQ, reward_out);
 }
 
 }  // namespace ipp

@@ -42,7 +42,7 @@ __host__ __device__ constexpr int step_small_floats() {
 // workgroup, no other workgroup touches this item's block, blocks are 64-byte aligned (no scalar-cache line shared
 // between items) and the scalar cache is invalidated at every kernel launch, so it cannot hold lines of a previous
 // step.
-template <int MC, int VEC>
+template <int MC, int VEC, bool RECT = false>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     View v, const int* __restrict__ env_ids, int n_items,
     const double* __restrict__ action, const double* __restrict__ prev_action, const float* __restrict__ meas_noise,
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     }
 
     // ---- phase B
-    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, IPP_SF_LMASK != 0, false, true, true>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
+    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, IPP_SF_LMASK != 0, false, true, true, 0, RECT && !IPP_SF_LMASK>(v, h, item, flags, lut_rows, lds, qrows_w, reward_out, nullptr, nullptr,
                                                                 nullptr, nullptr, &ar);
 }
 
