@@ -83,6 +83,7 @@ struct Engine {
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
     bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
     bool rect_commit = false;  // ... used for committed steps too (else for predict-only calls only)
+    bool rect_tree = false;    // tree steps on rectangle tiles (same width rule; either tile size)
     int tree_split_min = 0;   // ipp_tree_step: launches of at least this many items run k_tree_prepare + k_tree_gain (0: never)
     int tree_T = kStepThreads;  // workgroup size of k_tree_gain
     size_t tree_step_lds = 0;   // k_tree_step: the fused kernel's LDS + the column-pointer table
@@ -617,6 +618,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     // rectangle tiles for committed steps where a rectangle (<= 2 R + 5 + 2 cells of alignment wide) is at most 0.4 grid rows
     e->rect_ok = v.clip_cols && L.MC == 9 && L.VEC == 2 && cfg->x_dim % 2 == 0;
     e->rect_commit = e->rect_ok && 5 * (2 * cfg->window_rows + 7) <= 2 * cfg->x_dim;
+    e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && 5 * (2 * cfg->window_rows + 5 + 2 * (L.VEC - 1)) <= 2 * cfg->x_dim;
+    if (const char* rt = getenv("IPP_RECT_TREE")) e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && atoi(rt) != 0;  // A/B experiments
     if (const char* rc = getenv("IPP_RECT")) { e->rect_commit = e->rect_ok && atoi(rc) == 2; e->rect_ok = e->rect_ok && atoi(rc) != 0; }  // A/B: 0 off, 1 predict-only, 2 always
     v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
@@ -731,6 +734,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->tree_step_lds = (e->gain_lds + (size_t)v.rank_cap * 8 + 15) & ~(size_t)15;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     if (e->fused && e->tv.node_cap > 0 && v.meas_cap == 9) {
         // Split tree steps: worth it once the launch fills the device several times over (below that the second launch
         // and the scratch round trip of L^-1 | Q cost more than the occupancy gains); IPP_TREE_SPLIT=<min items> / 0
@@ -741,6 +746,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_prepare<9>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -1019,18 +1026,18 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     if (v.meas_cap == 9 && e->tree_split_min > 0 && n >= e->tree_split_min) {
         timed_launch(e, 2, k_tree_prepare<9>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action,
                      prev_action, flags, status);
-        if (v.vec == 2)
-            timed_launch(e, 0, k_tree_gain<9, 2>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
-                         new_ids, n, flags, e->lut_rows, reward);
-        else
-            timed_launch(e, 0, k_tree_gain<9, 4>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
-                         new_ids, n, flags, e->lut_rows, reward);
-    } else if (v.meas_cap == 9 && v.vec == 2)
-        timed_launch(e, 0, k_tree_step<9, 2>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
-                     action, prev_action, flags, e->lut_rows, status, reward);
-    else if (v.meas_cap == 9)
-        timed_launch(e, 0, k_tree_step<9, 4>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
-                     action, prev_action, flags, e->lut_rows, status, reward);
+#define IPP_TREE_GAIN(V, R) timed_launch(e, 0, k_tree_gain<9, V, R>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, \
+                                         root_ids, path_ids, new_ids, n, flags, e->lut_rows, reward)
+        if (v.vec == 2) { if (e->rect_tree) IPP_TREE_GAIN(2, true); else IPP_TREE_GAIN(2, false); }
+        else            { if (e->rect_tree) IPP_TREE_GAIN(4, true); else IPP_TREE_GAIN(4, false); }
+#undef IPP_TREE_GAIN
+    } else if (v.meas_cap == 9) {
+#define IPP_TREE_STEP(V, R) timed_launch(e, 0, k_tree_step<9, V, R>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, \
+                                         new_ids, n, action, prev_action, flags, e->lut_rows, status, reward)
+        if (v.vec == 2) { if (e->rect_tree) IPP_TREE_STEP(2, true); else IPP_TREE_STEP(2, false); }
+        else            { if (e->rect_tree) IPP_TREE_STEP(4, true); else IPP_TREE_STEP(4, false); }
+#undef IPP_TREE_STEP
+    }
     else
         timed_launch(e, 0, k_tree_step<25, 2>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
                      action, prev_action, flags, e->lut_rows, status, reward);

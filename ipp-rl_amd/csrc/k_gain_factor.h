@@ -207,7 +207,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     // that store nothing (predict-only calls at 50x50: 21.6 -> 23.2 M).  Committed steps at 50x50 lose what the halved
     // pairs save to the store-only pass and the per-lane addressing (headline +-0, 32768 envs 25.1 -> 23.4 M): band tiles.
     // A compile-time variant (RECT; the host picks the kernel): with both tilings in one kernel the band path lost 6 %.
-    static_assert(!RECT || (!LMASK && !CHAIN), "rectangle tiles: per-tile mask, env steps only");
+    static_assert(!RECT || !LMASK, "rectangle tiles need the per-tile mask");
     constexpr bool rect = RECT;  // (the host guarantees View::clip_cols and W % VEC == 0)
     const int rect_lo = clip_lo & ~(VEC - 1), rect_hi = min(v.W - 1, clip_hi | (VEC - 1));
     const int rect_row0 = max(0, h.yu - v.window_rows), rect_row1 = min(v.H - 1, h.yd + v.window_rows);
@@ -236,7 +236,13 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 float zv[VEC];
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) zv[c] = 0.f;
-                for (int j = 0; j < m; ++j) store_stream<VEC>(cov_dst + (size_t)(r + j) * npad + zc, zv);
+                for (int j = 0; j < m; ++j)
+                    store_stream<VEC>((CHAIN ? new_cols + (size_t)j * cc->nstride : cov_dst + (size_t)(r + j) * npad) + zc, zv);
+                if (CHAIN) {  // the new node's diagonal outside the rectangle is the parent state's
+                    float dv[VEC];
+                    load_vec<VEC>(dch->source(zt) + zc, dv);
+                    store_vec<VEC>(diag_rw + zc, dv);
+                }
             }
             const int zcells = __popcll(__ballot(outside)) * VEC;
             units += (unsigned long long)(h.commit ? m : 0) * zcells;
@@ -258,7 +264,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         float md_in[2][VEC];
         if (!LMASK) {
             load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, md_in[0]);
-            load_vec<VEC>((CHAIN ? dch->source(tile) : v.diag + (size_t)h.env * npad) + cell0, md_in[1]);  // (CHAIN: the parent state's)
+            load_vec<VEC>((CHAIN ? dch->source(rect ? bt_lane : tile) : v.diag + (size_t)h.env * npad) + cell0, md_in[1]);  // (CHAIN: the parent state's)
         }
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)

@@ -81,7 +81,7 @@ __device__ __forceinline__ int tree_chain(const View& v, const TreeView& tv, con
     return n_cols;
 }
 
-template <int MC, int VEC>
+template <int MC, int VEC, bool RECT = false>
 __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids,
     const int* __restrict__ new_ids, int n_items, const double* __restrict__ action, const double* __restrict__ prev_action,
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     float* new_cols = expand ? new_cols0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     if (expand && tid == 0) { new_meta[2] = parent_id; new_meta[3] = root; }
-    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, false, true, true>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
+    gain_tiles<MC, VEC, sf_pipe<MC, VEC>(), true, false, true, true, false, 0, RECT>(v, h, item, flags_eff, lut_rows, lds, qrows_w,
                                                           reward_out, &cc, new_cols, new_diag, new_meta, nullptr, &dc);
 }
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_tree_prepar
     if (lane < MC) blk_out[MC * MC + lane] = ys[lane];
 }
 
-template <int MC, int VEC>
+template <int MC, int VEC, bool RECT = false>
 __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     View v, TreeView tv, const float* __restrict__ q_all, const int* __restrict__ root_ids, const int* __restrict__ path_ids,
     const int* __restrict__ new_ids, int n_items, unsigned flags, int lut_rows, float* __restrict__ reward_out) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     float* new_diag = expand ? new_diag0 - (size_t)h.t_lo * v.tile_cells : nullptr;
     // (mask and the new node's diagonal per tile, from the parent state's diagonal read under the tile's stream: no
     // phase-A pass over the span)
-    gain_tiles<MC, VEC, gf_pipe<MC, VEC>(), false, false, true>(v, h, item, flags_eff, lut_rows, lds, blk + LQ, reward_out, &cc, new_cols,
+    gain_tiles<MC, VEC, gf_pipe<MC, VEC>(), false, false, true, false, false, 0, RECT>(v, h, item, flags_eff, lut_rows, lds, blk + LQ, reward_out, &cc, new_cols,
                                                        new_diag, new_meta, nullptr, &dc);
 }
 
