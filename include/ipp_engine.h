@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 7
+#define IPP_ABI_VERSION 8
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -355,6 +355,15 @@ int ipp_observe(void* engine, const int32_t* env_ids, int32_t n, const double* a
 
 /* UAV limits of the flight-time cost (uav_specifications argument, planning/common/actions.py:8-41). */
 int ipp_set_uav(void* engine, double max_v, double max_a);
+
+/*
+ * Dispatch order of the items of the following ipp_step / ipp_step_autoreset launches of exactly n items: workgroup b
+ * takes item order[b] ([dev] int32[n], a permutation of 0..n-1 that stays alive until replaced; NULL = the default
+ * XCD-balanced order).  Results do not depend on it.  The batched driver sorts by descending steps since the env's reset
+ * (more stored columns = a longer item), so that a launch ends on its short items: no reference counterpart
+ * (scheduling only).
+ */
+int ipp_set_item_order(void* engine, const int32_t* order, int32_t n);
 
 /* Change the adaptive-mask parameters used by subsequent steps.  The reference passes them per call in
  * adaptive_info = {"mean", "value_threshold", "interval_factor"} (planning/common/optimization.py:22-25). */

@@ -116,6 +116,8 @@ struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL
     int mode, cap, rank_cap, max_batch;
     int window_rows, tile_cells;
+    const int* item_order;  // [n] dispatch order of the items of a launch (ipp_set_item_order), NULL: xcd_item
+    int item_order_n;
     int clip_cols;  // windowed factor state: new columns are zero on the grid COLUMNS farther than window_rows from the footprint too
     int win_tiles;  // windowed factor state: most tiles [t_lo, t_hi] one step can touch (n_tiles when not windowed)
     int meas_cap, fp_cap, q_stride, q_rows;
@@ -261,6 +263,12 @@ __device__ __forceinline__ bool decode_block(int b, int n_items, int parts, int&
     if (vb >= n_items) { item = 0; return false; }
     item = xcd_item(vb, n_items);
     return true;
+}
+// Item of workgroup b: the caller's dispatch order when one is set for this launch size (heaviest items first: workgroups are
+// dealt to the XCDs round-robin, so every XCD works through a descending list and the launch ends on the short items), else
+// the XCD-balanced default.
+__device__ __forceinline__ int launch_item(const View& v, int b, int n_items) {
+    return (v.item_order && v.item_order_n == n_items) ? v.item_order[b] : xcd_item(b, n_items);
 }
 inline int grid_for(int n_items, int parts) { return ((n_items + 7) / 8) * 8 * parts; }
 

@@ -410,10 +410,22 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_begin, 0));
     const int per = ((n + chunks - 1) / chunks + 7) / 8 * 8;
     int used = 0;
+    const bool ordered = e->v.item_order && e->v.item_order_n == n && e->v.mode == IPP_FACTOR && e->v.window_rows > 0 && e->v.T != kWave;  // (k_gain_wave keeps its own item map)
     for (int c = 0, off = 0; off < n; ++c, off += per) {
         const int nc = std::min(per, n - off);
         hipStream_t st = (c % 2 == 0) ? s : e->side;
         View v = e->v;
+        if (c > 0) HIP_TRY(hipStreamWaitEvent(st, e->ev_prep[c - 1], 0));
+        if (ordered) {
+            // a dispatch order is set for this launch size: chunk c takes positions [off, off + nc) of it -- any items, so the
+            // per-item arrays keep their global indexing (heaviest chunk first, the last chunk ends the step on the lightest)
+            v.item_order = e->v.item_order + off;
+            v.item_order_n = nc;
+            launch_chunk<MC, VEC>(e, v, env_ids, dst_ids, nc, action, prev, noise, flags, reward, status, st, e->ev_prep[c], ar);
+            used = c + 1;
+            continue;
+        }
+        v.item_order = nullptr;
         v.env_base = off;
         v.hdr += off;
         v.linv += (size_t)off * v.meas_cap * v.meas_cap;
@@ -422,7 +434,6 @@ int launch_step(Engine* e, const int32_t* env_ids, const int32_t* dst_ids, int n
         if (v.wc) v.wc += (size_t)off * v.meas_cap * v.Npad;
         v.partial += (size_t)off * v.n_tiles;
         v.dbg += (size_t)off * (2 * v.meas_cap * v.meas_cap + 2 * v.meas_cap);
-        if (c > 0) HIP_TRY(hipStreamWaitEvent(st, e->ev_prep[c - 1], 0));
         AutoReset arc = ar;
         if (arc.src) arc.src += off;
         launch_chunk<MC, VEC>(e, v, env_ids ? env_ids + off : nullptr, dst_ids ? dst_ids + off : nullptr, nc,
@@ -964,6 +975,15 @@ int ipp_set_uav(void* engine, double max_v, double max_a) {
     if (!(max_v > 0) || !(max_a > 0)) return fail(-1, "max_v and max_a must be positive");
     e->v.vmax = max_v;
     e->v.amax = max_a;
+    return 0;
+}
+
+int ipp_set_item_order(void* engine, const int32_t* order, int32_t n) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (order && (n <= 0 || n > e->v.max_batch)) return fail(-1, "n = %d outside [1, max_batch = %d]", n, e->v.max_batch);
+    e->v.item_order = order;
+    e->v.item_order_n = order ? n : 0;
     return 0;
 }
 

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
     const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles);
     if ((int)blockIdx.x >= n_items) return;
-    const int item = xcd_item(blockIdx.x, n_items);
+    const int item = launch_item(v, blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;
     __builtin_amdgcn_s_dcache_inv();  // (Q through the non-coherent scalar cache: nothing of an earlier launch may be served)
     const ItemHdr h = uniform_hdr(v.hdr[item]);

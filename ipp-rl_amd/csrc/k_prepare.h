@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_prepare(Vie
                                                           int* __restrict__ obs_m, int* __restrict__ obs_shape) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x >= n_items) return;
-    const int item = xcd_item(blockIdx.x, n_items);
+    const int item = launch_item(v, blockIdx.x, n_items);
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]: one block for the gain kernel
     float* big = reinterpret_cast<float*>(smem + ((prep_small_bytes<MC>() + 15) & ~(size_t)15));

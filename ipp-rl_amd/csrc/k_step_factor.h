@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
                           kStepThreads / kWave, v.win_tiles, IPP_SF_LMASK ? v.win_tiles * kWave : 0);
     if ((int)blockIdx.x >= n_items) return;
-    const int item = xcd_item(blockIdx.x, n_items);
+    const int item = launch_item(v, blockIdx.x, n_items);
     const int tid = threadIdx.x;
     if (tid == 0) IPP_MARK(item, 0);
 

@@ -386,6 +386,17 @@ class IPPEngine:
     def set_uav(self, max_v: float, max_a: float):
         _ffi.check(self._lib.ipp_set_uav(self._h, float(max_v), float(max_a)))
 
+    def set_item_order(self, order):
+        """Dispatch order of the items of the following step launches (device int32 permutation, kept alive by the caller's
+        reference here; None = default).  Scheduling only: results do not depend on it."""
+        if order is None:
+            self._order = None
+            _ffi.check(self._lib.ipp_set_item_order(self._h, None, 0))
+            return
+        o = self._dev(order, _torch().int32)
+        self._order = o
+        _ffi.check(self._lib.ipp_set_item_order(self._h, self._ptr(o), int(o.numel())))
+
     def set_adaptive(self, value_threshold: float, interval_factor: float):
         _ffi.check(self._lib.ipp_set_adaptive(self._h, float(value_threshold), float(interval_factor)))
 

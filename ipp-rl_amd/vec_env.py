@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import os
+
 import numpy as np
 
 from .engine import EngineConfig, IPPEngine
@@ -81,6 +83,13 @@ class VecIPPEnv:
             torch.zeros(B, dtype=torch.int64, device=dev)
         self.t = 0
         self.episode = np.zeros(B, dtype=np.int64)  # completed-episode counters (host side, never read by kernels)
+        # dispatch orders of the step launches, one per schedule phase (staggered runs): env e has done (t + phase_e) % T steps
+        # of its episode when step t starts; descending = longest items first (engine.set_item_order)
+        self._orders = None
+        if stagger and os.environ.get("IPP_ITEM_ORDER", "1") != "0":
+            ph = (np.arange(B, dtype=np.int64) + self.env_id_offset) % self.episode_steps
+            self._orders = [torch.as_tensor(np.argsort(-((t + ph) % self.episode_steps), kind="stable").astype(np.int32), device=dev)
+                            for t in range(self.episode_steps)]
         self._reset_ids_by_phase = None
         if stagger:
             ph = self.phase.cpu().numpy()
@@ -271,6 +280,9 @@ class VecIPPEnv:
             p, k, n = scheduled
             main.wait_event(self._staged_ready[k])
             fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
+        if self._orders is not None and env_ids is None:
+            # heaviest items first: an env's stored columns grow with the steps since its reset
+            self.engine.set_item_order(self._orders[self.t % self.episode_steps])
         self.engine.step(a, self.prev, env_ids=env_ids, meas_noise=nz, adaptive=self.adaptive,
                          use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status,
                          update_prev=env_ids is None, **(fused or {}))

@@ -80,6 +80,39 @@ def test_fused_kernel_two_runs_are_bit_identical():
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
+@pytest.mark.parametrize("B,tile_threads,chunks", [(4096, 0, "1"), (8192, 128, "2")])
+def test_dispatch_order_changes_nothing_but_the_schedule(B, tile_threads, chunks, monkeypatch):
+    """ipp_set_item_order (VecIPPEnv: heaviest envs first) vs the default XCD-balanced order vs a random permutation: rewards,
+    ranks and states bit-identical -- on the fused kernel and on the split path in 2 chunks (where a chunk is a slice of the
+    order, not a contiguous item range)."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    T, steps = 40, 48
+    monkeypatch.setenv("IPP_STEP_CHUNKS", chunks)  # read by ipp_engine_create
+    acts = [torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, ALTS)).cuda() for t in range(steps)]
+    runs = []
+    for mode in ("sorted", "default", "random"):
+        monkeypatch.setenv("IPP_ITEM_ORDER", "0" if mode == "default" else "1")
+        env = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=7, tile_threads=tile_threads)
+        assert (env._orders is None) == (mode == "default")
+        if mode == "random":
+            g = torch.Generator(device="cpu").manual_seed(3)
+            env._orders = [torch.randperm(B, generator=g).to(torch.int32).cuda() for _ in range(T)]
+        env.reset()
+        rewards = []
+        for t in range(steps):
+            r, st = env.step(acts[t])
+            rewards.append(r.clone())
+        assert int(st.abs().sum()) == 0
+        runs.append((torch.stack(rewards), env.engine.ranks().clone(), env.mean(B - 1).clone(), env.diag(B // 3).clone()))
+        del env
+    for other in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], other))
+
+
 # ---------------------------------------------------------------------------------------- window property test
 _PAIR = {}
 
