@@ -561,6 +561,9 @@ def main(argv=None):
                                                 "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
                                                 "cells of the step's window within window_rows of the footprint in BOTH directions; the cells of the "
                                                 "row band outside that column range only receive the m zeros of the new columns",
+                "note": "since the two-dimensional windows a step moves ~1/4 of the bytes it moved on row-band windows in ~2/3 of the time: "
+                        "the kernel is bound by latency (its prologue and the request groups per tile), not by HBM; traffic exceeds the "
+                        "algorithmic bytes because the 64-byte sectors of the row band are fetched whole (DESIGN.md sections 2, 5)",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],
