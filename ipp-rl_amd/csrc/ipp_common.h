@@ -82,9 +82,25 @@ __device__ __forceinline__ ItemHdr uniform_hdr(const ItemHdr& h) {
 // followed by the column blocks of the nodes on the path from the root (each node holds the <= MC columns its own
 // step appended, at stride Npad, plus their tile span).  Plain env steps read one slab and do not use this.
 constexpr int kTreeDepth = 6;  // nodes on a path (episode_horizon of the tree searches is <= 5)
+constexpr int kNodeMeta = 8;   // ints per node record (TreeView::node_meta)
+
+// RECTANGLE of a stored column (View::rect_meta): a column written on rectangle tiles holds values on the grid rows
+// [r0, r1] x columns [c0, c1] only (inclusive, the column bounds on whole VEC-cell groups) -- the other cells of its tile
+// span are NOT written (no zeros stored) and every reader masks them.  Packed r0 | r1 << 8 | c0 << 16 | c1 << 24
+// (grids of <= 256 x 256 cells); kRectFull = the whole tile span (columns written on band tiles).
+constexpr unsigned kRectFull = 0xff00ff00u;
+__host__ __device__ __forceinline__ unsigned rect_pack(int r0, int r1, int c0, int c1) {
+    return (unsigned)r0 | ((unsigned)r1 << 8) | ((unsigned)c0 << 16) | ((unsigned)c1 << 24);
+}
+__host__ __device__ __forceinline__ bool rect_has(unsigned rc, int row, int col) {
+    const int r0 = rc & 0xff, r1 = (rc >> 8) & 0xff, c0 = (rc >> 16) & 0xff, c1 = rc >> 24;
+    return row >= r0 && row <= r1 && col >= c0 && col <= c1;
+}
+
 struct ChainCols {
     const float* root;        // root slab: columns 0 .. r_root-1
     const int* root_spans;    // tile spans of the root's columns
+    const int* root_rects;    // their rectangles (View::colrect)
     int r_root, depth;
     // column block of path node j.  A node stores its columns on its own tile span only (stride nstride = win_tiles tiles
     // per column); the pointer is pre-shifted by -t_lo tiles so that it is indexed with the ABSOLUTE cell like the root's
@@ -92,6 +108,7 @@ struct ChainCols {
     const float* node[kTreeDepth];
     int off[kTreeDepth];            // index of its first column in the chained state
     int nspan[kTreeDepth];          // its tile span (lo | hi << 16)
+    unsigned nrect[kTreeDepth];     // its rectangle (rect_pack)
     size_t npad, nstride;
     __device__ __forceinline__ const float* row(int k) const {
         const float* b = root;
@@ -107,6 +124,13 @@ struct ChainCols {
 #pragma unroll
         for (int j = 0; j < kTreeDepth; ++j)
             if (j < depth && k >= off[j]) s = nspan[j];
+        return s;
+    }
+    __device__ __forceinline__ unsigned rect(int k) const {
+        unsigned s = (r_root > 0) ? (unsigned)root_rects[min(k, r_root - 1)] : kRectFull;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < depth && k >= off[j]) s = nrect[j];
         return s;
     }
 };
@@ -131,6 +155,8 @@ struct View {
     double* prior;   // [cap][2]  (sigma^2, l)
     int* rank;       // [cap]
     int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
+    int* colrect;    // factor: [cap][rank_cap]  rectangle of every column of U inside its tile span (rect_pack)
+    int rect_meta;   // 1: steps on rectangle tiles write no zeros outside the rectangle; readers mask with colrect
     // kCountSlots slots of 16 words (128 B apart): a workgroup adds its totals to slot (item % kCountSlots), word 0 =
     // streamed floats (SURVEY 8(d) count), word 8 = floats re-read for the mask.  One address for all workgroups cost
     // 5 % (one counter) / 19 % (two) of the fused step kernel: the waves' exits queued up behind same-address atomics.

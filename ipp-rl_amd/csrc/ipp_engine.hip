@@ -203,7 +203,7 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_gt = o; o += up(cap * np * 4);
     L.off_prior = o; o += up(cap * 2 * 8);
     L.off_rank = o; o += up(cap * 4);
-    L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(cap * (uint64_t)c.rank_cap * 4) : 0;
+    L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(2 * cap * (uint64_t)c.rank_cap * 4) : 0;  // tile spans, then rectangles
     L.off_cnt = o; o += up((uint64_t)kCountSlots * 128);
     L.off_tick = o; o += up((uint64_t)kTicketSlots * 4);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
@@ -239,7 +239,7 @@ int plan(const ipp_config& c, Layout& L) {
         const uint64_t nc = c.node_capacity, wc = (uint64_t)L.win_tiles * 64 * L.VEC;  // a node lives on its step's tile span
         L.off_tr_cov = o; o += up(nc * L.MC * wc * 4 + 4096);
         L.off_tr_diag = o; o += up(nc * wc * 4 + 4096);
-        L.off_tr_meta = o; o += up(nc * 4 * 4);
+        L.off_tr_meta = o; o += up(nc * kNodeMeta * 4);
         L.off_sc_ndiag = o; o += c.score_scratch ? up(np * 4) : 0;
     }
     L.total = o;
@@ -618,6 +618,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.prior = reinterpret_cast<double*>(base + L.off_prior);
     v.rank = reinterpret_cast<int*>(base + L.off_rank);
     v.colspan = reinterpret_cast<int*>(base + L.off_span);
+    v.colrect = v.colspan + (size_t)cfg->capacity * cfg->rank_cap;
     v.counters = reinterpret_cast<unsigned long long*>(base + L.off_cnt);
     v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
@@ -632,6 +633,15 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && 5 * (2 * cfg->window_rows + 5 + 2 * (L.VEC - 1)) <= 2 * cfg->x_dim;
     if (const char* rt = getenv("IPP_RECT_TREE")) e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && atoi(rt) != 0;  // A/B experiments
     if (const char* rc = getenv("IPP_RECT")) { e->rect_commit = e->rect_ok && atoi(rc) == 2; e->rect_ok = e->rect_ok && atoi(rc) != 0; }  // A/B: 0 off, 1 predict-only, 2 always
+    // Rectangle metadata (View::rect_meta, ipp_common.h): steps on rectangle tiles store the new columns on the rectangle
+    // only and record it per column; every reader of stored columns masks with it.  Without it the band cells outside the
+    // rectangle received zeros from a store-only pass: 75 % of the gain kernel's HBM writes at 100x100, more at 200x200.
+    v.rect_meta = (v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && cfg->x_dim <= 256 && cfg->y_dim <= 256 && (e->rect_ok || e->rect_tree)) ? 1 : 0;
+    if (const char* rm = getenv("IPP_RECT_META")) v.rect_meta = v.rect_meta && atoi(rm) != 0;  // A/B experiments
+    // Only the rectangle-tile variants of the streaming kernels mask (k_gain_factor.h), so with the metadata on every
+    // stream over columns that may carry a true rectangle runs on rectangle tiles: env steps where they exist (VEC = 2;
+    // else the env columns are written on band tiles and carry full rectangles), tree steps always.
+    if (v.rect_meta) { e->rect_commit = e->rect_ok; e->rect_tree = true; }
     v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;
@@ -698,6 +708,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
             // pipeline is producer-bound (0.357 vs 0.313 ms at 4096 items of 50x50); IPP_PIPE=1 opts in
             const char* pp = getenv("IPP_PIPE");
             e->pipe = e->pipe && pp && atoi(pp) != 0;
+            if (e->pipe) v.rect_meta = 0;  // (the pipelined kernel's consumers do not stage the rectangles)
         }
         if (v.T == kWave)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +

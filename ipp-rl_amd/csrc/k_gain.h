@@ -336,7 +336,10 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
             }
         if (tile == h.t_lo) {  // one workgroup per item publishes the new rank and the span of the new columns
             if (tid == 0) v.rank[h.dst] = h.rank + m;
-            if (tid < m) v.colspan[(size_t)h.dst * v.rank_cap + h.rank + tid] = h.t_lo | (h.t_hi << 16);
+            if (tid < m) {
+                v.colspan[(size_t)h.dst * v.rank_cap + h.rank + tid] = h.t_lo | (h.t_hi << 16);
+                v.colrect[(size_t)h.dst * v.rank_cap + h.rank + tid] = (int)kRectFull;
+            }
         }
     } else {
         float* wc = v.wc + (size_t)item * MC * v.Npad + cell0;

@@ -51,13 +51,13 @@ struct GainLds {
     static constexpr int QS = (MC + 3) & ~3;
     static constexpr int LQ = (MC * MC + MC + 3) & ~3;
     float* Ls; float* ys; float* work; float* lut; unsigned char* small; double* red; int* next_tile; int* done_waves;
-    int* solve_flag; int* span_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
+    int* solve_flag; int* span_s; unsigned* rect_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
     double* tile_red;  // [win_tiles] masked trace reduction of every touched tile (summed in tile order at the end)
     const float** rowp;  // [chain_rows] tree steps: pointer to every column of the chained state (ChainCols::row, evaluated once)
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
                                             int n_tiles, int mask_bytes = 0, int chain_rows = 0) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
-        b += (size_t)((rank_cap + 3) & ~3) * 4 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
+        b += (size_t)((rank_cap + 3) & ~3) * 8 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
         b = ((b + 15) & ~(size_t)15) + (size_t)mask_bytes;
         b = ((b + 15) & ~(size_t)15) + (size_t)n_tiles * 8 + (size_t)chain_rows * 8;
         return (b + 15) & ~(size_t)15;
@@ -78,7 +78,8 @@ struct GainLds {
         done_waves = next_tile + 1;
         solve_flag = reinterpret_cast<int*>(red + 14);  // fused kernel: 0 = L^-1 / y pending, 1 = ready, 2 = S not PD
         span_s = reinterpret_cast<int*>(red + 16);
-        fb_yx = span_s + ((rank_cap + 3) & ~3);            // [MC][4] footprint cell (row << 16 | col) of block b
+        rect_s = reinterpret_cast<unsigned*>(span_s + ((rank_cap + 3) & ~3));  // [rank_cap] rectangles of the stored columns (View::rect_meta)
+        fb_yx = span_s + 2 * ((rank_cap + 3) & ~3);        // [MC][4] footprint cell (row << 16 | col) of block b
         fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);   // [MC][4] weight of that cell (0 for padding)
         // [waves][2][64 lanes][4]: mean / diag of the wave's current tile, parked here across the stream loop
         // (typed pointer arithmetic only: an integer round trip would turn the LDS pointer into a flat one)
@@ -122,12 +123,21 @@ struct DiagChain {
     const float* root_diag;
     const float* node[kTreeDepth];  // pre-shifted by -t_lo tiles like ChainCols::node
     int nspan[kTreeDepth];
+    unsigned nrect[kTreeDepth];  // View::rect_meta: a node holds its diagonal on the rectangle of its step only
     int depth;
     __device__ __forceinline__ const float* source(int tile) const {
         const float* p = root_diag;
 #pragma unroll
         for (int j = 0; j < kTreeDepth; ++j)
             if (j < depth && tile >= (nspan[j] & 0xffff) && tile <= (nspan[j] >> 16)) p = node[j];  // deeper nodes override
+        return p;
+    }
+    // ... of the cell group at (row, col) on `tile` when the nodes' rectangles count (rectangle tiles with View::rect_meta)
+    __device__ __forceinline__ const float* source(int tile, int row, int col) const {
+        const float* p = root_diag;
+#pragma unroll
+        for (int j = 0; j < kTreeDepth; ++j)
+            if (j < depth && tile >= (nspan[j] & 0xffff) && tile <= (nspan[j] >> 16) && rect_has(nrect[j], row, col)) p = node[j];
         return p;
     }
 };
@@ -214,7 +224,14 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const int rect_gpr = (rect_hi - rect_lo + 1) / VEC;                       // groups of VEC cells per rectangle row
     const int rect_groups = (rect_row1 - rect_row0 + 1) * rect_gpr;
     const int n_rect_tiles = rect ? (rect_groups + kWave - 1) / kWave : 0;
-    const int n_band_tiles = h.t_hi - h.t_lo + 1;
+    // View::rect_meta: the appended columns are written on the rectangle only (no zeros stored outside it: their rectangle is
+    // recorded in View::colrect / the node record) and every stored column is read under its rectangle; a tree node's diagonal
+    // likewise lives on its rectangle only (DiagChain::source per cell group).  There is no store-only pass then.
+    // (Compiled into the rectangle-tile variants only: the host never runs a band-tile variant on columns that carry a true
+    // rectangle -- ipp_engine.hip, rect_meta rule -- and the extra live values cost the band variants a wave of occupancy.)
+    const bool rm = RECT && v.rect_meta != 0;
+    const unsigned* rect_s = lds.rect_s;
+    const int n_band_tiles = (rect && rm) ? 0 : h.t_hi - h.t_lo + 1;
     constexpr int kTileShift = (kWaveTile == 64) ? 6 : (kWaveTile == 128) ? 7 : 8;
     static_assert(kWaveTile == (1 << kTileShift), "tile size must be a power of two");
 
@@ -236,7 +253,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 float zv[VEC];
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) zv[c] = 0.f;
-                for (int j = 0; j < m; ++j)
+                for (int j = 0; j < (rm ? 0 : m); ++j)
                     store_stream<VEC>((CHAIN ? new_cols + (size_t)j * cc->nstride : cov_dst + (size_t)(r + j) * npad) + zc, zv);
                 if (CHAIN) {  // the new node's diagonal outside the rectangle is the parent state's
                     float dv[VEC];
@@ -245,7 +262,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 }
             }
             const int zcells = __popcll(__ballot(outside)) * VEC;
-            units += (unsigned long long)(h.commit ? m : 0) * zcells;
+            units += (unsigned long long)((h.commit && !rm) ? m : 0) * zcells;
             continue;
         }
         // band tile of this work unit (rect: of every lane's cells, and the range [bt_min, bt_max] the unit touches)
@@ -264,8 +281,17 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         float md_in[2][VEC];
         if (!LMASK) {
             load_vec<VEC>(v.mean + (size_t)h.env * npad + cell0, md_in[0]);
-            load_vec<VEC>((CHAIN ? dch->source(rect ? bt_lane : tile) : v.diag + (size_t)h.env * npad) + cell0, md_in[1]);  // (CHAIN: the parent state's)
+            load_vec<VEC>((CHAIN ? ((rect && v.rect_meta) ? dch->source(bt_lane, rrow, rcol) : dch->source(rect ? bt_lane : tile))
+                                 : v.diag + (size_t)h.env * npad) + cell0, md_in[1]);  // (CHAIN: the parent state's)
         }
+
+        // grid rows / columns of this unit (wave-uniform) and of this lane's VEC-cell group (rect_meta: W % VEC == 0, a group
+        // lies in one grid row)
+        const int urow0 = rect ? __builtin_amdgcn_readfirstlane(rrow) : (tile * kWaveTile) / v.W;
+        const int urow1 = rect ? __builtin_amdgcn_readlane(rrow, kWave - 1) : min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
+        const int ucol0 = rect ? (urow0 == urow1 ? __builtin_amdgcn_readfirstlane(rcol) : rect_lo) : 0;
+        const int ucol1 = rect ? (urow0 == urow1 ? __builtin_amdgcn_readlane(rcol, kWave - 1) + VEC - 1 : rect_hi) : v.W - 1;
+        int lrow = rrow, lcol = rcol;
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
         int nact = 0;
@@ -278,6 +304,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 const int sp = span_s[k];
                 on = bt_max >= (sp & 0xffff) && bt_min <= (sp >> 16);
                 part_k = on && !(bt_min >= (sp & 0xffff) && bt_max <= (sp >> 16));  // stored on a part of this unit's cells only
+                if (rm) {
+                    const unsigned rc = rect_s[k];
+                    const int r0 = rc & 0xff, r1 = (rc >> 8) & 0xff, c0 = (rc >> 16) & 0xff, c1 = rc >> 24;
+                    on = on && r1 >= urow0 && r0 <= urow1 && c1 >= ucol0 && c0 <= ucol1;
+                    part_k = on && (part_k || !(r0 <= urow0 && r1 >= urow1 && c0 <= ucol0 && c1 >= ucol1));
+                }
             }
             partial |= __ballot(part_k) != 0ull;
             const unsigned long long mask = __ballot(on);
@@ -312,8 +344,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
             // the table covers |drow| < lut_rows: decided per tile (wave-uniform) from the farthest tile / footprint rows
-            const int trow0 = rect ? __builtin_amdgcn_readfirstlane(rrow) : (tile * kWaveTile) / v.W;
-            const int trow1 = rect ? __builtin_amdgcn_readlane(rrow, kWave - 1) : min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
+            const int trow0 = urow0, trow1 = urow1;
             const int dmax = max(max(abs(trow0 - h.yu), abs(trow0 - h.yd)), max(abs(trow1 - h.yu), abs(trow1 - h.yd)));
             const bool tile_lut = dmax < lut_rows;
             // rf = 1 (altitude <= rf_altitude): every measurement block is one cell, the other three table entries
@@ -411,12 +442,14 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     // instructions per column and spilled SGPRs: the tile loop was issue-bound, not memory-bound)
                     rowk[i] = CHAIN ? uni_ptr(lds.rowp[ku]) : cov_src + (size_t)ku * npad;
                 }
-                if (rect && partial) {  // (units at the edge of a stored column's span: per column, only the lanes it is stored on)
+                if ((rect || rm) && partial) {  // (units at the edge of a stored column's span / rectangle: per column, only the lanes it is stored on)
 #pragma unroll
                     for (int i = 0; i < KP; ++i) {
-                        const int sp = span_s[kk[i] < r ? kk[i] : safe_k];
+                        const int kx = kk[i] < r ? kk[i] : safe_k;
+                        const int sp = uni(span_s[kx]);
+                        const unsigned rc = rm ? (unsigned)uni((int)rect_s[kx]) : kRectFull;
                         u[i] = (rowv)(0.f);
-                        if (inmask && bt_lane >= (sp & 0xffff) && bt_lane <= (sp >> 16))
+                        if (inmask && bt_lane >= (sp & 0xffff) && bt_lane <= (sp >> 16) && rect_has(rc, lrow, lcol))
                             u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk[i] + cell0));
                     }
                 } else if (inmask) {  // (one exec-mask region for the whole group: clipped lanes request nothing)
@@ -592,18 +625,22 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (PRE) dead = __hip_atomic_load(lds.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without tiles never looked)
     const bool commit_item = h.commit && !dead;
+    const unsigned new_rect = (rect && rm) ? rect_pack(rect_row0, rect_row1, rect_lo, rect_hi) : kRectFull;
     if (lane == 0) {
         IPP_MARK(item, 2);
         double tot = 0.0;
         for (int t = 0; t < (rect ? n_rect_tiles : n_band_tiles); ++t) tot += lds.tile_red[t];
         reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
         if (commit_item && !CHAIN) v.rank[h.dst] = r + m;
-        if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); }
+        if (commit_item && CHAIN) { node_meta[0] = m; node_meta[1] = h.t_lo | (h.t_hi << 16); node_meta[4] = (int)new_rect; }
         unsigned long long* slot = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
         if (cnt[0]) atomicAdd(slot, cnt[0]);
         if (cnt[1]) atomicAdd(slot + 8, cnt[1]);
     }
-    if (commit_item && !CHAIN && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+    if (commit_item && !CHAIN && lane < m) {
+        v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+        v.colrect[(size_t)h.dst * v.rank_cap + r + lane] = (int)new_rect;
+    }
     if (RESET && reset_k >= 0) wave_reset_env(v, *ar, h.dst, reset_k, lane);  // (after the rank store above, same lane 0)
 }
 
@@ -630,6 +667,8 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
+    if (v.rect_meta)
+        for (int k = tid; k < r; k += T) lds.rect_s[k] = (unsigned)v.colrect[(size_t)h.env * v.rank_cap + k];
     if (v.clip_cols) {
         __syncthreads();
         mark_inactive_columns(lds.span_s, blk + LQ, (MC + 3) & ~3, r, h.m, tid, T);

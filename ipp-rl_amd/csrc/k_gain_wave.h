@@ -249,7 +249,10 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
         if (h.commit) v.rank[h.dst] = r + m;
         if (units) atomicAdd(v.counters + (size_t)(item & (kCountSlots - 1)) * 16, units);
     }
-    if (h.commit && lane < m) v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+    if (h.commit && lane < m) {
+        v.colspan[(size_t)h.dst * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+        v.colrect[(size_t)h.dst * v.rank_cap + r + lane] = (int)kRectFull;  // (band tiles: the whole span is written)
+    }
 }
 
 }  // namespace ipp

@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256) void k_fork(View v, const int* __restrict__ sr
         }
         if (v.mode == IPP_FACTOR)
             for (int i = threadIdx.x; i < r; i += blockDim.x)
+            {
                 v.colspan[(size_t)d * v.rank_cap + i] = v.colspan[(size_t)s * v.rank_cap + i];
+                v.colrect[(size_t)d * v.rank_cap + i] = v.colrect[(size_t)s * v.rank_cap + i];
+            }
     }
 }
 // rank is written by a second tiny launch so that k_fork never reads a rank another block already replaced
@@ -232,6 +235,10 @@ __global__ __launch_bounds__(256) void k_read_cov_factor(View v, int env, float*
     for (int k = 0; k < r; ++k) {
         const int lo = span[k] & 0xffff, hi = span[k] >> 16;  // a column is zero outside its stored tiles
         if (ti < lo || ti > hi || tj < lo || tj > hi) continue;
+        if (v.rect_meta) {  // ... and outside its rectangle
+            const unsigned rc = (unsigned)v.colrect[(size_t)env * v.rank_cap + k];
+            if (!rect_has(rc, ri, ci) || !rect_has(rc, rj, cj)) continue;
+        }
         acc -= (double)U[(size_t)k * v.Npad + i] * (double)U[(size_t)k * v.Npad + j];
     }
     out[(size_t)i * v.N + j] = (float)acc;

@@ -130,11 +130,16 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     const double sv = v.prior[2 * envc + 0], ls = v.prior[2 * envc + 1];
     const float eps_ld = (meas_noise && tid < MC) ? meas_noise[(size_t)item * MC + tid] : 0.f;
     const int* __restrict__ span = v.colspan + (size_t)envc * v.rank_cap;
+    const int* __restrict__ rects = v.colrect + (size_t)envc * v.rank_cap;
     int sp_pre[UN];  // tile spans of this thread's first-pass rows (factor)
+    unsigned rc_pre[UN];  // ... and their rectangles (View::rect_meta)
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
         const int k = tid / MP + u * KS;
         sp_pre[u] = CHAIN ? cc->span(min(k, max(rank_chain - 1, 0))) : ((MODE == IPP_FACTOR && k < v.rank_cap) ? span[k] : 0);
+        rc_pre[u] = kRectFull;
+        if (MODE == IPP_FACTOR && v.rect_meta)
+            rc_pre[u] = CHAIN ? cc->rect(min(k, max(rank_chain - 1, 0))) : (k < v.rank_cap ? (unsigned)rects[k] : kRectFull);
     }
 
     // ------------------------------------------------------------------ header (every thread, fp64 like NumPy)
@@ -235,7 +240,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // ground-truth / mean requests issued in front of the gather (one more round trip).  Touching the spans here puts
     // that wait where it costs nothing.
 #pragma unroll
-    for (int u = 0; u < UN; ++u) asm volatile("" : : "v"(sp_pre[u]));
+    for (int u = 0; u < UN; ++u) { asm volatile("" : : "v"(sp_pre[u])); asm volatile("" : : "v"(rc_pre[u])); }
     IPP_TICK(v, 1, tick);
     if ((FRONT_ONLY || WAVE) && threadIdx.x == 0) IPP_MARK(item, 3);
 
@@ -261,13 +266,16 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // A column contributes only where it is stored (its tile span): cells outside hold nothing and count as zero.
     const int gi = tid & (MP - 1);
     const Block gb = block_of(min(gi, m - 1), h.nx, h.rf, h.w, h.h);
-    int gc[4], gtile[4];
+    int gc[4], gtile[4], grow[4], gcol[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int aa = min(a, gb.count() - 1);
-        gc[a] = (h.yu + gb.y0 + aa / gb.bw) * v.W + h.xl + gb.x0 + aa % gb.bw;
+        grow[a] = h.yu + gb.y0 + aa / gb.bw;
+        gcol[a] = h.xl + gb.x0 + aa % gb.bw;
+        gc[a] = grow[a] * v.W + gcol[a];
         gtile[a] = gc[a] / v.tile_cells;
     }
+    const bool rect_meta = v.rect_meta != 0;  // (columns written on rectangle tiles hold nothing outside their rectangle)
     const int gcnt = gb.count();
     const float gw = (float)gb.weight;
     // All requests of a pass leave before the first is waited for.  A column is requested only where it is stored
@@ -275,7 +283,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // wave-uniform) request only that cell.  Written as "test, load, add" per cell, hipcc waits for every load
     // before it issues the next one: 12 .. 36 dependent round trips per pass.
     const bool one_cell = (h.rf == 1);
-    auto gather_issue = [&](int k0, const int (&sp)[UN], float (&l)[UN][4]) {
+    auto gather_issue = [&](int k0, const int (&sp)[UN], const unsigned (&rc)[UN], float (&l)[UN][4]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = min(k0 + u * KS, r - 1);
@@ -285,7 +293,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
             for (int a = 0; a < 4; ++a) {
                 l[u][a] = 0.f;
                 if (a == 0 || (!one_cell && a < gcnt))
-                    if (gtile[a] >= lo && gtile[a] <= hi) l[u][a] = row[gc[a]];
+                    if (gtile[a] >= lo && gtile[a] <= hi && (!rect_meta || rect_has(rc[u], grow[a], gcol[a]))) l[u][a] = row[gc[a]];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -299,9 +307,9 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
             sacc[u] = t;
         }
     };
-    auto gather_rows = [&](int k0, const int (&sp)[UN], float (&sacc)[UN]) {
+    auto gather_rows = [&](int k0, const int (&sp)[UN], const unsigned (&rc)[UN], float (&sacc)[UN]) {
         float l[UN][4];
-        gather_issue(k0, sp, l);
+        gather_issue(k0, sp, rc, l);
         gather_sum(l, sacc);
     };
     float sacc0[UN];
@@ -312,7 +320,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // registers and 12 spills and was 4 % slower; the mask is per tile now.)
     {
         float l0[UN][4];
-        if (gather_on) gather_issue(tid / MP, sp_pre, l0);
+        if (gather_on) gather_issue(tid / MP, sp_pre, rc_pre, l0);
         mid_work(h);
         if (gather_on) gather_sum(l0, sacc0);
     }
@@ -425,10 +433,15 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                 if (k00 + u * KS < r) big[gi * SI + (k00 + u * KS) * SK] = sacc0[u] * gw;
             for (int k0 = k00 + UN * KS; k0 < r; k0 += UN * KS) {  // further passes (rank > UN * KS)
                 int sp[UN];
+                unsigned rc[UN];
 #pragma unroll
-                for (int u = 0; u < UN; ++u) sp[u] = CHAIN ? cc->span(min(k0 + u * KS, r - 1)) : span[min(k0 + u * KS, r - 1)];
+                for (int u = 0; u < UN; ++u) {
+                    const int kc = min(k0 + u * KS, r - 1);
+                    sp[u] = CHAIN ? cc->span(kc) : span[kc];
+                    rc[u] = !rect_meta ? kRectFull : (CHAIN ? cc->rect(kc) : (unsigned)rects[kc]);
+                }
                 float sacc[UN];
-                gather_rows(k0, sp, sacc);
+                gather_rows(k0, sp, rc, sacc);
 #pragma unroll
                 for (int u = 0; u < UN; ++u)
                     if (k0 + u * KS < r) big[gi * SI + (k0 + u * KS) * SK] = sacc[u] * gw;

@@ -111,17 +111,18 @@ __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int
     const int* span = v.colspan + (size_t)env * v.rank_cap;
     ChainCols cc;
     if (CHAIN) {
-        cc.root = U; cc.root_spans = span; cc.r_root = r; cc.depth = 0; cc.npad = (size_t)v.Npad; cc.nstride = (size_t)win_cells;
+        cc.root = U; cc.root_spans = span; cc.root_rects = v.colrect + (size_t)env * v.rank_cap; cc.r_root = r; cc.depth = 0; cc.npad = (size_t)v.Npad; cc.nstride = (size_t)win_cells;
 #pragma unroll
-        for (int j = 0; j < kTreeDepth; ++j) { cc.node[j] = U; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0; }
+        for (int j = 0; j < kTreeDepth; ++j) { cc.node[j] = U; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0; cc.nrect[j] = kRectFull; }
 #pragma unroll
         for (int j = 0; j < kTreeDepth; ++j)
             if (j < path.depth) {
                 const int id = path.ids[j];
-                cc.nspan[j] = node_meta[4 * id + 1];
+                cc.nspan[j] = node_meta[kNodeMeta * id + 1];
+                cc.nrect[j] = (unsigned)node_meta[kNodeMeta * id + 4];
                 cc.node[j] = node_cov + (size_t)id * v.meas_cap * win_cells - (size_t)(cc.nspan[j] & 0xffff) * v.tile_cells;
                 cc.off[j] = r;
-                r += node_meta[4 * id];
+                r += node_meta[kNodeMeta * id];
             }
         cc.depth = path.depth;
     }
@@ -140,8 +141,11 @@ __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int
             if (k < r) {
                 const int sp = CHAIN ? cc.span(k) : span[k], lo = sp & 0xffff, hi = sp >> 16;
                 const float* rowk = CHAIN ? cc.row(k) : U + (size_t)k * v.Npad;
-                if (tile_i >= lo && tile_i <= hi && i0 + c < v.N) a = rowk[i0 + c];
-                if (tile_j >= lo && tile_j <= hi && j0 + c < v.N) b = rowk[j0 + c];
+                unsigned rc = kRectFull;  // (View::rect_meta: nothing is stored outside a column's rectangle)
+                if (v.rect_meta) rc = CHAIN ? cc.rect(k) : (unsigned)v.colrect[(size_t)env * v.rank_cap + k];
+                const int ic = min(i0 + c, v.N - 1), jc = min(j0 + c, v.N - 1);
+                if (tile_i >= lo && tile_i <= hi && i0 + c < v.N && rect_has(rc, ic / v.W, ic % v.W)) a = rowk[i0 + c];
+                if (tile_j >= lo && tile_j <= hi && j0 + c < v.N && rect_has(rc, jc / v.W, jc % v.W)) b = rowk[j0 + c];
             }
             ui[kk][c] = a;
             uj[kk][c] = b;

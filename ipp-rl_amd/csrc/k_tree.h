@@ -19,7 +19,7 @@ namespace ipp {
 struct TreeView {
     float* node_cov;   // [node_cap][MC][win_cells] columns appended by the node's step, cell c at index c - t_lo * tile_cells
     float* node_diag;  // [node_cap][win_cells]     diag of the node's state on its span
-    int* node_meta;    // [node_cap][4]             m, tile span (lo | hi << 16), parent node (-1: child of the root env), root env
+    int* node_meta;    // [node_cap][kNodeMeta]     m, tile span (lo | hi << 16), parent node (-1: child of the root env), root env, rectangle (rect_pack)
     int node_cap;
     int win_cells;     // View::win_tiles * View::tile_cells
 };
@@ -33,6 +33,7 @@ __device__ __forceinline__ int tree_chain(const View& v, const TreeView& tv, con
     root = min(max(root_ids[item], 0), v.cap - 1);  // (a bad id is reported by the prologue's slot check)
     cc.root = v.cov + (size_t)root * v.cov_slot;
     cc.root_spans = v.colspan + (size_t)root * v.rank_cap;
+    cc.root_rects = v.colrect + (size_t)root * v.rank_cap;
     cc.r_root = uni(v.rank[root]);
     cc.depth = 0;
     cc.npad = (size_t)v.Npad;
@@ -43,19 +44,20 @@ __device__ __forceinline__ int tree_chain(const View& v, const TreeView& tv, con
     parent_id = -1;
 #pragma unroll
     for (int j = 0; j < kTreeDepth; ++j) {
-        cc.node[j] = cc.root; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0;
-        dc.node[j] = dc.root_diag; dc.nspan[j] = 0xffff;  // (lo 0xffff > hi 0: covers nothing)
+        cc.node[j] = cc.root; cc.off[j] = 0x7fffffff; cc.nspan[j] = 0; cc.nrect[j] = kRectFull;
+        dc.node[j] = dc.root_diag; dc.nspan[j] = 0xffff; dc.nrect[j] = kRectFull;  // (lo 0xffff > hi 0: covers nothing)
     }
     // Two rounds of loads (all the path ids, then all the nodes' records) in front of branch-free bookkeeping: behind
     // a per-level `if (id valid)` they are 2 kTreeDepth dependent scalar round trips.
-    int pid[kTreeDepth], pm[kTreeDepth], psp[kTreeDepth];
+    int pid[kTreeDepth], pm[kTreeDepth], psp[kTreeDepth], prc[kTreeDepth];
 #pragma unroll
     for (int j = 0; j < kTreeDepth; ++j) pid[j] = uni(path_ids[(size_t)item * kTreeDepth + j]);
 #pragma unroll
     for (int j = 0; j < kTreeDepth; ++j) {
         const int idc = min(max(pid[j], 0), tv.node_cap - 1);
-        pm[j] = uni(tv.node_meta[4 * idc]);
-        psp[j] = uni(tv.node_meta[4 * idc + 1]);
+        pm[j] = uni(tv.node_meta[kNodeMeta * idc]);
+        psp[j] = uni(tv.node_meta[kNodeMeta * idc + 1]);
+        prc[j] = uni(tv.node_meta[kNodeMeta * idc + 4]);
     }
 #pragma unroll
     for (int j = 0; j < kTreeDepth; ++j) {
@@ -69,8 +71,10 @@ __device__ __forceinline__ int tree_chain(const View& v, const TreeView& tv, con
                     cc.node[d] = tv.node_cov + (size_t)id * MC * tv.win_cells - shift;
                     cc.off[d] = n_cols;
                     cc.nspan[d] = sp;
+                    cc.nrect[d] = (unsigned)prc[j];
                     dc.node[d] = tv.node_diag + (size_t)id * tv.win_cells - shift;
                     dc.nspan[d] = sp;
+                    dc.nrect[d] = (unsigned)prc[j];
                 }
             n_cols += pm[j];
             cc.depth += 1;
@@ -107,12 +111,14 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     // (shifted by the new node's own t_lo once the header is known: in `mid` below / after the prologue)
     float* new_cols0 = expand ? tv.node_cov + (size_t)new_id * MC * tv.win_cells : nullptr;
     float* new_diag0 = expand ? tv.node_diag + (size_t)new_id * tv.win_cells : nullptr;
-    int* new_meta = expand ? tv.node_meta + 4 * new_id : nullptr;
+    int* new_meta = expand ? tv.node_meta + kNodeMeta * new_id : nullptr;
 
     // ---- phase A; under the footprint-dependent loads: block tables and the prior table
     auto mid = [&](const ItemHdr& hh) {
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
+        if (v.rect_meta)
+            for (int k = tid; k < hh.rank; k += kStepThreads) lds.rect_s[k] = cc.rect(k);
         // (mask and the new node's diagonal per tile, from the parent state's diagonal read under the tile's stream, like
         // k_tree_gain: the pass over the span in front of the stream was 9 of the 36 us of this prologue)
         const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
@@ -228,12 +234,14 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
     float* new_cols0 = expand ? tv.node_cov + (size_t)new_id * MC * tv.win_cells : nullptr;
     float* new_diag0 = expand ? tv.node_diag + (size_t)new_id * tv.win_cells : nullptr;
-    int* new_meta = expand ? tv.node_meta + 4 * new_id : nullptr;
+    int* new_meta = expand ? tv.node_meta + kNodeMeta * new_id : nullptr;
 
     const float* __restrict__ blk = q_all + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]
     for (int i = tid; i < LQ; i += T) lds.Ls[i] = blk[i];
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) { lds.span_s[k] = cc.span(k); lds.rowp[k] = cc.row(k); }
+    if (v.rect_meta)
+        for (int k = tid; k < r; k += T) lds.rect_s[k] = cc.rect(k);
     if (v.clip_cols) {
         __syncthreads();
         mark_inactive_columns(lds.span_s, blk + LQ, (MC + 3) & ~3, r, h.m, tid, T);
@@ -257,22 +265,22 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
 }
 
 // diag of a node's state, assembled along its parent chain: out[c] = diagonal of the deepest node (from `node` upwards)
-// whose span covers c's tile, else the root env's.
+// whose span (and rectangle) covers c, else the root env's.
 __global__ void k_tree_read_diag(View v, TreeView tv, int node, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= v.N) return;
     const int tile = c / v.tile_cells;
-    int cur = node, root = tv.node_meta[4 * node + 3];
+    int cur = node, root = tv.node_meta[kNodeMeta * node + 3];
     float val = 0.f;
     bool found = false;
     for (int hops = 0; hops <= kTreeDepth && cur >= 0; ++hops) {
-        const int sp = tv.node_meta[4 * cur + 1], lo = sp & 0xffff, hi = sp >> 16;
-        if (tile >= lo && tile <= hi) {
+        const int sp = tv.node_meta[kNodeMeta * cur + 1], lo = sp & 0xffff, hi = sp >> 16;
+        if (tile >= lo && tile <= hi && rect_has((unsigned)tv.node_meta[kNodeMeta * cur + 4], c / v.W, c % v.W)) {
             val = tv.node_diag[(size_t)cur * tv.win_cells + (c - lo * v.tile_cells)];
             found = true;
             break;
         }
-        cur = tv.node_meta[4 * cur + 2];
+        cur = tv.node_meta[kNodeMeta * cur + 2];
     }
     out[c] = found ? val : v.diag[(size_t)root * v.Npad + c];
 }

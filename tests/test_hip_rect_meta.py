@@ -1,0 +1,190 @@
+"""
+GPU tests of the rectangle metadata of the windowed factor state (csrc/ipp_common.h `rect_pack`, View::rect_meta):
+steps on rectangle tiles store the m new columns on the clipped rectangle only -- no zeros are written to the rest of the
+row band -- record the rectangle per column (View::colrect / the tree node's record), and every reader of stored columns
+(the footprint gather, the row stream, the dense read-out, the chained tree states) masks with it.
+
+The arena of every engine the tests create is filled with 0xFF bytes (NaN), so a reader that misses a mask fails loudly.
+
+  * three builds of the same episode -- rectangle metadata (default), rectangle tiles with the zeros stored
+    (IPP_RECT_META=0 IPP_RECT=2: the round-2 kernels) and band tiles (IPP_RECT_META=0 IPP_RECT=0) -- give bit-identical
+    rewards, means, variances and dense covariances between the two rectangle builds, and agree to 3e-6 with the band tiles
+    (which clip per cell instead of per VEC-cell group);
+  * the same for tree steps (ipp_tree_step on chained node states) at 100x100, plus the node diagonals;
+  * forked slots carry their rectangles with them.
+"""
+import os
+from contextlib import contextmanager
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ALTS = [float(a) for a in range(5, 15)]
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@contextmanager
+def engine_env(**kv):
+    """Environment switches the engine reads at creation (A/B switches of csrc/ipp_engine.hip)."""
+    old = {k: os.environ.get(k) for k in kv}
+    try:
+        for k, val in kv.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(val)
+        yield
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+
+
+VARIANTS = {
+    "rect_meta": dict(IPP_RECT_META=None, IPP_RECT=None),
+    "rect_zeros": dict(IPP_RECT_META=0, IPP_RECT=2),
+    "band": dict(IPP_RECT_META=0, IPP_RECT=0),
+}
+
+
+def run_episode(dim, B, T, steps, variant, seed=7):
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    with engine_env(**VARIANTS[variant]):
+        env = VecIPPEnv(cfg, B, state="factor", episode_steps=T, seed=seed, stagger=True, window_rows=-1)
+    env.reset()
+    rewards, predicted = [], []
+    for t in range(steps):
+        acts = cell_centre_actions(cfg, t, 0, B, B, ALTS)
+        if t % 5 == 3:  # a predict-only call from the same states (simulate_prediction_step)
+            a = torch.as_tensor(acts, dtype=torch.float64, device="cuda")
+            rp, sp = env.engine.step(a, env.prev, predict_only=True)
+            assert int(sp.abs().sum()) == 0
+            predicted.append(rp.clone())
+        r, s = env.step(acts)
+        assert int(s.abs().sum()) == 0
+        rewards.append(r.clone())
+    out = dict(rewards=torch.stack(rewards), predicted=torch.stack(predicted),
+               mean=torch.stack([env.mean(e) for e in range(B)]), diag=torch.stack([env.diag(e) for e in range(B)]),
+               ranks=env.engine.ranks().clone(), cov=[env.engine.read_cov(e).clone() for e in (0, B // 2, B - 1)])
+    assert bool(torch.isfinite(out["rewards"]).all()) and bool(torch.isfinite(out["mean"]).all())
+    return out
+
+
+@pytest.mark.parametrize("dim,B,T,steps", [(50, 48, 20, 45), (100, 24, 16, 36), (64, 16, 12, 26)])
+def test_rectangle_metadata_equals_stored_zeros_and_band_tiles(dim, B, T, steps):
+    import torch
+
+    runs = {name: run_episode(dim, B, T, steps, name) for name in VARIANTS}
+    a, z, b = runs["rect_meta"], runs["rect_zeros"], runs["band"]
+    assert torch.equal(a["ranks"], z["ranks"]) and torch.equal(a["ranks"], b["ranks"])
+    # identical arithmetic per cell: masking a column outside its rectangle and reading the zeros stored there are the same
+    for key in ("rewards", "predicted", "mean", "diag"):
+        assert torch.equal(a[key], z[key]), key
+    for ca, cz in zip(a["cov"], z["cov"]):
+        assert torch.equal(ca, cz)
+    # band tiles clip the new columns per cell, rectangle tiles per VEC-cell group (the rectangle is one grid column wider where
+    # the clip range starts or ends inside a group): the values at that extra column are below the window criterion (1e-6)
+    for key in ("mean", "diag", "rewards", "predicted"):
+        assert np.allclose(host(a[key]), host(b[key]), rtol=0, atol=3e-6), (key, np.abs(host(a[key]) - host(b[key])).max())
+    for ca, cb in zip(a["cov"], b["cov"]):
+        assert np.allclose(host(ca), host(cb), rtol=0, atol=3e-6)
+
+
+def test_engine_reports_rectangle_metadata_only_where_it_applies():
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.engine import IPPEngine
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    # exact columns, one-wave kernels and narrow grids keep whole tile spans: every path must still agree with the oracle
+    # (tests/test_hip_parity.py, test_hip_window.py); here: creation succeeds and steps run with the switch forced off
+    with engine_env(IPP_RECT_META=0):
+        eng = IPPEngine(cfg, capacity=4, state="factor", window_rows=-1)
+    eng.reset()
+    eng.close()
+
+
+@pytest.mark.parametrize("dim", [100])
+def test_tree_steps_with_rectangle_metadata_equal_stored_zeros(dim):
+    """Chained tree states: root env columns (written by env steps) + node columns (written by tree steps), depth 4."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.engine import IPPEngine
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    R, depth, root_steps = 12, 4, 6
+    results = {}
+    for name in ("rect_meta", "rect_zeros"):
+        with engine_env(**VARIANTS[name]):
+            eng = IPPEngine(cfg, capacity=R, state="factor", window_rows=-1, node_capacity=R * depth * 2, score_scratch=True, max_batch=64)
+        rng = np.random.RandomState(3)
+        eng.reset(white_noise=torch.as_tensor(rng.normal(size=(R, dim * dim)), dtype=torch.float32, device="cuda"))
+        prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(R, 1)
+        for t in range(root_steps):
+            a = torch.as_tensor(cell_centre_actions(cfg, t, 0, R, R, ALTS), dtype=torch.float64, device="cuda")
+            r, s = eng.step(a, prev, meas_noise=torch.zeros((R, 9), device="cuda"))
+            assert int(s.abs().sum()) == 0
+            prev = a
+        roots = torch.arange(R, dtype=torch.int32, device="cuda")
+        path = torch.full((R, 6), -1, dtype=torch.int32, device="cuda")
+        rewards, diags = [], []
+        for d in range(depth):
+            # revisit the neighbourhood of the previous action so that node rectangles overlap partially
+            a = prev.clone()
+            a[:, 0] = (a[:, 0] + 8.0 * (d + 1)) % (dim * cfg.resolution)
+            a[:, 2] = float(ALTS[(3 * d + 4) % len(ALTS)])
+            new_ids = torch.arange(d * R, (d + 1) * R, dtype=torch.int32, device="cuda")
+            r, s = eng.tree_step(roots, path, a, prev, new_ids)
+            assert int(s.abs().sum()) == 0
+            path[:, d] = new_ids
+            prev = a
+            rewards.append(r.clone())
+            diags.append(torch.stack([eng.tree_diag(int(n)) for n in new_ids[:3]]))
+        # all-candidate scoring from the deepest chained state (densifies root + path columns)
+        cand = torch.as_tensor(cell_centre_actions(cfg, 99, 0, 64, 64, ALTS), dtype=torch.float64, device="cuda")
+        sc = eng.tree_score_actions(0, [int(x) for x in path[0, :depth].cpu()], cand, prev[0].cpu().numpy())
+        assert int(sc[1].abs().sum()) == 0
+        results[name] = (torch.stack(rewards), torch.stack(diags), sc[0].clone())
+        assert bool(torch.isfinite(results[name][0]).all()) and bool(torch.isfinite(results[name][2]).all())
+        eng.close()
+    for x, y in zip(results["rect_meta"], results["rect_zeros"]):
+        assert torch.equal(x, y)
+
+
+def test_forked_slots_keep_their_rectangles():
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.engine import IPPEngine
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B = 8
+    eng = IPPEngine(cfg, capacity=2 * B, state="factor", window_rows=-1)
+    rng = np.random.RandomState(5)
+    eng.reset(white_noise=torch.as_tensor(rng.normal(size=(2 * B, 2500)), dtype=torch.float32, device="cuda"))
+    ids = torch.arange(B, dtype=torch.int32, device="cuda")
+    prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+    for t in range(8):
+        a = torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, ALTS), dtype=torch.float64, device="cuda")
+        r, s = eng.step(a, prev, env_ids=ids, meas_noise=torch.zeros((B, 9), device="cuda"))
+        assert int(s.abs().sum()) == 0
+        prev = a
+    eng.fork(ids, ids + B)
+    a = torch.as_tensor(cell_centre_actions(cfg, 50, 0, B, B, ALTS), dtype=torch.float64, device="cuda")
+    r0, s0 = eng.step(a, prev, env_ids=ids, meas_noise=torch.zeros((B, 9), device="cuda"))
+    r1, s1 = eng.step(a, prev, env_ids=ids + B, meas_noise=torch.zeros((B, 9), device="cuda"))
+    assert int(s0.abs().sum()) == 0 and int(s1.abs().sum()) == 0
+    assert torch.equal(r0, r1)
+    for e in range(B):
+        assert torch.equal(eng.read_diag(e), eng.read_diag(e + B))
+    assert torch.equal(eng.read_cov(3), eng.read_cov(3 + B))
