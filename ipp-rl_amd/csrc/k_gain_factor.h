@@ -54,10 +54,19 @@ struct GainLds {
     int* solve_flag; int* span_s; unsigned* rect_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
     double* tile_red;  // [win_tiles] masked trace reduction of every touched tile (summed in tile order at the end)
     const float** rowp;  // [chain_rows] tree steps: pointer to every column of the chained state (ChainCols::row, evaluated once)
+    int rect_n;
+    // rectangle of stored column k (rect_pack) -> the two words of the per-lane test: a cell group at (row, col) lies inside
+    // iff, as pairs of 16-bit lanes, min(pos - lo, ext) == pos - lo with pos = row | col << 16  (two packed instructions and
+    // one compare per stored row and lane instead of four unpacked range tests)
+    __device__ __forceinline__ void stage_rect(int k, unsigned rc) const {
+        const unsigned r0 = rc & 0xff, r1 = (rc >> 8) & 0xff, c0 = (rc >> 16) & 0xff, c1 = rc >> 24;
+        rect_s[k] = r0 | (c0 << 16);
+        rect_s[rect_n + k] = (rc == kRectFull) ? 0xffffffffu : ((r1 - r0) | ((c1 - c0) << 16));
+    }
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
                                             int n_tiles, int mask_bytes = 0, int chain_rows = 0) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
-        b += (size_t)((rank_cap + 3) & ~3) * 8 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
+        b += (size_t)((rank_cap + 3) & ~3) * 12 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
         b = ((b + 15) & ~(size_t)15) + (size_t)mask_bytes;
         b = ((b + 15) & ~(size_t)15) + (size_t)n_tiles * 8 + (size_t)chain_rows * 8;
         return (b + 15) & ~(size_t)15;
@@ -78,8 +87,11 @@ struct GainLds {
         done_waves = next_tile + 1;
         solve_flag = reinterpret_cast<int*>(red + 14);  // fused kernel: 0 = L^-1 / y pending, 1 = ready, 2 = S not PD
         span_s = reinterpret_cast<int*>(red + 16);
-        rect_s = reinterpret_cast<unsigned*>(span_s + ((rank_cap + 3) & ~3));  // [rank_cap] rectangles of the stored columns (View::rect_meta)
-        fb_yx = span_s + 2 * ((rank_cap + 3) & ~3);        // [MC][4] footprint cell (row << 16 | col) of block b
+        // [2][rank_cap] rectangles of the stored columns (View::rect_meta) in the form the per-lane test wants (stage_rect):
+        // first row | first column << 16, then (rows - 1) | (columns - 1) << 16
+        rect_s = reinterpret_cast<unsigned*>(span_s + ((rank_cap + 3) & ~3));
+        rect_n = (rank_cap + 3) & ~3;
+        fb_yx = span_s + 3 * ((rank_cap + 3) & ~3);        // [MC][4] footprint cell (row << 16 | col) of block b
         fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);   // [MC][4] weight of that cell (0 for padding)
         // [waves][2][64 lanes][4]: mean / diag of the wave's current tile, parked here across the stream loop
         // (typed pointer arithmetic only: an integer round trip would turn the LDS pointer into a flat one)
@@ -141,6 +153,20 @@ struct DiagChain {
         return p;
     }
 };
+
+// Predicated row load of the stream: VEC floats at byte offset `off` of a wave-uniform row, or zeros where the lane's
+// predicate is false -- as a BUFFER load whose offset is pushed out of range for the masked lanes (the hardware returns 0),
+// instead of a global load under a per-row exec mask (hipcc wraps each of those in s_and_saveexec / s_cbranch_execz / s_or:
+// ~10 scalar instructions and two branches per stored row).  `row` must be wave-uniform (SGPRs).
+template <int VEC>
+__device__ __forceinline__ auto row_load_masked(const float* row, unsigned row_bytes, unsigned off, bool ok) {
+    typedef float rowv __attribute__((ext_vector_type(VEC)));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, (int)row_bytes, 0x00020000);
+    const unsigned voff = ok ? off : 0xffffffffu;
+    if constexpr (VEC == 2) return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 2));  // (aux 2: nt)
+    else if constexpr (VEC == 4) return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 2));
+    else return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 2));
+}
 
 // Tile loop + per-item results; expects Ls / ys, the block tables, the prior table P0(|drow| < lut_rows, |dcol|)
 // (row distances beyond it fall back to sqrt / exp), span_s[0..r)
@@ -291,27 +317,30 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         const int urow1 = rect ? __builtin_amdgcn_readlane(rrow, kWave - 1) : min(tile * kWaveTile + kWaveTile - 1, v.N - 1) / v.W;
         const int ucol0 = rect ? (urow0 == urow1 ? __builtin_amdgcn_readfirstlane(rcol) : rect_lo) : 0;
         const int ucol1 = rect ? (urow0 == urow1 ? __builtin_amdgcn_readlane(rcol, kWave - 1) + VEC - 1 : rect_hi) : v.W - 1;
-        int lrow = rrow, lcol = rcol;
+        const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
 
         // ---- ordered compaction of the columns stored on this tile (wave-local, no barrier)
         int nact = 0;
         bool partial = false;  // (rect: some active column covers only a part of the unit: its loads are predicated per lane)
+        bool span_part = false;  // (rm: ... already by its tile span -- columns written on band tiles; else the rectangle test suffices)
         for (int k0 = 0; k0 < ((IPP_GF_ABLATE & 8) ? 0 : r); k0 += kWave) {
             const int k = k0 + lane;
             bool on = false;
-            bool part_k = false;
+            bool part_k = false, part_sp = false;
             if (k < r) {
                 const int sp = span_s[k];
                 on = bt_max >= (sp & 0xffff) && bt_min <= (sp >> 16);
                 part_k = on && !(bt_min >= (sp & 0xffff) && bt_max <= (sp >> 16));  // stored on a part of this unit's cells only
                 if (rm) {
-                    const unsigned rc = rect_s[k];
-                    const int r0 = rc & 0xff, r1 = (rc >> 8) & 0xff, c0 = (rc >> 16) & 0xff, c1 = rc >> 24;
+                    const unsigned lo = rect_s[k], ext = rect_s[lds.rect_n + k];
+                    const int r0 = lo & 0xffff, c0 = lo >> 16, r1 = r0 + (int)(ext & 0xffff), c1 = c0 + (int)(ext >> 16);
                     on = on && r1 >= urow0 && r0 <= urow1 && c1 >= ucol0 && c0 <= ucol1;
+                    part_sp = part_k;
                     part_k = on && (part_k || !(r0 <= urow0 && r1 >= urow1 && c0 <= ucol0 && c1 >= ucol1));
                 }
             }
             partial |= __ballot(part_k) != 0ull;
+            span_part |= __ballot(part_sp) != 0ull;  // (all lanes: wave-uniform)
             const unsigned long long mask = __ballot(on);
             if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)k;
             nact += __popcll(mask);
@@ -443,14 +472,43 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     rowk[i] = CHAIN ? uni_ptr(lds.rowp[ku]) : cov_src + (size_t)ku * npad;
                 }
                 if ((rect || rm) && partial) {  // (units at the edge of a stored column's span / rectangle: per column, only the lanes it is stored on)
+                    // The table words of all KP rows are read first (one LDS round trip for the group, not one in front of every
+                    // request), and the three cases are separate loops (a wave-uniform choice per row cost a branch per row).
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    const unsigned row_bytes = (unsigned)v.Npad * 4u;  // (any bound >= the largest in-range offset + 16 that stays inside the row)
+                    int kx[KP];
 #pragma unroll
-                    for (int i = 0; i < KP; ++i) {
-                        const int kx = kk[i] < r ? kk[i] : safe_k;
-                        const int sp = uni(span_s[kx]);
-                        const unsigned rc = rm ? (unsigned)uni((int)rect_s[kx]) : kRectFull;
-                        u[i] = (rowv)(0.f);
-                        if (inmask && bt_lane >= (sp & 0xffff) && bt_lane <= (sp >> 16) && rect_has(rc, lrow, lcol))
-                            u[i] = __builtin_nontemporal_load(reinterpret_cast<const rowv*>(rowk[i] + cell0));
+                    for (int i = 0; i < KP; ++i) kx[i] = kk[i] < r ? kk[i] : safe_k;
+                    if (rm && !span_part) {  // rectangles only (every active column written on rectangle tiles, or covering the unit's tiles)
+                        unsigned wlo[KP], wex[KP];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) { wlo[i] = rect_s[kx[i]]; wex[i] = rect_s[lds.rect_n + kx[i]]; }
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) {
+                            const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, wlo[i]);
+                            const bool ok = inmask != 0u && __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, wex[i]))) == __builtin_bit_cast(unsigned, d);
+                            u[i] = row_load_masked<VEC>(rowk[i], row_bytes, (unsigned)cell0 * 4u, ok);
+                        }
+                    } else if (!rm) {  // tile spans only
+                        int wsp[KP];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) wsp[i] = span_s[kx[i]];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) {
+                            u[i] = row_load_masked<VEC>(rowk[i], row_bytes, (unsigned)cell0 * 4u, inmask != 0u && bt_lane >= (wsp[i] & 0xffff) && bt_lane <= (wsp[i] >> 16));
+                        }
+                    } else {  // both (columns written on band tiles beside columns written on rectangle tiles)
+                        unsigned wlo[KP], wex[KP];
+                        int wsp[KP];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) { wlo[i] = rect_s[kx[i]]; wex[i] = rect_s[lds.rect_n + kx[i]]; wsp[i] = span_s[kx[i]]; }
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) {
+                            const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, wlo[i]);
+                            const bool ok = inmask != 0u && bt_lane >= (wsp[i] & 0xffff) && bt_lane <= (wsp[i] >> 16) &&
+                                            __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, wex[i]))) == __builtin_bit_cast(unsigned, d);
+                            u[i] = row_load_masked<VEC>(rowk[i], row_bytes, (unsigned)cell0 * 4u, ok);
+                        }
                     }
                 } else if (inmask) {  // (one exec-mask region for the whole group: clipped lanes request nothing)
 #pragma unroll
@@ -668,7 +726,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) lds.span_s[k] = v.colspan[(size_t)h.env * v.rank_cap + k];
     if (v.rect_meta)
-        for (int k = tid; k < r; k += T) lds.rect_s[k] = (unsigned)v.colrect[(size_t)h.env * v.rank_cap + k];
+        for (int k = tid; k < r; k += T) lds.stage_rect(k, (unsigned)v.colrect[(size_t)h.env * v.rank_cap + k]);
     if (v.clip_cols) {
         __syncthreads();
         mark_inactive_columns(lds.span_s, blk + LQ, (MC + 3) & ~3, r, h.m, tid, T);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
         if (v.rect_meta)  // rectangles of the stored columns (their loads return right behind the gather's first pass)
-            for (int k = tid; k < hh.rank; k += kStepThreads) lds.rect_s[k] = (unsigned)v.colrect[(size_t)hh.env * v.rank_cap + k];
+            for (int k = tid; k < hh.rank; k += kStepThreads) lds.stage_rect(k, (unsigned)v.colrect[(size_t)hh.env * v.rank_cap + k]);
         // adaptive mask of the whole env (rewards.py:11: pre-step mean and pre-step diag), one byte per VEC cells: the
         // tile loop then needs neither mean nor diag (their updates are no-return atomics)
         typedef float cellv __attribute__((ext_vector_type(VEC)));

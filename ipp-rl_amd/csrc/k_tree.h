@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
         if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
         if (v.rect_meta)
-            for (int k = tid; k < hh.rank; k += kStepThreads) lds.rect_s[k] = cc.rect(k);
+            for (int k = tid; k < hh.rank; k += kStepThreads) lds.stage_rect(k, cc.rect(k));
         // (mask and the new node's diagonal per tile, from the parent state's diagonal read under the tile's stream, like
         // k_tree_gain: the pass over the span in front of the stream was 9 of the 36 us of this prologue)
         const float s3 = (float)(kSqrt3 * v.res) / hh.ls;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
     for (int k = tid; k < r; k += T) { lds.span_s[k] = cc.span(k); lds.rowp[k] = cc.row(k); }
     if (v.rect_meta)
-        for (int k = tid; k < r; k += T) lds.rect_s[k] = cc.rect(k);
+        for (int k = tid; k < r; k += T) lds.stage_rect(k, cc.rect(k));
     if (v.clip_cols) {
         __syncthreads();
         mark_inactive_columns(lds.span_s, blk + LQ, (MC + 3) & ~3, r, h.m, tid, T);

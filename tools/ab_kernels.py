@@ -26,7 +26,8 @@ from ipp_rl_amd.vec_env import cell_centre_actions  # noqa: E402
 def make_engine(lib_path, cfg, B, tile_threads, window_rows=0):
     _ffi._lib = None
     _ffi.LIB_PATH = lib_path
-    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, tile_threads=tile_threads, window_rows=window_rows)
+    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, tile_threads=tile_threads, window_rows=window_rows,
+                    fixed_prior=(0 < window_rows < 12))
     return eng
 
 
