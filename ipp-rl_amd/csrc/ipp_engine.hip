@@ -695,12 +695,12 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         const int lutf = e->lut_rows * v.W;
         if (v.meas_cap == 9)
             e->gain_lds = e->fused ? std::max(GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, v.win_tiles * kWave),
-                                              GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, 0))
-                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles);
+                                              GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, 0, 0, v.vec))
+                                   : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
         else
             e->gain_lds = e->fused ? std::max(GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave),
-                                              GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0))
-                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles);
+                                              GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec))
+                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
         if (e->fused) {
             e->pipe_lds = (v.meas_cap == 9) ? PipeLds<9>::bytes(v.rank_cap, lutf, v.win_tiles) : PipeLds<25>::bytes(v.rank_cap, lutf, v.win_tiles);
             e->pipe = e->pipe_lds <= 160 * 1024;
@@ -762,7 +762,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         // Split tree steps: worth it once the launch fills the device several times over (below that the second launch
         // and the scratch round trip of L^-1 | Q cost more than the occupancy gains); IPP_TREE_SPLIT=<min items> / 0
         if (const char* tt = getenv("IPP_TREE_T")) e->tree_T = (atoi(tt) == 128) ? 128 : kStepThreads;
-        e->tree_gain_lds = (GainLds<9>::bytes(v.rank_cap, 0, e->lut_rows * v.W, 0, e->tree_T / kWave, v.win_tiles, 0, v.rank_cap) + 15) & ~(size_t)15;
+        e->tree_gain_lds = (GainLds<9>::bytes(v.rank_cap, 0, e->lut_rows * v.W, 0, e->tree_T / kWave, v.win_tiles, 0, v.rank_cap, v.vec) + 15) & ~(size_t)15;
         e->tree_split_min = 2048;
         if (const char* ts = getenv("IPP_TREE_SPLIT")) e->tree_split_min = atoi(ts);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_prepare<9>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

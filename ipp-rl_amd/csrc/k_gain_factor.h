@@ -54,19 +54,21 @@ struct GainLds {
     int* solve_flag; int* span_s; unsigned* rect_s; int* fb_yx; float* fb_w; float* stage; unsigned short* ridx_all; unsigned char* mask4;
     double* tile_red;  // [win_tiles] masked trace reduction of every touched tile (summed in tile order at the end)
     const float** rowp;  // [chain_rows] tree steps: pointer to every column of the chained state (ChainCols::row, evaluated once)
-    int rect_n;
-    // rectangle of stored column k (rect_pack) -> the two words of the per-lane test: a cell group at (row, col) lies inside
-    // iff, as pairs of 16-bit lanes, min(pos - lo, ext) == pos - lo with pos = row | col << 16  (two packed instructions and
-    // one compare per stored row and lane instead of four unpacked range tests)
+    // rectangle of stored column k (rect_pack) -> the bytes of the per-lane test: a cell group at (row, col) lies inside
+    // iff, as pairs of 16-bit lanes, min(pos - lo, ext) == pos - lo with pos = row | col << 16, lo = first row | first
+    // column << 16, ext = (rows - 1) | (columns - 1) << 16 (rect_lo / rect_ext spread the bytes: one v_perm each) -- two
+    // packed instructions and one compare per stored row and lane instead of four unpacked range tests
     __device__ __forceinline__ void stage_rect(int k, unsigned rc) const {
         const unsigned r0 = rc & 0xff, r1 = (rc >> 8) & 0xff, c0 = (rc >> 16) & 0xff, c1 = rc >> 24;
-        rect_s[k] = r0 | (c0 << 16);
-        rect_s[rect_n + k] = (rc == kRectFull) ? 0xffffffffu : ((r1 - r0) | ((c1 - c0) << 16));
+        rect_s[k] = (rc == kRectFull) ? 0xffff0000u : (r0 | (c0 << 8) | ((r1 - r0) << 16) | ((c1 - c0) << 24));
     }
+    static __device__ __forceinline__ unsigned rect_lo(unsigned w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); }   // bytes [b0, 0, b1, 0]
+    static __device__ __forceinline__ unsigned rect_ext(unsigned w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }  // bytes [b2, 0, b3, 0]
+    // vec: cells per lane of the kernel's tiles (the per-wave mean / diag parking area holds 2 * 64 * vec floats)
     __host__ __device__ static size_t bytes(int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
-                                            int n_tiles, int mask_bytes = 0, int chain_rows = 0) {
+                                            int n_tiles, int mask_bytes = 0, int chain_rows = 0, int vec = 4) {
         size_t b = (size_t)(LQ + ((work_floats + 3) & ~3) + ((lut_floats + 3) & ~3) + ((small_floats + 3) & ~3)) * 4 + 16 * 8;
-        b += (size_t)((rank_cap + 3) & ~3) * 12 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 8 * 4) + (size_t)waves * (rank_cap + 8) * 2;
+        b += (size_t)((rank_cap + 3) & ~3) * 8 + (size_t)8 * MC * 4 + (mask_bytes ? 0 : (size_t)waves * kWave * 2 * vec * 4) + (size_t)waves * (rank_cap + 8) * 2;
         b = ((b + 15) & ~(size_t)15) + (size_t)mask_bytes;
         b = ((b + 15) & ~(size_t)15) + (size_t)n_tiles * 8 + (size_t)chain_rows * 8;
         return (b + 15) & ~(size_t)15;
@@ -76,7 +78,7 @@ struct GainLds {
     // mask_bytes > 0 (fused kernel): no mean / diag staging area, the env's mask bytes instead
     __device__ __forceinline__ GainLds() {}
     __device__ __forceinline__ GainLds(unsigned char* base, int rank_cap, int work_floats, int lut_floats, int small_floats, int waves,
-                                       int n_tiles, int mask_bytes = 0) {
+                                       int n_tiles, int mask_bytes = 0, int vec = 4) {
         Ls = reinterpret_cast<float*>(base);
         ys = Ls + MC * MC;
         work = Ls + LQ;
@@ -87,16 +89,16 @@ struct GainLds {
         done_waves = next_tile + 1;
         solve_flag = reinterpret_cast<int*>(red + 14);  // fused kernel: 0 = L^-1 / y pending, 1 = ready, 2 = S not PD
         span_s = reinterpret_cast<int*>(red + 16);
-        // [2][rank_cap] rectangles of the stored columns (View::rect_meta) in the form the per-lane test wants (stage_rect):
-        // first row | first column << 16, then (rows - 1) | (columns - 1) << 16
+        // [rank_cap] rectangles of the stored columns (View::rect_meta) as four bytes: first row, first column, rows - 1,
+        // columns - 1 (stage_rect).  (One word per column: with two, the fused kernel's LDS passed 40 KiB and a CU held
+        // three workgroups instead of four.)
         rect_s = reinterpret_cast<unsigned*>(span_s + ((rank_cap + 3) & ~3));
-        rect_n = (rank_cap + 3) & ~3;
-        fb_yx = span_s + 3 * ((rank_cap + 3) & ~3);        // [MC][4] footprint cell (row << 16 | col) of block b
+        fb_yx = span_s + 2 * ((rank_cap + 3) & ~3);        // [MC][4] footprint cell (row << 16 | col) of block b
         fb_w = reinterpret_cast<float*>(fb_yx + 4 * MC);   // [MC][4] weight of that cell (0 for padding)
-        // [waves][2][64 lanes][4]: mean / diag of the wave's current tile, parked here across the stream loop
+        // [waves][2][64 lanes][vec]: mean / diag of the wave's current tile, parked here across the stream loop
         // (typed pointer arithmetic only: an integer round trip would turn the LDS pointer into a flat one)
         stage = fb_w + 4 * MC;
-        ridx_all = reinterpret_cast<unsigned short*>(stage + (mask_bytes ? 0 : (size_t)waves * kWave * 8));
+        ridx_all = reinterpret_cast<unsigned short*>(stage + (mask_bytes ? 0 : (size_t)waves * kWave * 2 * vec));
         // adaptive-mask bits of the whole env, one byte per VEC cells (fused kernel), behind the per-wave index lists
         mask4 = reinterpret_cast<unsigned char*>(ridx_all + (((size_t)waves * (rank_cap + 8) + 7) & ~(size_t)7));
         tile_red = reinterpret_cast<double*>(mask4 + (((size_t)mask_bytes + 15) & ~(size_t)15));
@@ -215,7 +217,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     const float* cov_src = v.cov + (size_t)h.env * v.cov_slot;
     float* cov_dst = v.cov + (size_t)h.dst * v.cov_slot;
     unsigned short* ridx = lds.ridx_all + (size_t)wave * (v.rank_cap + 8);
-    float* stage_w = lds.stage + (size_t)wave * kWave * 8;  // (VEC <= 4)
+    float* stage_w = lds.stage + (size_t)wave * kWave * 2 * VEC;  // (the callers carve the area with vec = VEC)
     const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
     const size_t npad = (size_t)v.Npad;
     unsigned long long units = 0, extra = 0;
@@ -332,8 +334,8 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 on = bt_max >= (sp & 0xffff) && bt_min <= (sp >> 16);
                 part_k = on && !(bt_min >= (sp & 0xffff) && bt_max <= (sp >> 16));  // stored on a part of this unit's cells only
                 if (rm) {
-                    const unsigned lo = rect_s[k], ext = rect_s[lds.rect_n + k];
-                    const int r0 = lo & 0xffff, c0 = lo >> 16, r1 = r0 + (int)(ext & 0xffff), c1 = c0 + (int)(ext >> 16);
+                    const unsigned w = rect_s[k];
+                    const int r0 = w & 0xff, c0 = (w >> 8) & 0xff, r1 = r0 + (int)((w >> 16) & 0xff), c1 = c0 + (int)(w >> 24);
                     on = on && r1 >= urow0 && r0 <= urow1 && c1 >= ucol0 && c0 <= ucol1;
                     part_sp = part_k;
                     part_k = on && (part_k || !(r0 <= urow0 && r1 >= urow1 && c0 <= ucol0 && c1 >= ucol1));
@@ -480,13 +482,13 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
 #pragma unroll
                     for (int i = 0; i < KP; ++i) kx[i] = kk[i] < r ? kk[i] : safe_k;
                     if (rm && !span_part) {  // rectangles only (every active column written on rectangle tiles, or covering the unit's tiles)
-                        unsigned wlo[KP], wex[KP];
+                        unsigned wrc[KP];
 #pragma unroll
-                        for (int i = 0; i < KP; ++i) { wlo[i] = rect_s[kx[i]]; wex[i] = rect_s[lds.rect_n + kx[i]]; }
+                        for (int i = 0; i < KP; ++i) wrc[i] = rect_s[kx[i]];
 #pragma unroll
                         for (int i = 0; i < KP; ++i) {
-                            const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, wlo[i]);
-                            const bool ok = inmask != 0u && __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, wex[i]))) == __builtin_bit_cast(unsigned, d);
+                            const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, GainLds<MC>::rect_lo(wrc[i]));
+                            const bool ok = inmask != 0u && __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, GainLds<MC>::rect_ext(wrc[i])))) == __builtin_bit_cast(unsigned, d);
                             u[i] = row_load_masked<VEC>(rowk[i], row_bytes, (unsigned)cell0 * 4u, ok);
                         }
                     } else if (!rm) {  // tile spans only
@@ -498,15 +500,15 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                             u[i] = row_load_masked<VEC>(rowk[i], row_bytes, (unsigned)cell0 * 4u, inmask != 0u && bt_lane >= (wsp[i] & 0xffff) && bt_lane <= (wsp[i] >> 16));
                         }
                     } else {  // both (columns written on band tiles beside columns written on rectangle tiles)
-                        unsigned wlo[KP], wex[KP];
+                        unsigned wrc[KP];
                         int wsp[KP];
 #pragma unroll
-                        for (int i = 0; i < KP; ++i) { wlo[i] = rect_s[kx[i]]; wex[i] = rect_s[lds.rect_n + kx[i]]; wsp[i] = span_s[kx[i]]; }
+                        for (int i = 0; i < KP; ++i) { wrc[i] = rect_s[kx[i]]; wsp[i] = span_s[kx[i]]; }
 #pragma unroll
                         for (int i = 0; i < KP; ++i) {
-                            const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, wlo[i]);
+                            const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, GainLds<MC>::rect_lo(wrc[i]));
                             const bool ok = inmask != 0u && bt_lane >= (wsp[i] & 0xffff) && bt_lane <= (wsp[i] >> 16) &&
-                                            __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, wex[i]))) == __builtin_bit_cast(unsigned, d);
+                                            __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, GainLds<MC>::rect_ext(wrc[i])))) == __builtin_bit_cast(unsigned, d);
                             u[i] = row_load_masked<VEC>(rowk[i], row_bytes, (unsigned)cell0 * 4u, ok);
                         }
                     }
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_gain_factor(View v, co
                                                                    float* __restrict__ reward_out) {
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
-    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles);
+    const GainLds<MC> lds(smem_gf, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles, 0, VEC);
     if ((int)blockIdx.x >= n_items) return;
     const int item = launch_item(v, blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sf[];
     const GainLds<MC> lds(smem_sf, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.win_tiles, IPP_SF_LMASK ? v.win_tiles * kWave : 0);
+                          kStepThreads / kWave, v.win_tiles, IPP_SF_LMASK ? v.win_tiles * kWave : 0, VEC);
     if ((int)blockIdx.x >= n_items) return;
     const int item = launch_item(v, blockIdx.x, n_items);
     const int tid = threadIdx.x;

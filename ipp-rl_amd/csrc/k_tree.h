@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_tree_step(
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tr[];
     const GainLds<MC> lds(smem_tr, v.rank_cap, step_work_floats<MC>(v.rank_cap), lut_rows * v.W, step_small_floats<MC>(),
-                          kStepThreads / kWave, v.win_tiles, 0);
+                          kStepThreads / kWave, v.win_tiles, 0, VEC);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, IPP_GF_MINWAVES) void k_tree_gain(
     const int* __restrict__ new_ids, int n_items, unsigned flags, int lut_rows, float* __restrict__ reward_out) {
     constexpr int LQ = (MC * MC + MC + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tg[];
-    const GainLds<MC> lds(smem_tg, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles);
+    const GainLds<MC> lds(smem_tg, v.rank_cap, 0, lut_rows * v.W, 0, blockDim.x / kWave, v.win_tiles, 0, VEC);
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x, T = blockDim.x;
