@@ -559,11 +559,12 @@ def main(argv=None):
                 "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
                 "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device: "
                                                 "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
-                                                "cells of the step's window within window_rows of the footprint in BOTH directions; the cells of the "
-                                                "row band outside that column range only receive the m zeros of the new columns",
-                "note": "since the two-dimensional windows a step moves ~1/4 of the bytes it moved on row-band windows in ~2/3 of the time: "
-                        "the kernel is bound by latency (its prologue and the request groups per tile), not by HBM; traffic exceeds the "
-                        "algorithmic bytes because the 64-byte sectors of the row band are fetched whole (DESIGN.md sections 2, 5)",
+                                                "cells of the rectangle within window_rows of the footprint in BOTH directions (the new columns are stored on "
+                                                "that rectangle only and carry it as metadata: nothing is written to, or read from, the rest of the row band)",
+                "note": "a step moves ~1/5 of the bytes it moved on row-band windows (two-dimensional windows, then rectangle metadata "
+                        "instead of stored zeros) in ~0.55 of the time: the kernel is bound by latency (a workgroup's prologue is half of "
+                        "its life, a rectangle is 4-6 wave-sized units), not by HBM; traffic exceeds the algorithmic bytes because the "
+                        "64-byte sectors of the grid rows a rectangle crosses are fetched whole (DESIGN.md sections 2, 5)",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],

@@ -356,7 +356,10 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // ~30 fp64 calls with divisions per lane, 10 us of the prologue for 40 % of the items
     double* wyt = L;           // [orows][h.h]
     double* wxt = L + 2 * MC;  // [ocols][h.w]
-    if (!cov_only && h.rf > 1) {
+#ifndef IPP_PREP_ABLATE
+#define IPP_PREP_ABLATE 0  // timing experiments only: 1 = no INTER_AREA arithmetic (rf = 2 observations are wrong)
+#endif
+    if (!cov_only && h.rf > 1 && !(IPP_PREP_ABLATE & 1)) {
         const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
         for (int idx = tid; idx < orows * h.h; idx += kPrepThreads) wyt[idx] = area_weight(h.h, orows, idx / h.h, idx % h.h);
         for (int idx = tid; idx < ocols * h.w; idx += kPrepThreads) wxt[idx] = area_weight(h.w, ocols, idx / h.w, idx % h.w);
@@ -365,7 +368,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     if (!cov_only) {
         if (tid < m) {
             double val;
-            if (h.rf == 1) {
+            if (h.rf == 1 || (IPP_PREP_ABLATE & 1)) {
                 val = sub[tid];
             } else {
                 // cv2.resize(sub, dsize=(ceil(h/rf), ceil(w/rf))) -> width=ceil(h/rf), height=ceil(w/rf)
