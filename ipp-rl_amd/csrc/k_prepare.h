@@ -90,7 +90,17 @@ __device__ __forceinline__ void prep_sync() {
     if (WAVE) wave_lds_sync(); else __syncthreads();
 }
 
-template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid, bool CHAIN = false, bool WAVE = false>
+// DEFER (fused step kernel): the observation -- ground-truth crop, INTER_AREA resampling, noise, innovation -- is NOT
+// evaluated here.  Its inputs are loaded by the lanes of WAVE 1 (ObsRegs, out) and the caller lets that wave run
+// observe_wave() after the prologue's last barrier, in parallel with wave 0's S / Cholesky / L^-1 (solve_wave_fast waits
+// for the innovation only in front of y = L^-T v) and with the streams of waves 2, 3: the stream does not need the
+// observation, and for items above rf_altitude (40 % of them) it was 7 of the prologue's ~15 us.
+struct ObsRegs { float gt, eps, mean[4]; };
+template <int MC> struct PrepLds;
+template <int MC>
+__device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, unsigned flags, unsigned char* small, const ObsRegs& o);
+
+template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid, bool CHAIN = false, bool WAVE = false, bool DEFER = false>
 __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int item, const int* __restrict__ env_ids,
                                                     const int* __restrict__ dst_ids, const double* __restrict__ action,
                                                     const double* __restrict__ prev_action,
@@ -99,7 +109,9 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                                                     int* __restrict__ obs_m, int* __restrict__ obs_shape,
                                                     unsigned char* small, float* big, int si, int sk, float* q_out,
                                                     float* linv_f, float* linv_f2, float* y_f, float* y_f2, int* span_s,
-                                                    Mid mid_work, const ChainCols* cc = nullptr, int rank_chain = 0) {
+                                                    Mid mid_work, const ChainCols* cc = nullptr, int rank_chain = 0,
+                                                    ObsRegs* obs_regs = nullptr) {
+    static_assert(!DEFER || (FRONT_ONLY && !WAVE && NT >= 2 * kWave && 4 * MC <= kWave), "deferred observation: fused kernel only");
     constexpr int kPrepThreads = NT;
     constexpr int FC = 4 * MC;
     constexpr int LD = MC + 1;
@@ -128,7 +140,8 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
     const int rank_ld = CHAIN ? rank_chain : ((MODE == IPP_FACTOR) ? v.rank[envc] : 0);
     const double sv = v.prior[2 * envc + 0], ls = v.prior[2 * envc + 1];
-    const float eps_ld = (meas_noise && tid < MC) ? meas_noise[(size_t)item * MC + tid] : 0.f;
+    const int otid = DEFER ? tid - kWave : tid;  // thread index as the observation's inputs see it (DEFER: lanes of wave 1)
+    const float eps_ld = (meas_noise && otid >= 0 && otid < MC) ? meas_noise[(size_t)item * MC + otid] : 0.f;
     const int* __restrict__ span = v.colspan + (size_t)envc * v.rank_cap;
     const int* __restrict__ rects = v.colrect + (size_t)envc * v.rank_cap;
     int sp_pre[UN];  // tile spans of this thread's first-pass rows (factor)
@@ -249,18 +262,24 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     float gt_ld[(FC + kPrepThreads - 1) / kPrepThreads];
 #pragma unroll
     for (int q = 0; q < (FC + kPrepThreads - 1) / kPrepThreads; ++q) {
-        const int fi = tid + q * kPrepThreads;
-        const int ly = fi / h.w, lx = fi - ly * h.w;
-        gt_ld[q] = (!cov_only && fi < f) ? gt_env[(h.yu + ly) * v.W + h.xl + lx] : 0.f;
+        const int fi = (DEFER ? otid : tid) + q * kPrepThreads;
+        const int ly = max(fi, 0) / h.w, lx = max(fi, 0) - ly * h.w;
+        gt_ld[q] = (!cov_only && fi >= 0 && fi < f) ? gt_env[(h.yu + ly) * v.W + h.xl + lx] : 0.f;
     }
     // (b) mean over the cells of measurement block tid (H x, mappings.py:195)
     const Block myb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+    const Block mob = DEFER ? block_of(min(max(otid, 0), m - 1), h.nx, h.rf, h.w, h.h) : myb;
     float mean_ld[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int aa = min(a, myb.count() - 1);
-        const int cell = (h.yu + myb.y0 + aa / myb.bw) * v.W + h.xl + myb.x0 + aa % myb.bw;
-        mean_ld[a] = (!cov_only && tid < m && a < myb.count()) ? mean_env[cell] : 0.f;
+        const int aa = min(a, mob.count() - 1);
+        const int cell = (h.yu + mob.y0 + aa / mob.bw) * v.W + h.xl + mob.x0 + aa % mob.bw;
+        mean_ld[a] = (!cov_only && otid >= 0 && otid < m && a < mob.count()) ? mean_env[cell] : 0.f;
+    }
+    if (DEFER) {
+        obs_regs->gt = gt_ld[0]; obs_regs->eps = eps_ld;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) obs_regs->mean[a] = mean_ld[a];
     }
     // (c) factor: first pass of the HT gather, HT[i][k] = sum_{cells of block i} w * U[k][cell]   (m x r).
     // A column contributes only where it is stored (its tile span): cells outside hold nothing and count as zero.
@@ -346,9 +365,10 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         const int fi = tid + q * kPrepThreads;
         float gt_f = gt_ld[q];
         asm volatile("" : "+v"(gt_f));  // (conversion pinned here, see eps below: hipcc otherwise waits for this load right at its request)
-        if (!cov_only && fi < f) sub[fi] = (double)gt_f;
+        if (!DEFER && !cov_only && fi < f) sub[fi] = (double)gt_f;
     }
     prep_sync<WAVE>();
+    if constexpr (!DEFER) {
 
     // ------------------------------------------------------------------ observation + innovation
     // rf = 2: the INTER_AREA weights of both axes (orows x h and ocols x w entries, <= 2 MC each) are evaluated one
@@ -402,6 +422,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         zz[tid] = 0.0;
         vv[tid] = 0.0;
     }
+    }  // (!DEFER)
     IPP_TICK(v, 2, tick);
     if ((FRONT_ONLY || WAVE) && threadIdx.x == 0) IPP_MARK(item, 4);
 
@@ -807,6 +828,69 @@ __device__ __forceinline__ int solve_wave(const View& v, const ItemHdr& h, const
 // the rank).  HT(i,k) = ht[i*si + k*sk].  Also writes Q = -HT^T L^-1 (fp32 rows [k][QS], then 8 zero rows) when q_out is
 // not null: the consumers of k_step_pipe stream against Q, so their tile epilogue needs no L^-1.
 // mapping/mappings.py:178-197.  Same outputs as solve_wave (L^-1 / y in fp32, debug copies in fp64, header, status).
+// The observation of an item by ONE wave (DEFER mode of prepare_item_ex; the same arithmetic in the same order as the
+// block-wide code there): z = clip(INTER_AREA(ground-truth crop) + nv * eps), innovation v = z - H x into the prologue's
+// LDS scratch (zz, vv).  simulations/simulations.py:26-34, sensor_manipulations.py:7-57, mappings.py:195.
+// The caller publishes the result to the solving wave (solve_wave_fast, obs_flag).
+template <int MC>
+__device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, unsigned flags, unsigned char* small, const ObsRegs& o) {
+    const PrepLds<MC> pl(small);
+    double* L = pl.L; double* zz = pl.zz; double* vv = pl.vv; double* sub = pl.sub;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int m = h.m, f = h.f;
+    const bool cov_only = (flags & IPP_COV_ONLY) != 0;
+    if (cov_only) {
+        if (lane < MC) { zz[lane] = 0.0; vv[lane] = 0.0; }
+        wave_lds_sync();
+        return;
+    }
+    float gt_f = o.gt;
+    asm volatile("" : "+v"(gt_f));
+    if (lane < f) sub[lane] = (double)gt_f;
+    double* wyt = L;           // [orows][h.h]   (the L / Li scratch is not used by solve_wave_fast)
+    double* wxt = L + 2 * MC;  // [ocols][h.w]
+    if (h.rf > 1) {
+        const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
+        for (int idx = lane; idx < orows * h.h; idx += kWave) wyt[idx] = area_weight(h.h, orows, idx / h.h, idx % h.h);
+        for (int idx = lane; idx < ocols * h.w; idx += kWave) wxt[idx] = area_weight(h.w, ocols, idx / h.w, idx % h.w);
+    }
+    wave_lds_sync();
+    if (lane < m) {
+        const Block myb = block_of(lane, h.nx, h.rf, h.w, h.h);
+        double val;
+        if (h.rf == 1) {
+            val = sub[lane];
+        } else {
+            const int ocols = (h.h + h.rf - 1) / h.rf;
+            const int orow = lane / ocols, ocol = lane - orow * ocols;
+            val = 0.0;
+            for (int sy = 0; sy < h.h; ++sy) {
+                const double wy = wyt[orow * h.h + sy];
+                if (wy == 0.0) continue;
+                for (int sx = 0; sx < h.w; ++sx) {
+                    const double wx = wxt[ocol * h.w + sx];
+                    if (wx != 0.0) val += sub[sy * h.w + sx] * wx * wy;
+                }
+            }
+        }
+        float eps_f = o.eps;
+        asm volatile("" : "+v"(eps_f));
+        const double eps = (double)eps_f;
+        if (flags & IPP_GIVEN_OBSERVATION)
+            val = eps;
+        else
+            val = fmin(fmax(val + h.nv_d * eps, 0.0), 1.0);
+        zz[lane] = val;
+        double hx = 0.0;
+        for (int a = 0; a < myb.count(); ++a) hx += myb.weight * (double)o.mean[a];
+        vv[lane] = val - hx;
+    } else if (lane < MC) {
+        zz[lane] = 0.0;
+        vv[lane] = 0.0;
+    }
+    wave_lds_sync();
+}
+
 __device__ __forceinline__ double bcast_lane(double x, int src) {  // src: wave-uniform constant
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
@@ -816,7 +900,8 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {  // src: wave-
 template <int MC>
 __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, const int item, unsigned flags,
                                                unsigned char* small, const float* ht, int si, int sk, float* linv_f,
-                                               float* y_f, float* __restrict__ q_out, int* __restrict__ status_out) {
+                                               float* y_f, float* __restrict__ q_out, int* __restrict__ status_out,
+                                               int* obs_flag = nullptr) {
     static_assert(MC == 9, "register layout written for MC = 9");
     constexpr int LD = MC + 1;
     constexpr int QS = (MC + 3) & ~3;
@@ -923,6 +1008,9 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         status = IPP_STATUS_NOT_PD;  // factor form cannot hold an indefinite update
     }
     const bool dead = !pd;
+    if (obs_flag) {  // the innovation (and z) come from the observing wave (observe_wave)
+        while (__hip_atomic_load(obs_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+    }
     // y = L_inv^T v   (mappings.py:189,196: W v = Wc L^-T v)
     double yv = 0.0;
     if (pd && lane < m) {

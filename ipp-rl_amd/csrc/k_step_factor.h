@@ -57,10 +57,15 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     const int tid = threadIdx.x;
     if (tid == 0) IPP_MARK(item, 0);
 
-    // ---- phase A: header, observation, gather of HT(i,k) = work[k*QS + i].  While the footprint-dependent loads are
+    // ---- phase A: header, gather of HT(i,k) = work[k*QS + i].  While the footprint-dependent loads are
     // in flight the workgroup builds the prior table and the block tables (pure arithmetic on the header).
+    // MC = 9: the observation is deferred (prepare_item_ex<DEFER>): wave 1 holds its inputs and evaluates it after the
+    // barrier below, while wave 0 factors S and waves 2, 3 already stream; obs_flag publishes z / the innovation.
+    constexpr bool kDeferObs = (MC == 9);
+    int* obs_flag = reinterpret_cast<int*>(lds.red + 13);  // (red[8..15] are unused by the reduction)
+    ObsRegs oregs;
     auto mid = [&](const ItemHdr& hh) {
-        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
+        if (tid == 0) { *lds.next_tile = 0; *lds.done_waves = 0; *lds.solve_flag = 0; *obs_flag = 0; lds.red[0] = 0.0; lds.red[1] = 0.0; }
         fill_block_tables<MC>(hh, lds.fb_yx, lds.fb_w);
         if (v.rect_meta)  // rectangles of the stored columns (their loads return right behind the gather's first pass)
             for (int k = tid; k < hh.rank; k += kStepThreads) lds.stage_rect(k, (unsigned)v.colrect[(size_t)hh.env * v.rank_cap + k]);
@@ -99,9 +104,9 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
             lds.lut[i] = matern_f(dr, dc, s3, hh.sv);
         }
     };
-    ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true>(
+    ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kStepThreads, true, decltype(mid), false, false, kDeferObs>(
         v, item, env_ids, nullptr, action, prev_action, meas_noise, flags, status_out, nullptr, nullptr, nullptr, lds.small,
-        lds.work, 1, QS, nullptr, lds.Ls, nullptr, lds.ys, nullptr, lds.span_s, mid);
+        lds.work, 1, QS, nullptr, lds.Ls, nullptr, lds.ys, nullptr, lds.span_s, mid, nullptr, 0, &oregs);
     const ItemHdr h = uniform_hdr(*hs);  // (every path of the prologue ends with a barrier)
     IPP_TICK_DECL(tick);
     if (h.m == 0) {  // nothing to stream (bad footprint): no step, but a scheduled reset still happens
@@ -135,12 +140,16 @@ __global__ __launch_bounds__(kStepThreads, IPP_GF_MINWAVES) void k_step_factor(
     // ---- wave 0 finishes the m x m algebra while waves 1..3 already stream (they need L^-1 only in a tile epilogue)
     if (tid < kWave) {
         int status;
-        if constexpr (MC == 9) status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.work, 1, QS, lds.Ls, lds.ys, nullptr, status_out);
+        if constexpr (MC == 9) status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.work, 1, QS, lds.Ls, lds.ys, nullptr, status_out, obs_flag);
         else status = solve_wave<MC>(v, h, item, flags, lds.small, lds.work, lds.Ls, lds.ys, status_out);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (tid == 0) __hip_atomic_store(lds.solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         IPP_TICK(v, 5, tick);
         if (tid == 0) IPP_MARK(item, 7);  // m x m algebra done
+    } else if (kDeferObs && tid < 2 * kWave) {  // wave 1: the observation, then it streams like waves 2, 3
+        if constexpr (kDeferObs) observe_wave<MC>(v, h, flags, lds.small, oregs);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (tid == kWave) __hip_atomic_store(obs_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
     // ---- phase B
