@@ -183,7 +183,9 @@ int plan(const ipp_config& c, Layout& L) {
         // faster per step with the two pipelined over 4 chunks.  Tree steps need the fused layout.
         // With two-dimensional windows the stream of an item is short enough for that to hold at 50x50 too (32768 envs:
         // fused 22.4 M env-steps/s, split 24.7 M, split in 2 chunks 25.6 M; at 4096 envs the fused kernel stays ahead).
-        if (c.tile_threads <= 0 && c.node_capacity <= 0 && c.capacity >= 8192) L.T = 128;
+        // (Since the rectangle metadata the fused kernel is ahead up to 16384 envs of 50x50 -- 8192: 24.7 vs 23.4 M, 16384:
+        // 26.0 vs 23.7 M env-steps/s -- and the split path from 32768: 28.3 vs 26.9 M; on 100x100 the split path stays 23 % ahead.)
+        if (c.tile_threads <= 0 && c.node_capacity <= 0 && c.capacity >= ((int64_t)c.x_dim * c.y_dim >= 6000 ? 8192 : 24576)) L.T = 128;
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;

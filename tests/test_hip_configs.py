@@ -54,7 +54,7 @@ def test_fullsize_batch_invariants_subset_parity_and_reproducibility(grid, B, T,
     N, S = cfg.n_cells, 192  # S: envs also run through the exact factor mode
     full = IPPEngine(cfg, capacity=B, state="factor", rank_cap=9 * T, window_rows=-1, fixed_prior=True)
     exact = IPPEngine(cfg, capacity=S, state="factor", rank_cap=9 * T, window_rows=0)
-    # the bench's path: window from the fixed prior; k_prepare + 128-thread k_gain_factor for batches of >= 8192 envs
+    # the bench's path: window from the fixed prior; k_prepare + 128-thread k_gain_factor for large batches (>= 8192 envs on grids of >= 6000 cells, >= 24576 envs below)
     # (csrc/ipp_engine.hip plan(); the fused k_step_factor of smaller batches is covered by the configs[1] tests)
     assert full.info.window_rows == 10 and full.info.tile_threads == 128
     print(f"[{name}] arena {full.info.arena_bytes / 1e9:.1f} GB, {full.info.cov_slot_bytes / 1e6:.2f} MB of columns per env")
