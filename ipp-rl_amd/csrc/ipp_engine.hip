@@ -630,10 +630,14 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.clip_cols = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0 && L.T != 64 && cfg->x_dim > 2 * cfg->window_rows + 13) ? 1 : 0;
     if (const char* cl = getenv("IPP_CLIP_COLS")) v.clip_cols = v.clip_cols && atoi(cl) != 0;  // A/B experiments
     // rectangle tiles for committed steps where a rectangle (<= 2 R + 5 + 2 cells of alignment wide) is at most 0.4 grid rows
-    e->rect_ok = v.clip_cols && L.MC == 9 && L.VEC == 2 && cfg->x_dim % 2 == 0;
+    // (the rectangle-tile kernels carry no sqrt / exp form of the prior term: the table P0(|drow|, |dcol|) must be complete,
+    // i.e. not cut at 48 KiB -- same arithmetic as for lut_rows below)
+    const int lut_tile_rows = (v.tile_cells + cfg->x_dim - 1) / cfg->x_dim + 1;
+    const bool lut_complete = (size_t)std::min(cfg->y_dim, std::max(0, cfg->window_rows) + lut_tile_rows + 6) * cfg->x_dim <= 12288;
+    e->rect_ok = v.clip_cols && L.MC == 9 && L.VEC == 2 && cfg->x_dim % 2 == 0 && lut_complete;
     e->rect_commit = e->rect_ok && 5 * (2 * cfg->window_rows + 7) <= 2 * cfg->x_dim;
-    e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && 5 * (2 * cfg->window_rows + 5 + 2 * (L.VEC - 1)) <= 2 * cfg->x_dim;
-    if (const char* rt = getenv("IPP_RECT_TREE")) e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && atoi(rt) != 0;  // A/B experiments
+    e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && lut_complete && 5 * (2 * cfg->window_rows + 5 + 2 * (L.VEC - 1)) <= 2 * cfg->x_dim;
+    if (const char* rt = getenv("IPP_RECT_TREE")) e->rect_tree = v.clip_cols && L.MC == 9 && cfg->x_dim % L.VEC == 0 && lut_complete && atoi(rt) != 0;  // A/B experiments
     if (const char* rc = getenv("IPP_RECT")) { e->rect_commit = e->rect_ok && atoi(rc) == 2; e->rect_ok = e->rect_ok && atoi(rc) != 0; }  // A/B: 0 off, 1 predict-only, 2 always
     // Rectangle metadata (View::rect_meta, ipp_common.h): steps on rectangle tiles store the new columns on the rectangle
     // only and record it per column; every reader of stored columns masks with it.  Without it the band cells outside the

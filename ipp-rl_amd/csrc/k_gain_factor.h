@@ -337,7 +337,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     const unsigned w = rect_s[k];
                     const int r0 = w & 0xff, c0 = (w >> 8) & 0xff, r1 = r0 + (int)((w >> 16) & 0xff), c1 = c0 + (int)(w >> 24);
                     on = on && r1 >= urow0 && r0 <= urow1 && c1 >= ucol0 && c0 <= ucol1;
-                    part_sp = part_k;
+                    part_sp = part_k && w == 0xffff0000u;  // (a true rectangle lies inside its span: its test covers the span's)
                     part_k = on && (part_k || !(r0 <= urow0 && r1 >= urow1 && c0 <= ucol0 && c1 >= ucol1));
                 }
             }
@@ -377,7 +377,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             // the table covers |drow| < lut_rows: decided per tile (wave-uniform) from the farthest tile / footprint rows
             const int trow0 = urow0, trow1 = urow1;
             const int dmax = max(max(abs(trow0 - h.yu), abs(trow0 - h.yd)), max(abs(trow1 - h.yu), abs(trow1 - h.yd)));
-            const bool tile_lut = dmax < lut_rows;
+            // Rectangle tiles (MC = 9) run only on engines whose prior table covers every unit (ipp_engine.hip: rect_ok /
+            // rect_tree require the complete table; a unit lies within window_rows of the footprint, |drow| <= R + 4):
+            // the sqrt / exp variants are not compiled into those kernels -- 16 KB less code in kernels that are
+            // larger than the instruction cache of a CU pair: fused step -4.4 % (A/B in profiles/r02_experiments.txt)
+            constexpr bool kLutAll = RECT && MC == 9;
+            const bool tile_lut = kLutAll || dmax < lut_rows;
             // rf = 1 (altitude <= rf_altitude): every measurement block is one cell, the other three table entries
             // carry weight 0: skip them (wave-uniform)
             // The variants are chosen ONCE per tile (both wave-uniform): decided per lookup, every one of the up to 36 VEC
