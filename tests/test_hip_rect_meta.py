@@ -54,11 +54,13 @@ VARIANTS = {
 
 
 def run_episode(dim, B, T, steps, variant, seed=7):
+    """dim: grid size, or (x_dim, y_dim) for a non-square grid."""
     import torch
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
 
-    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    xd, yd = (dim, dim) if isinstance(dim, int) else dim
+    cfg = EngineConfig(x_dim=xd, y_dim=yd)
     with engine_env(**VARIANTS[variant]):
         env = VecIPPEnv(cfg, B, state="factor", episode_steps=T, seed=seed, stagger=True, window_rows=-1)
     env.reset()
@@ -80,7 +82,7 @@ def run_episode(dim, B, T, steps, variant, seed=7):
     return out
 
 
-@pytest.mark.parametrize("dim,B,T,steps", [(50, 48, 20, 45), (100, 24, 16, 36), (64, 16, 12, 26)])
+@pytest.mark.parametrize("dim,B,T,steps", [(50, 48, 20, 45), (100, 24, 16, 36), (64, 16, 12, 26), (51, 12, 10, 22)])
 def test_rectangle_metadata_equals_stored_zeros_and_band_tiles(dim, B, T, steps):
     import torch
 
@@ -188,3 +190,53 @@ def test_forked_slots_keep_their_rectangles():
     for e in range(B):
         assert torch.equal(eng.read_diag(e), eng.read_diag(e + B))
     assert torch.equal(eng.read_cov(3), eng.read_cov(3 + B))
+
+
+@pytest.mark.parametrize("xd,yd", [(80, 44), (44, 80)])
+def test_non_square_grids_rectangles_vs_stored_zeros_vs_exact_columns(xd, yd):
+    """Rows and columns of the rectangle are not interchangeable: non-square grids, given ground truths (the device GRF
+    needs a square grid), 14 committed steps + predict-only calls; the three builds against each other and against the
+    exact factor mode (full columns, window_rows = 0) at the parity bar."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.engine import IPPEngine
+
+    cfg = EngineConfig(x_dim=xd, y_dim=yd)
+    B, steps = 12, 14
+    rng = np.random.RandomState(11)
+    gt = torch.as_tensor(rng.uniform(size=(B, xd * yd)), dtype=torch.float32, device="cuda")
+    acts = []
+    for t in range(steps):
+        a = np.stack([rng.uniform(0, xd * cfg.resolution, B), rng.uniform(0, yd * cfg.resolution, B),
+                      rng.choice(ALTS, B)], axis=1)
+        if t % 3 == 2:  # revisit the previous neighbourhood: partially overlapping rectangles
+            a[:, :2] = acts[-1][:, :2] + rng.uniform(-12, 12, (B, 2))
+            a[:, 0] = np.clip(a[:, 0], 0, xd * cfg.resolution - 1e-3)
+            a[:, 1] = np.clip(a[:, 1], 0, yd * cfg.resolution - 1e-3)
+        acts.append(a)
+    noise = torch.as_tensor(rng.normal(size=(steps, B, 9)), dtype=torch.float32, device="cuda")
+    out = {}
+    for name in list(VARIANTS) + ["exact"]:
+        with engine_env(**VARIANTS.get(name, {})):
+            eng = IPPEngine(cfg, capacity=B, state="factor", window_rows=0 if name == "exact" else -1)
+        eng.reset(gt=gt)
+        prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+        rewards = []
+        for t in range(steps):
+            a = torch.as_tensor(acts[t], dtype=torch.float64, device="cuda")
+            if t % 4 == 1:
+                rp, sp = eng.step(a, prev, predict_only=True)
+                assert int(sp.abs().sum()) == 0
+                rewards.append(rp.clone())
+            r, s_ = eng.step(a, prev, meas_noise=noise[t])
+            assert int(s_.abs().sum()) == 0
+            rewards.append(r.clone())
+            prev = a
+        out[name] = dict(rewards=torch.stack(rewards), mean=torch.stack([eng.read_mean(e) for e in range(B)]),
+                         diag=torch.stack([eng.read_diag(e) for e in range(B)]), cov=eng.read_cov(B - 1).clone())
+        eng.close()
+    a, z, b, x = out["rect_meta"], out["rect_zeros"], out["band"], out["exact"]
+    for key in ("rewards", "mean", "diag", "cov"):
+        assert torch.equal(a[key], z[key]), key
+        assert np.allclose(host(a[key]), host(b[key]), rtol=0, atol=3e-6), key
+        assert np.allclose(host(a[key]), host(x[key]), rtol=0, atol=1e-5), (key, np.abs(host(a[key]) - host(x[key])).max())
