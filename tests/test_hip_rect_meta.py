@@ -240,3 +240,62 @@ def test_non_square_grids_rectangles_vs_stored_zeros_vs_exact_columns(xd, yd):
         assert torch.equal(a[key], z[key]), key
         assert np.allclose(host(a[key]), host(b[key]), rtol=0, atol=3e-6), key
         assert np.allclose(host(a[key]), host(x[key]), rtol=0, atol=1e-5), (key, np.abs(host(a[key]) - host(x[key])).max())
+
+
+def _short_run(xd, window, env=None, steps=6, B=6, tree=False):
+    """A few committed steps (every second one next to the previous) and, optionally, three chained tree steps."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.engine import IPPEngine
+
+    cfg = EngineConfig(x_dim=xd, y_dim=xd)
+    with engine_env(**(env or {})):
+        eng = IPPEngine(cfg, capacity=B, state="factor", window_rows=window, rank_cap=9 * (steps + 8), node_capacity=4 * B if tree else 0)
+    rng = np.random.RandomState(5)
+    eng.reset(gt=torch.as_tensor(rng.uniform(size=(B, xd * xd)), dtype=torch.float32, device="cuda"))
+    prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+    rewards = []
+    for t in range(steps):
+        a = np.stack([rng.uniform(0, xd * 4, B), rng.uniform(0, xd * 4, B), rng.choice(ALTS, B)], axis=1)
+        if t % 2:
+            a[:, :2] = np.clip(prev.cpu().numpy()[:, :2] + rng.uniform(-10, 10, (B, 2)), 0, xd * 4 - 1e-3)
+        a = torch.as_tensor(a, dtype=torch.float64, device="cuda")
+        r, s_ = eng.step(a, prev, meas_noise=torch.zeros((B, 9), device="cuda"))
+        assert int(s_.abs().sum()) == 0
+        rewards.append(r.clone())
+        prev = a
+    out = [torch.stack(rewards), torch.stack([eng.read_diag(e) for e in range(B)]), torch.stack([eng.read_mean(e) for e in range(B)])]
+    if tree:
+        roots = torch.arange(B, dtype=torch.int32, device="cuda")
+        path = torch.full((B, 6), -1, dtype=torch.int32, device="cuda")
+        for d in range(3):
+            a = prev.clone()
+            a[:, 0] = (a[:, 0] + 9.0 * (d + 1)) % (xd * 4)
+            a[:, 2] = ALTS[(3 * d + 4) % 10]
+            ids = torch.arange(d * B, (d + 1) * B, dtype=torch.int32, device="cuda")
+            r, s_ = eng.tree_step(roots, path, a, prev, ids)
+            assert int(s_.abs().sum()) == 0
+            path[:, d] = ids
+            prev = a
+            out += [r.clone(), eng.tree_diag(int(ids[0])).clone()]
+    eng.close()
+    return out
+
+
+def _worst(a, b):
+    return max(float((x.double() - y.double()).abs().max()) for x, y in zip(a, b))
+
+
+def test_shapes_at_the_edges_of_the_rectangle_rules():
+    """Where the engine's rules switch (csrc/ipp_engine.hip): a window of 40 rows at 100x100 (rectangles 85 cells wide), a
+    260x260 grid (beyond the 8-bit rectangle coordinates: metadata off, rectangle tiles with stored zeros for tree steps,
+    band tiles for env steps), 200x200 tree steps (256-cell tiles: env columns written on band tiles, node columns on
+    rectangles)."""
+    w40 = _short_run(100, 40, steps=10)
+    assert _worst(w40, _short_run(100, 0, steps=10)) <= 1e-5              # vs exact factor columns
+    assert _worst(w40, _short_run(100, 40, {"IPP_RECT_META": 0, "IPP_RECT": 0}, steps=10)) <= 3e-6
+    big = _short_run(260, -1, tree=True)
+    assert _worst(big, _short_run(260, -1, {"IPP_RECT_TREE": 0, "IPP_RECT": 0}, tree=True)) <= 3e-6
+    assert _worst(big[:3], _short_run(260, 0)) <= 1e-5
+    t200 = _short_run(200, -1, tree=True)
+    assert _worst(t200, _short_run(200, -1, {"IPP_RECT_META": 0}, tree=True)) == 0.0
