@@ -200,11 +200,41 @@ __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& a
     float* diag = v.diag + (size_t)env * v.Npad;
     float* gt = v.gt + (size_t)env * v.Npad;
     const float* src = ar.gt + (size_t)k * v.N;
-    for (int c = lane; c < v.Npad; c += kWave) {
-        const bool valid = c < v.N;
-        mean[c] = valid ? 0.5f : 0.f;
-        diag[c] = valid ? sv : 0.f;
-        gt[c] = valid ? src[c] : 0.f;
+    if ((v.N & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15ull) == 0ull) {
+        // four cells per lane and instruction, the ground-truth loads of a pass all in flight before the first store: written one
+        // cell per lane with the load inside the loop, the wave waited for ~40 dependent round trips (~80 us at 50x50) with
+        // its workgroup's slot held -- resets folded into the step launch cost more than their own kernel
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4* mean4 = reinterpret_cast<float4*>(mean);
+        float4* diag4 = reinterpret_cast<float4*>(diag);
+        float4* gt4 = reinterpret_cast<float4*>(gt);
+        const int n4 = v.N / 4, np4 = v.Npad / 4;
+        constexpr int kU = 8;
+        for (int c0 = lane; c0 < np4; c0 += kU * kWave) {
+            float4 g[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int c = c0 + u * kWave;
+                g[u] = (c < n4) ? src4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int c = c0 + u * kWave;
+                if (c < np4) {
+                    const bool valid = c < n4;
+                    mean4[c] = valid ? make_float4(0.5f, 0.5f, 0.5f, 0.5f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    diag4[c] = valid ? make_float4(sv, sv, sv, sv) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    gt4[c] = g[u];
+                }
+            }
+        }
+    } else {
+        for (int c = lane; c < v.Npad; c += kWave) {
+            const bool valid = c < v.N;
+            mean[c] = valid ? 0.5f : 0.f;
+            diag[c] = valid ? sv : 0.f;
+            gt[c] = valid ? src[c] : 0.f;
+        }
     }
     if (lane == 0) {
         v.rank[env] = 0;
