@@ -680,7 +680,10 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
     if (lane == 0 && extra) atomicAdd(cnt + 1, extra);
     int reset_k = -1;
     if (RESET && ar->src) reset_k = __builtin_amdgcn_readfirstlane(ar->src[item]);
-    if (RESET && reset_k >= 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores / atomics have landed
+    // this wave's stores / atomics have landed (acknowledged by L2) before the last wave rewrites the env's planes: an
+    // explicit wait, not an agent-scope release fence -- that one also writes the XCD's L2 back (buffer_wbl2), once per
+    // wave of every resetting item: +13 us per fused step kernel (profiles/r02_experiments.txt)
+    if (RESET && reset_k >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int arrived = 0;
     if (lane == 0) arrived = atomicAdd(done_waves, 1);
