@@ -66,8 +66,10 @@ def build_parser():
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--predict-only", action="store_true", help="time the predict-only rate (tree-search call)")
-    ap.add_argument("--fused-resets", action="store_true",
-                    help="A/B: scheduled episode resets inside the step launch (ipp_step_autoreset) instead of their own launch")
+    ap.add_argument("--fused-resets", action="store_true", default=True,
+                    help="scheduled episode resets inside the step launch (ipp_step_autoreset; VecIPPEnv's default)")
+    ap.add_argument("--no-fused-resets", dest="fused_resets", action="store_false",
+                    help="A/B: the scheduled resets as their own launch after every step")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
     return ap
 
@@ -258,7 +260,7 @@ def pmc_traffic(kernel_name, key):
 
 # --------------------------------------------------------------------------------------------- the measurement
 def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_envs, episode_steps, state="factor",
-                     window_rows=-1, shuffle_prior=False, tile_threads=0, predict_only=False, fused_resets=False,
+                     window_rows=-1, shuffle_prior=False, tile_threads=0, predict_only=False, fused_resets=True,
                      steps=80, warmup=8, timed=True):
     """One workload: build the batched env, pre-roll to the stationary rank mix, W warm-up steps, the timed region
     (all ranks), then the roofline leg (same steps again with HIP events on the streaming kernel's dispatches).

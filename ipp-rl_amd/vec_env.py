@@ -58,7 +58,7 @@ class VecIPPEnv:
     def __init__(self, cfg: EngineConfig, num_envs: int, state: str = "factor", episode_steps: int = 40,
                  device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
                  rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
-                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0, fused_reset: bool = False):
+                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0, fused_reset: bool = True):
         import torch
 
         self.torch = torch
@@ -96,10 +96,15 @@ class VecIPPEnv:
             self._reset_ids_host = [np.nonzero(ph == p)[0].astype(np.int32) for p in range(self.episode_steps)]
             self._reset_ids_by_phase = [torch.as_tensor(i, device=dev) for i in self._reset_ids_host]
         # fused_reset: scheduled resets folded into the step launch (ipp_step_autoreset): per phase, the index of every
-        # env's new ground truth among the staged fields, -1 for the envs that carry on (built on first use).  Off by
-        # default: the envs that reset are the highest-rank items of the launch, the ones its tail waits for, and
-        # their extra work costs more (4096 envs: +15 us per step) than the separate reset launch it saves
+        # env's new ground truth among the staged fields, -1 for the envs that carry on (built on first use).  On by default
+        # since (a) the waves of a resetting item wait for their own stores instead of an agent-scope release fence (which
+        # wrote the L2 back: +13 us per step kernel) and (b) the staging meets the main stream once per block of steps, not
+        # once per step: 4096 envs of 50x50: 23.1-23.9 M env-steps/s against 22.6 M with the separate reset launch.
+        # Not with shuffled priors (the reset kernel installs the per-episode prior scales).
+        # Only where the engine runs the fused step kernel: on the split path of large batches (k_prepare + k_gain_factor in
+        # chunks) the resets are a launch of their own either way and the folded form is slower (32768 envs: 24.9 vs 28.7 M).
         self._fused_reset = bool(fused_reset and stagger and state == "factor" and not shuffle_prior_cov and
+                                 self.engine.info.tile_threads == 256 and self.engine.info.window_rows > 0 and
                                  4 * B * self.episode_steps <= (64 << 20))
         self._reset_src_by_phase = {}
         self._prior_ring = {}
@@ -108,16 +113,24 @@ class VecIPPEnv:
         # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
         # for the resets after step t+1 is started at the beginning of step t, so it has two steps to finish
         self._side = torch.cuda.Stream(device=dev) if stagger else None
-        self._pending = None      # (ids, buffer, n) staged for the resets at the end of the current step
-        self._pending_for = -1    # step index the staged fields belong to
+        # Staging in BLOCKS of K steps: the fields of all resets of block b + 1 are generated while block b runs, into one of
+        # two buffer sets, and the streams meet ONCE per block (main waits for the block's `ready` event before its first step
+        # and records `free` behind its last; the side stream waits for `free` before it refills the set).  With an event
+        # wait and an event record per step the stream protocol cost 12-20 us of every step (4096 envs of 50x50: 0.186 ms per
+        # step against 0.171 without events, profiles/r02_experiments.txt).  2 K <= episode_steps: within the staging
+        # horizon an env resets at most once, so its episode counter read at staging time names the right ground truth.
         if stagger:
             n_max = max(int(i.numel()) for i in self._reset_ids_by_phase)
-            self._staged = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
-            self._staged_white = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
-            self._staged_ready = [torch.cuda.Event() for _ in range(2)]
-            self._staged_free = [torch.cuda.Event() for _ in range(2)]
-            for ev in self._staged_free:
+            K = max(1, min(8, self.episode_steps // 2, (256 << 20) // max(1, n_max * cfg.n_cells * 8)))
+            self._blk_K = K
+            self._staged = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2 * K)]
+            self._staged_white = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2 * K)]
+            self._blk_ready = [torch.cuda.Event() for _ in range(2)]
+            self._blk_free = [torch.cuda.Event() for _ in range(2)]
+            for ev in self._blk_free:
                 ev.record(torch.cuda.current_stream(dev))
+            self._blk_tag = [-1, -1]   # block index staged in each buffer set
+            self._blk_waited = -1      # block whose `ready` event the main stream has waited for
         # measurement noise for NOISE_RING steps per generator launch
         self._noise_ring = torch.empty((self.NOISE_RING, B, self.engine.meas_cap), dtype=torch.float32, device=dev)
         self._noise_pos = 0
@@ -187,6 +200,7 @@ class VecIPPEnv:
         if _phase is not None:
             self.episode[self._reset_ids_host[_phase]] += 1
         else:
+            self._invalidate_staging()
             if env_ids is None:
                 self.episode += 1
             elif not torch.is_tensor(env_ids):
@@ -206,20 +220,32 @@ class VecIPPEnv:
         """Phase whose envs finish their episode with step index t: env e has done (t + 1 + phase_e) steps."""
         return (self.episode_steps - ((t + 1) % self.episode_steps)) % self.episode_steps
 
-    def _stage(self, t: int):
-        """Start, on the side stream, the ground truths for the resets at the end of step index t."""
+    def _stage_block(self, b: int):
+        """Start, on the side stream, the ground truths of every reset of the steps [b K, (b + 1) K) into buffer set b % 2."""
         torch = self.torch
-        p = self._phase_ending_at(t)
-        n = int(self._reset_ids_by_phase[p].numel())
-        if n == 0:
-            return None
-        k = t % 2
-        self._side.wait_event(self._staged_free[k])
+        K, set_ = self._blk_K, b % 2
+        self._side.wait_event(self._blk_free[set_])
         with torch.cuda.stream(self._side):
-            white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white[k][:n])
-            self.engine.generate_grf(white, out=self._staged[k][:n], stream=self._side)
-            self._staged_ready[k].record(self._side)
-        return (p, k, n)
+            for j in range(K):
+                p = self._phase_ending_at(b * K + j)
+                n = int(self._reset_ids_by_phase[p].numel())
+                if n == 0:
+                    continue
+                buf = set_ * K + j
+                white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white[buf][:n])
+                self.engine.generate_grf(white, out=self._staged[buf][:n], stream=self._side)
+            self._blk_ready[set_].record(self._side)
+        self._blk_tag[set_] = b
+
+    def _invalidate_staging(self):
+        """A reset outside the schedule moved episode counters: staged fields may name the wrong episodes."""
+        if self._side is None:
+            return
+        main = self.torch.cuda.current_stream(self.device)
+        for set_ in range(2):
+            self._blk_tag[set_] = -1
+            self._blk_free[set_].record(main)  # (everything that read the set is in front of this point of the stream)
+        self._blk_waited = -1
 
     GT_STREAM, NOISE_STREAM = 1 << 40, 2 << 40  # subsequence = stream kind + episode index / step index
 
@@ -258,11 +284,23 @@ class VecIPPEnv:
         a = self.engine._dev(actions, torch.float64).reshape(-1, 3)
         main = torch.cuda.current_stream(self.device)
         scheduled = None
+        blk = None
         if auto_reset and self._reset_ids_by_phase is not None:
-            if self._pending_for != self.t:  # first step (or the schedule was disturbed): stage for this step now
-                self._pending, self._pending_for = self._stage(self.t), self.t
-            scheduled = self._pending
-            self._pending, self._pending_for = self._stage(self.t + 1), self.t + 1
+            K = self._blk_K
+            b, j = divmod(self.t, K)
+            set_ = b % 2
+            if self._blk_tag[set_] != b:  # first step (or the schedule was disturbed): stage this block now
+                self._stage_block(b)
+                self._blk_waited = -1
+            if self._blk_waited != b:
+                main.wait_event(self._blk_ready[set_])
+                self._blk_waited = b
+            if self._blk_tag[1 - set_] != b + 1:  # the next block's fields are generated while this block runs
+                self._stage_block(b + 1)
+            p = self._phase_ending_at(self.t)
+            n = int(self._reset_ids_by_phase[p].numel())
+            scheduled = (p, set_ * K + j, n) if n > 0 else None
+            blk = (set_, j == K - 1)
         if meas_noise is None:
             if self._noise_pos == 0:
                 # plane p of the ring = step (fills * NOISE_RING + p); row = global env id
@@ -276,9 +314,8 @@ class VecIPPEnv:
         # full-batch steps let the kernel store the new previous waypoint (IPP_UPDATE_PREV): no copy launch; with staged
         # ground truths the scheduled resets ride in the same launch as well (ipp_step_autoreset)
         fused = None
-        if self._fused_reset and env_ids is None and scheduled is not None and scheduled[1] is not None:
+        if self._fused_reset and env_ids is None and scheduled is not None:
             p, k, n = scheduled
-            main.wait_event(self._staged_ready[k])
             fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
         if self._orders is not None and env_ids is None:
             # heaviest items first: an env's stored columns grow with the steps since its reset
@@ -287,7 +324,6 @@ class VecIPPEnv:
                          use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status,
                          update_prev=env_ids is None, **(fused or {}))
         if fused is not None:
-            self._staged_free[scheduled[1]].record(main)
             self.episode[self._reset_ids_host[scheduled[0]]] += 1
             scheduled = None
         if env_ids is not None:
@@ -297,12 +333,9 @@ class VecIPPEnv:
             after_step_hook()
         if scheduled is not None:
             p, k, n = scheduled
-            if k is None:
-                self.reset(_phase=p)
-            else:
-                main.wait_event(self._staged_ready[k])
-                self.reset(gt=self._staged[k][:n], _phase=p)
-                self._staged_free[k].record(main)
+            self.reset(gt=self._staged[k][:n], _phase=p)
+        if blk is not None and blk[1]:
+            self._blk_free[blk[0]].record(main)  # last step of the block: its buffer set may be refilled
         return self.reward, self.status
 
     # ------------------------------------------------------------------ views
