@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 8
+#define IPP_ABI_VERSION 9
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -185,6 +185,16 @@ int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const dou
 int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const double* action, double* prev_action,
                        const float* meas_noise, uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src,
                        const float* reset_gt, const double* init_action, void* stream);
+
+/*
+ * Priors of the episodes that the following ipp_step_autoreset launches start: prior [dev] double[..][2] = (sigma^2, l)
+ * of the episode that takes ground truth reset_gt[k] -- Mapping.init_priors with shuffle_prior_cov
+ * (mapping/mappings.py:235-240: 0.8 .. 1.2 x the config's values per episode), the same numbers ipp_reset_episode takes
+ * as prior_scale.  NULL (default): the config's prior.  The pointer is kept, not copied: it has to stay valid until the
+ * launches that use it have run.  A length scale beyond what the column window was sized for poisons the env with NaN,
+ * as in ipp_reset_episode.
+ */
+int ipp_set_reset_prior(void* engine, const double* prior);
 
 /*
  * Reward of n candidate actions from the CURRENT state of ONE env slot; nothing is written.  The call of

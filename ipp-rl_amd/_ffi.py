@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class IppConfig(C.Structure):
@@ -107,6 +107,7 @@ PROTOTYPES = {
     "ipp_set_uav": (C.c_int, [_P, C.c_double, C.c_double]),
     "ipp_set_adaptive": (C.c_int, [_P, C.c_double, C.c_double]),
     "ipp_set_item_order": (C.c_int, [_P, _P, C.c_int32]),
+    "ipp_set_reset_prior": (C.c_int, [_P, _P]),
     "ipp_fork": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "ipp_read_mean": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_read_diag": (C.c_int, [_P, C.c_int32, _P, _P]),

@@ -187,6 +187,7 @@ struct View {
 struct AutoReset {
     const int* src;     // [n] or NULL (no resets in this launch)
     const float* gt;    // [..][N]
+    const double* prior; // [..][2] prior (sigma^2, l) of the new episode that takes ground truth k, or NULL: the config's (ipp_set_reset_prior)
     double* prev;       // [capacity][3] indexed by env id, or NULL
     double init[3];
 };
@@ -195,7 +196,12 @@ struct AutoReset {
 // installs ground truth field k.  The caller guarantees that every earlier store / atomic to the env's planes
 // has completed.
 __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& ar, int env, int k, int lane) {
-    const float sv = (float)v.sv0;
+    // (prior of the new episode like k_reset_small: shuffle_prior_cov scales, mappings.py:238-240; a length scale the column
+    // window was not sized for poisons the env instead of losing accuracy silently)
+    double sv_d = ar.prior ? ar.prior[2 * k + 0] : v.sv0, ls_d = ar.prior ? ar.prior[2 * k + 1] : v.ls0;
+    if (v.ls_max > 0.0 && ls_d > v.ls_max * (1.0 + 1e-12)) sv_d = ls_d = NAN;
+    const float sv = (float)sv_d;
+    const float m0 = isnan(sv_d) ? NAN : 0.5f;
     float* mean = v.mean + (size_t)env * v.Npad;
     float* diag = v.diag + (size_t)env * v.Npad;
     float* gt = v.gt + (size_t)env * v.Npad;
@@ -222,7 +228,7 @@ __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& a
                 const int c = c0 + u * kWave;
                 if (c < np4) {
                     const bool valid = c < n4;
-                    mean4[c] = valid ? make_float4(0.5f, 0.5f, 0.5f, 0.5f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    mean4[c] = valid ? make_float4(m0, m0, m0, m0) : make_float4(0.f, 0.f, 0.f, 0.f);
                     diag4[c] = valid ? make_float4(sv, sv, sv, sv) : make_float4(0.f, 0.f, 0.f, 0.f);
                     gt4[c] = g[u];
                 }
@@ -231,15 +237,15 @@ __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& a
     } else {
         for (int c = lane; c < v.Npad; c += kWave) {
             const bool valid = c < v.N;
-            mean[c] = valid ? 0.5f : 0.f;
+            mean[c] = valid ? m0 : 0.f;
             diag[c] = valid ? sv : 0.f;
             gt[c] = valid ? src[c] : 0.f;
         }
     }
     if (lane == 0) {
         v.rank[env] = 0;
-        v.prior[2 * env + 0] = v.sv0;
-        v.prior[2 * env + 1] = v.ls0;
+        v.prior[2 * env + 0] = sv_d;
+        v.prior[2 * env + 1] = ls_d;
     }
     if (ar.prev && lane < 3) ar.prev[3 * env + lane] = ar.init[lane];
 }

@@ -81,6 +81,7 @@ struct Engine {
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
+    const double* reset_prior = nullptr;  // ipp_set_reset_prior: priors of the episodes started by ipp_step_autoreset
     bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
     bool rect_commit = false;  // ... used for committed steps too (else for predict-only calls only)
     bool rect_tree = false;    // tree steps on rectangle tiles (same width rule; either tile size)
@@ -918,7 +919,7 @@ static int step_impl(void* engine, const int32_t* env_ids, const int32_t* dst_id
     }
     // the fused kernel resets the flagged envs itself; every other path gets a separate launch behind the step
     const bool in_kernel = e->fused;
-    const AutoReset none = {nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
+    const AutoReset none = {nullptr, nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
     int rc;
     if (e->v.meas_cap == 9)
         rc = (e->v.vec == 2) ? launch_step<9, 2>(e, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, s, in_kernel ? ar : none)
@@ -935,7 +936,7 @@ static int step_impl(void* engine, const int32_t* env_ids, const int32_t* dst_id
 int ipp_step(void* engine, const int32_t* env_ids, const int32_t* dst_ids, int32_t n, const double* action,
              const double* prev_action, const float* meas_noise, uint32_t flags, float* reward, int32_t* status,
              void* stream) {
-    const AutoReset none = {nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
+    const AutoReset none = {nullptr, nullptr, nullptr, nullptr, {0.0, 0.0, 0.0}};
     return step_impl(engine, env_ids, dst_ids, n, action, prev_action, meas_noise, flags, reward, status, stream, none);
 }
 
@@ -947,7 +948,7 @@ int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const do
     if (e->v.mode != IPP_FACTOR) return fail(-1, "ipp_step_autoreset: factor state only (dense engines: ipp_step + ipp_reset_episode)");
     if (flags & IPP_PREDICT_ONLY) return fail(-1, "ipp_step_autoreset: not with IPP_PREDICT_ONLY");
     if (reset_src && (!reset_gt || !init_action)) return fail(-1, "reset_src needs reset_gt and init_action");
-    AutoReset ar = {reset_src, reset_gt, reset_src ? prev_action : nullptr, {0.0, 0.0, 0.0}};
+    AutoReset ar = {reset_src, reset_gt, reset_src ? e->reset_prior : nullptr, reset_src ? prev_action : nullptr, {0.0, 0.0, 0.0}};
     if (init_action) for (int k = 0; k < 3; ++k) ar.init[k] = init_action[k];
     return step_impl(engine, env_ids, nullptr, n, action, prev_action, meas_noise, flags, reward, status, stream, ar);
 }
@@ -1001,6 +1002,13 @@ int ipp_set_item_order(void* engine, const int32_t* order, int32_t n) {
     if (order && (n <= 0 || n > e->v.max_batch)) return fail(-1, "n = %d outside [1, max_batch = %d]", n, e->v.max_batch);
     e->v.item_order = order;
     e->v.item_order_n = order ? n : 0;
+    return 0;
+}
+
+int ipp_set_reset_prior(void* engine, const double* prior) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    e->reset_prior = prior;
     return 0;
 }
 

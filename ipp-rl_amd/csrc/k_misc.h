@@ -42,18 +42,20 @@ __global__ void k_reset_flagged(View v, const int* __restrict__ env_ids, int n_i
     if (k < 0) return;
     const int env = env_ids ? env_ids[item] : item;
     if (env < 0 || env >= v.cap) return;
+    double sv = ar.prior ? ar.prior[2 * k + 0] : v.sv0, ls = ar.prior ? ar.prior[2 * k + 1] : v.ls0;
+    if (v.ls_max > 0.0 && ls > v.ls_max * (1.0 + 1e-12)) sv = ls = NAN;  // (like k_reset_small)
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell == 0) {
         v.rank[env] = 0;
-        v.prior[2 * env + 0] = v.sv0;
-        v.prior[2 * env + 1] = v.ls0;
+        v.prior[2 * env + 0] = sv;
+        v.prior[2 * env + 1] = ls;
         if (ar.prev)
             for (int j = 0; j < 3; ++j) ar.prev[3 * env + j] = ar.init[j];
     }
     if (cell >= v.Npad) return;
     const bool valid = cell < v.N;
-    v.mean[(size_t)env * v.Npad + cell] = valid ? 0.5f : 0.f;
-    v.diag[(size_t)env * v.Npad + cell] = valid ? (float)v.sv0 : 0.f;
+    v.mean[(size_t)env * v.Npad + cell] = valid ? (isnan(sv) ? NAN : 0.5f) : 0.f;
+    v.diag[(size_t)env * v.Npad + cell] = valid ? (float)sv : 0.f;
     v.gt[(size_t)env * v.Npad + cell] = valid ? ar.gt[(size_t)k * v.N + cell] : 0.f;
 }
 

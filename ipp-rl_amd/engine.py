@@ -397,6 +397,13 @@ class IPPEngine:
         self._order = o
         _ffi.check(self._lib.ipp_set_item_order(self._h, self._ptr(o), int(o.numel())))
 
+    def set_reset_prior(self, prior):
+        """Priors (sigma^2, l) of the episodes started by the following fused resets (step(reset_src=...)): device float64
+        [k, 2] aligned with reset_gt, kept alive by the reference here; None = the config's prior (ipp_set_reset_prior)."""
+        p = None if prior is None else self._dev(prior, _torch().float64)
+        self._reset_prior = p
+        _ffi.check(self._lib.ipp_set_reset_prior(self._h, self._ptr(p)))
+
     def set_adaptive(self, value_threshold: float, interval_factor: float):
         _ffi.check(self._lib.ipp_set_adaptive(self._h, float(value_threshold), float(interval_factor)))
 

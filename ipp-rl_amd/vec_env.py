@@ -100,10 +100,13 @@ class VecIPPEnv:
         # since (a) the waves of a resetting item wait for their own stores instead of an agent-scope release fence (which
         # wrote the L2 back: +13 us per step kernel) and (b) the staging meets the main stream once per block of steps, not
         # once per step: 4096 envs of 50x50: 23.1-23.9 M env-steps/s against 22.6 M with the separate reset launch.
-        # Not with shuffled priors (the reset kernel installs the per-episode prior scales).
+        # Shuffled priors can ride along (ipp_set_reset_prior: the per-episode (sigma^2, l) of every staged ground truth).
         # Only where the engine runs the fused step kernel: on the split path of large batches (k_prepare + k_gain_factor in
         # chunks) the resets are a launch of their own either way and the folded form is slower (32768 envs: 24.9 vs 28.7 M).
-        self._fused_reset = bool(fused_reset and stagger and state == "factor" and not shuffle_prior_cov and
+        # (with shuffled priors the folded form is available -- fused_reset="always" -- but not the default: measured equal
+        # to the separate launch, 19.4-19.5 vs 19.3-20.3 M env-steps/s at window 12)
+        self._fused_reset = bool(fused_reset and stagger and state == "factor" and
+                                 (not shuffle_prior_cov or fused_reset == "always") and
                                  self.engine.info.tile_threads == 256 and self.engine.info.window_rows > 0 and
                                  4 * B * self.episode_steps <= (64 << 20))
         self._reset_src_by_phase = {}
@@ -317,6 +320,8 @@ class VecIPPEnv:
         if self._fused_reset and env_ids is None and scheduled is not None:
             p, k, n = scheduled
             fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
+            if self.shuffle_prior_cov:  # priors of the episodes this launch starts, row i for staged field i
+                self.engine.set_reset_prior(self._prior_scale_scheduled(p))
         if self._orders is not None and env_ids is None:
             # heaviest items first: an env's stored columns grow with the steps since its reset
             self.engine.set_item_order(self._orders[self.t % self.episode_steps])

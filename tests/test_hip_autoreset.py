@@ -69,14 +69,18 @@ def test_step_autoreset_equals_step_then_reset(window_rows, tile_threads):
     assert torch.equal(ra, rb)
 
 
-def test_vec_env_fused_resets_equal_separate_resets():
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_vec_env_fused_resets_equal_separate_resets(shuffle):
+    """shuffle: per-episode prior scales (shuffle_prior_cov) installed by the folded reset (ipp_set_reset_prior) vs by the
+    reset kernel; the priors themselves are compared through the diagonals right after a reset and the later rewards."""
     import torch
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
 
     cfg = EngineConfig(x_dim=50, y_dim=50)
     B, T = 4096, 8  # full-size batch: races show at this scale, not at 64 envs
-    envs = [VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=12, seed=5, fused_reset=f) for f in (True, False)]
+    envs = [VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=12, seed=5, fused_reset=f, shuffle_prior_cov=shuffle)
+            for f in ("always", False)]
     assert envs[0]._fused_reset and not envs[1]._fused_reset
     for env in envs:
         env.reset()
@@ -92,4 +96,5 @@ def test_vec_env_fused_resets_equal_separate_resets():
     assert np.array_equal(envs[0].episode, envs[1].episode)
     for e in (0, 7, 63):
         assert torch.equal(envs[0].mean(e), envs[1].mean(e))
+        assert torch.equal(envs[0].diag(e), envs[1].diag(e))
         assert torch.equal(envs[0].ground_truth(e), envs[1].ground_truth(e))
