@@ -332,6 +332,8 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
             tt = int(eng.info.tile_threads)
             fused = tt == 256 and os.environ.get("IPP_FUSED", "1") != "0"
             kernel_name = "k_step_factor" if fused else ("k_gain_wave" if tt == 64 else "k_gain_factor")
+            if int(eng.info.patch_layout):
+                kernel_name = "k_step_patch"
     else:
         per_step = (4.0 * N * 25 + 8.0 * N) if predict_only else (8.0 * N * N + 16.0 * N)
         kernel_ms, kernel_name = (gain_ms, "k_gain") if predict_only else (down_ms, "k_downdate")

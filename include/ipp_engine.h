@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 9
+#define IPP_ABI_VERSION 10
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -104,6 +104,8 @@ typedef struct ipp_info {
     uint64_t arena_bytes;     /* total bytes the engine carves from the caller's arena */
     uint64_t cov_slot_bytes;  /* bytes of covariance state per env slot */
     uint64_t step_lds_bytes;  /* dynamic LDS per workgroup of the streaming step kernel (occupancy: 160 KiB per CU) */
+    int32_t fused_step;       /* 1: ipp_step is ONE fused kernel per launch (ipp_step_autoreset folds the resets into it) */
+    int32_t patch_layout;     /* 1: factor columns stored as compact patches of their rectangles (k_step_patch.h) */
 } ipp_info;
 
 /* Debug / test view of the last ipp_step's per-item prologue (host struct, filled by ipp_debug_step_item). */

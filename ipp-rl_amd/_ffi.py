@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class IppConfig(C.Structure):
@@ -38,6 +38,7 @@ class IppInfo(C.Structure):
         ("abi_version", C.c_int32), ("n_cells", C.c_int32), ("n_pad", C.c_int32), ("tile_threads", C.c_int32),
         ("n_tiles", C.c_int32), ("meas_cap", C.c_int32), ("fp_cap", C.c_int32), ("window_rows", C.c_int32),
         ("arena_bytes", C.c_uint64), ("cov_slot_bytes", C.c_uint64), ("step_lds_bytes", C.c_uint64),
+        ("fused_step", C.c_int32), ("patch_layout", C.c_int32),
     ]
 
 

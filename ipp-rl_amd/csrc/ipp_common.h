@@ -157,6 +157,15 @@ struct View {
     int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
     int* colrect;    // factor: [cap][rank_cap]  rectangle of every column of U inside its tile span (rect_pack)
     int rect_meta;   // 1: steps on rectangle tiles write no zeros outside the rectangle; readers mask with colrect
+    // PATCH layout of the windowed factor columns (k_step_patch.h): stored column k of an env is the compact patch of its
+    // rectangle, ph x pw floats with the fixed row stride pw, at cov + env * cov_slot + k * pstride
+    int patch;       // 1: patch layout (then rect_meta == 1 and colrect holds every column's rectangle)
+    int pw, ph;      // patch width (cells, even) and height (rows)
+    int pstride;     // floats per stored column: ph * pw rounded up to 16
+    int pdiv;        // ceil(65536 / pw): flat / pw == (flat * pdiv) >> 16 for every flat index of a patch
+    int plw;         // the prior table of the patch kernel is P0(|drow| < plw, |dcol| < plw)
+    int pcap;        // column records per item kept in LDS (the rest in the item's global scratch block)
+    int punits;      // most (64 lanes x 2 cells) units of one patch
     // kCountSlots slots of 16 words (128 B apart): a workgroup adds its totals to slot (item % kCountSlots), word 0 =
     // streamed floats (SURVEY 8(d) count), word 8 = floats re-read for the mask.  One address for all workgroups cost
     // 5 % (one counter) / 19 % (two) of the fused step kernel: the waves' exits queued up behind same-address atomics.

@@ -17,6 +17,7 @@
 #include "k_gain.h"
 #include "k_gain_factor.h"
 #include "k_step_factor.h"
+#include "k_step_patch.h"
 #include "k_step_pipe.h"
 #include "k_gain_wave.h"
 #include "k_misc.h"
@@ -80,6 +81,8 @@ struct Engine {
     bool profile = false;
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
+    bool patch = false;   // k_step_patch on compact column patches (View::patch)
+    int patch_waves = 2;  // waves per item of k_step_patch
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
     const double* reset_prior = nullptr;  // ipp_set_reset_prior: priors of the episodes started by ipp_step_autoreset
     bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
@@ -101,6 +104,9 @@ struct Engine {
 
 struct Layout {
     int N, Npad, T, n_tiles, win_tiles, MC, FC, QS, q_rows, VEC;
+    bool patch;
+    int patch_waves;
+    PatchGeo pg;
     uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
         off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfhp, off_grfamp, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
 };
@@ -108,7 +114,28 @@ struct Layout {
 uint64_t q_item_floats(const Layout& L) {
     const uint64_t lq = ((uint64_t)L.MC * L.MC + L.MC + 3) & ~(uint64_t)3;
     // multiple of 16 floats: item blocks start on 64-byte lines (no scalar-cache line shared between two items)
-    return (lq + (uint64_t)(L.q_rows + 8) * L.QS + 15) & ~(uint64_t)15;
+    uint64_t q = lq + (uint64_t)(L.q_rows + 8) * L.QS;
+    if (L.patch) q = std::max<uint64_t>(q, (uint64_t)L.q_rows * kPatchRec);  // column records that overflow the LDS staging
+    return (q + 15) & ~(uint64_t)15;
+}
+
+// Compact column patches + k_step_patch (k_step_patch.h): windowed factor engines of the batched driver (no tree / scoring
+// scratch: those kernels read row-major band tiles), grids wide enough for two-dimensional windows, MC = 9.  Any of the A/B
+// switches of the band-tile kernels selects those kernels instead; IPP_PATCH=0 does so explicitly.
+bool patch_layout(const ipp_config& c, int MC) {
+    if (c.state_repr != IPP_FACTOR || c.window_rows <= 0 || MC != 9) return false;
+    if (c.tile_threads != 0 || c.node_capacity > 0 || c.score_scratch) return false;
+    if (c.x_dim % 2 != 0 || c.x_dim > 256 || c.y_dim > 256) return false;
+    if (!(c.x_dim > 2 * c.window_rows + 13)) return false;
+    if (c.rank_cap > kPatchMaxRank) return false;
+    for (const char* name : {"IPP_RECT_META", "IPP_RECT", "IPP_CLIP_COLS", "IPP_FUSED", "IPP_PIPE", "IPP_VEC", "IPP_STEP_CHUNKS"})
+        if (getenv(name)) return false;
+    if (const char* p = getenv("IPP_PATCH")) return atoi(p) != 0;
+    return true;
+}
+int patch_waves_wanted() {
+    if (const char* w = getenv("IPP_PATCH_WAVES")) { const int n = atoi(w); if (n == 1 || n == 2 || n == 4) return n; }
+    return 2;
 }
 
 // Windowed factor columns: the largest length scale a reset may install and the prior covariance dropped at the
@@ -147,6 +174,12 @@ int plan(const ipp_config& c, Layout& L) {
     const long window_cells = std::min<long>(c.y_dim, 2L * c.window_rows + 5) * c.x_dim;
     L.VEC = (L.MC == 9 && !(windowed && window_cells < 16 * 256)) ? 4 : 2;
     if (const char* ve = getenv("IPP_VEC")) { if (L.MC == 9 && (atoi(ve) == 2 || atoi(ve) == 4)) L.VEC = atoi(ve); }  // A/B experiments
+    L.patch = patch_layout(c, L.MC);
+    L.patch_waves = patch_waves_wanted();
+    if (L.patch) {
+        L.VEC = 2;
+        L.pg = patch_geometry(c.x_dim, c.y_dim, c.window_rows);
+    }
     L.N = c.x_dim * c.y_dim;
     const int n4 = (L.N + L.VEC - 1) / L.VEC;
     if (c.tile_threads > 0) {
@@ -187,6 +220,7 @@ int plan(const ipp_config& c, Layout& L) {
         // (Since the rectangle metadata the fused kernel is ahead up to 16384 envs of 50x50 -- 8192: 24.7 vs 23.4 M, 16384:
         // 26.0 vs 23.7 M env-steps/s -- and the split path from 32768: 28.3 vs 26.9 M; on 100x100 the split path stays 23 % ahead.)
         if (c.tile_threads <= 0 && c.node_capacity <= 0 && c.capacity >= ((int64_t)c.x_dim * c.y_dim >= 6000 ? 8192 : 24576)) L.T = 128;
+        if (L.patch) L.T = 64 * L.patch_waves;  // one fused kernel for every batch size
         if (L.T > 512) return fail(-1, "tile_threads must be <= 512 for IPP_FACTOR");
         L.n_tiles = (n4 + 63) / 64;
         L.Npad = L.n_tiles * 64 * L.VEC;
@@ -199,6 +233,7 @@ int plan(const ipp_config& c, Layout& L) {
     }
     L.q_rows = (c.state_repr == IPP_FACTOR) ? c.rank_cap : L.FC;
     L.cov_slot_floats = (c.state_repr == IPP_FACTOR) ? (uint64_t)c.rank_cap * L.Npad : (uint64_t)L.N * L.Npad;
+    if (L.patch) L.cov_slot_floats = (uint64_t)c.rank_cap * L.pg.pstride;
     uint64_t o = 0;
     const uint64_t cap = c.capacity, mb = c.max_batch, np = L.Npad;
     L.off_mean = o; o += up(cap * np * 4);
@@ -349,6 +384,18 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
         const int slot = (int)(e->launch_seq++ & (kTicketSlots - 1));
         timed_launch(e, 0, k_step_pipe<MC, VEC>, dim3(std::min(n, e->pipe_grid)), dim3(kPipeThreads), e->pipe_lds, s, v, env_ids, n, action,
                      prev, noise, flags, e->lut_rows, status, reward, slot);
+        if (prep_done) (void)hipEventRecord(prep_done, s);
+        return;
+    }
+    if (e->patch) {  // compact column patches: one fused kernel, one small workgroup per item (k_step_patch.h)
+        if constexpr (MC == 9 && VEC == 2) {
+            if (e->patch_waves == 1)
+                timed_launch(e, 0, k_step_patch<1>, dim3(n), dim3(64), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+            else if (e->patch_waves == 4)
+                timed_launch(e, 0, k_step_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+            else
+                timed_launch(e, 0, k_step_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+        }
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
     }
@@ -649,6 +696,23 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     // stream over columns that may carry a true rectangle runs on rectangle tiles: env steps where they exist (VEC = 2;
     // else the env columns are written on band tiles and carry full rectangles), tree steps always.
     if (v.rect_meta) { e->rect_commit = e->rect_ok; e->rect_tree = true; }
+    v.patch = L.patch ? 1 : 0;
+    v.pw = v.ph = v.pstride = v.pdiv = v.plw = v.pcap = v.punits = 0;
+    e->patch = L.patch;
+    e->patch_waves = L.patch_waves;
+    if (L.patch) {
+        v.clip_cols = 1;
+        v.rect_meta = 1;
+        v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.pdiv = L.pg.pdiv; v.plw = L.pg.plw; v.punits = L.pg.punits;
+        for (int flat = 0; flat < v.ph * v.pw + 2 * kWave; ++flat)  // (the multiply-shift division of the kernel's flat index)
+            if ((int)(((unsigned)flat * (unsigned)v.pdiv) >> 16) != flat / v.pw) { delete e; return fail(-3, "patch index division is inexact for pw = %d", v.pw); }
+        // column records in LDS: what fits the share of a workgroup when 16 waves of the kernel are resident per CU
+        const size_t budget = (size_t)160 * 1024 / (16 / L.patch_waves);
+        const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
+        int pcap = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;
+        if (const char* pc = getenv("IPP_PATCH_CAP")) pcap = std::max(8, atoi(pc));  // A/B experiments, overflow tests
+        v.pcap = std::min(pcap, cfg->rank_cap);
+    }
     v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
     v.cov_slot = L.cov_slot_floats;
@@ -691,7 +755,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->gain_lds = gain_lds_bytes(v, e->q_chunk, e->lut_cap);
     if (v.mode == IPP_FACTOR && v.window_rows > 0) {
         const size_t MCs = v.meas_cap, LQ = (MCs * MCs + MCs + 3) & ~(size_t)3;
-        e->fused = (v.T == kStepThreads);
+        e->fused = (v.T == kStepThreads) || e->patch;
         if (const char* fu = getenv("IPP_FUSED")) e->fused = e->fused && atoi(fu) != 0;  // A/B experiments
         const int waves = v.T / 64;
         // prior table rows: a tile that holds new columns lies within window_rows of the footprint, so
@@ -708,7 +772,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
             e->gain_lds = e->fused ? std::max(GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave),
                                               GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec))
                                    : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
-        if (e->fused) {
+        if (e->patch) e->gain_lds = PatchLds::bytes(v.pcap, v.plw * v.plw, e->patch_waves, v.punits, v.rank_cap);
+        if (e->fused && !e->patch) {
             e->pipe_lds = (v.meas_cap == 9) ? PipeLds<9>::bytes(v.rank_cap, lutf, v.win_tiles) : PipeLds<25>::bytes(v.rank_cap, lutf, v.win_tiles);
             e->pipe = e->pipe_lds <= 160 * 1024;
             // off by default: one producer wave needs ~50 us per item against ~37 us of its three consumers, so the
@@ -861,6 +926,8 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     out->arena_bytes = e->used_bytes;
     out->cov_slot_bytes = e->v.cov_slot * 4;
     out->step_lds_bytes = e->gain_lds;
+    out->fused_step = e->fused ? 1 : 0;
+    out->patch_layout = e->patch ? 1 : 0;
     return 0;
 }
 
@@ -1268,7 +1335,8 @@ int ipp_read_cov_dense(void* engine, int32_t env_id, float* out, void* stream) {
         HIP_TRY(hipMemcpy2DAsync(out, (size_t)v.N * 4, v.cov + (size_t)env_id * v.cov_slot, (size_t)v.Npad * 4,
                                  (size_t)v.N * 4, v.N, hipMemcpyDeviceToDevice, s));
     } else {
-        hipLaunchKernelGGL(k_read_cov_factor, dim3((v.N + 255) / 256, v.N), dim3(256), 0, s, v, env_id, out);
+        if (v.patch) hipLaunchKernelGGL(k_read_cov_patch, dim3((v.N + 255) / 256, v.N), dim3(256), 0, s, v, env_id, out);
+        else hipLaunchKernelGGL(k_read_cov_factor, dim3((v.N + 255) / 256, v.N), dim3(256), 0, s, v, env_id, out);
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_fork(View v, const int* __restrict__ sr
     const int s = src_ids[item], d = dst_ids[item];
     if (s < 0 || s >= v.cap || d < 0 || d >= v.cap || s == d) return;
     const int r = (v.mode == IPP_FACTOR) ? v.rank[s] : v.N;
-    const size_t n4 = (size_t)r * v.Npad / 4;
+    const size_t n4 = (size_t)r * (v.patch ? (size_t)v.pstride : (size_t)v.Npad) / 4;  // (patch layout: a column is pstride floats)
     const float4* cs = reinterpret_cast<const float4*>(v.cov + (size_t)s * v.cov_slot);
     float4* cd = reinterpret_cast<float4*>(v.cov + (size_t)d * v.cov_slot);
     const size_t stride = (size_t)gridDim.x * blockDim.x;

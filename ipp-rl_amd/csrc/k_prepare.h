@@ -66,6 +66,78 @@ struct PrepLds {
     }
 };
 
+// The item header of a step: footprint, resolution factor, noise variance, cost, rank / status bookkeeping -- computed
+// by every thread from the same inputs (fp64 like NumPy: sensors/cameras.py:34-75,122-125, sensors/models/sensor_models.py:27-36,
+// planning/common/actions.py:8-41, mapping/mappings.py:125-126).  Shared by the prologue (prepare_item_ex) and the patch
+// step kernel (k_step_patch.h).
+template <int MC, int MODE>
+__device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int dst0, bool slots_ok, double ax, double ay, double az,
+                                                    double px, double py, double pz, int rank_ld, double sv, double ls, unsigned flags) {
+    constexpr int FC = 4 * MC;
+    ItemHdr h;
+    h.env = env0;
+    h.dst = dst0;
+    h.status = IPP_STATUS_OK;
+    h.fallback = 0;
+    h.commit = (flags & IPP_PREDICT_ONLY) ? 0 : 1;
+    h.t_lo = 0;
+    h.t_hi = v.n_tiles - 1;
+    bool ok = isfinite(ax) && isfinite(ay) && isfinite(az) && slots_ok;
+    int xl = 0, xr = 0, yu = 0, yd = 0;
+    if (ok) {
+        const double ext_x = 2 * az * v.tanx, ext_y = 2 * az * v.tany;           // cameras.py:44-45
+        const double cells_x = floor(ext_x / v.res), cells_y = floor(ext_y / v.res);  // :63-64
+        const double gx = floor(ax / v.res), gy = floor(ay / v.res);              // :66
+        const double rad_x = floor(0.5 * cells_x), rad_y = floor(0.5 * cells_y);  // :67
+        xl = (int)fmin(fmax(gx - rad_x, 0.0), (double)(v.W - 1));                 // :69-73
+        xr = (int)fmin(fmax(gx + rad_x, 0.0), (double)(v.W - 1));
+        yu = (int)fmin(fmax(gy - rad_y, 0.0), (double)(v.H - 1));
+        yd = (int)fmin(fmax(gy + rad_y, 0.0), (double)(v.H - 1));
+        ok = (xr >= xl) && (yd >= yu);
+    }
+    h.xl = xl; h.xr = xr; h.yu = yu; h.yd = yd;
+    h.rf = (az > v.rf_alt) ? 2 : 1;                                               // cameras.py:125
+    h.w = xr - xl + 1;
+    h.h = yd - yu + 1;
+    h.nx = (h.w - 1) / h.rf + 1;                                                  // sensor_models.py:57
+    h.ny = (h.h - 1) / h.rf + 1;
+    h.m = h.nx * h.ny;                                                            // mappings.py:125-126
+    h.f = h.w * h.h;
+    h.nv_d = v.coeff_a * (1.0 - exp(-v.coeff_b * az));                            // sensor_models.py:30
+    h.nv = (float)h.nv_d;
+    const double dx = ax - px, dy = ay - py, dz = az - pz;
+    const double dist = sqrt(dx * dx + dy * dy + dz * dz);                        // actions.py:15-16
+    double cost = dist;
+    if (flags & IPP_USE_FLIGHT_TIME) {                                            // actions.py:32-41
+        const double d_acc = fmin(dist * 0.5, v.vmax * v.vmax / (2 * v.amax));
+        cost = (dist - 2 * d_acc) / v.vmax + 2 * sqrt(2 * d_acc / v.amax);
+    }
+    h.cost_d = cost;
+    h.cost = (float)cost;
+    h.rank = ok ? rank_ld : 0;
+    h.sv = ok ? (float)sv : 0.f;
+    h.ls = ok ? (float)ls : 0.f;
+    if (!ok || h.m > MC || h.f > FC) h.status = IPP_STATUS_BAD_FOOTPRINT;
+    if (h.status == IPP_STATUS_OK && h.rf > 1 && !(flags & IPP_COV_ONLY)) {
+        // area resampler is only restated for shrinking scales
+        const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
+        if (h.w < ocols || h.h < orows) h.status = IPP_STATUS_BAD_FOOTPRINT;
+    }
+    if (MODE == IPP_FACTOR && h.status == IPP_STATUS_OK && h.commit && h.rank + h.m > v.rank_cap) {
+        h.status = IPP_STATUS_RANK_FULL;
+        h.commit = 0;
+    }
+    if (MODE == IPP_FACTOR && v.window_rows > 0 && ok) {
+        // the appended columns are kept on the grid rows within window_rows of the footprint (whole tiles)
+        const int row_lo = max(0, yu - v.window_rows), row_hi = min(v.H - 1, yd + v.window_rows);
+        h.t_lo = (row_lo * v.W) / v.tile_cells;
+        h.t_hi = ((row_hi + 1) * v.W - 1) / v.tile_cells;
+    }
+    h.rows = (MODE == IPP_FACTOR) ? h.rank : h.f;
+    if (h.status == IPP_STATUS_BAD_FOOTPRINT) { h.m = 0; h.f = 0; h.rows = 0; h.commit = 0; }
+    return h;
+}
+
 struct NoMidWork { __device__ __forceinline__ void operator()(const ItemHdr&) const {} };
 
 // The per-item prologue as a device function so that it can run as its own kernel (k_prepare: dense state, exact
@@ -156,69 +228,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     }
 
     // ------------------------------------------------------------------ header (every thread, fp64 like NumPy)
-    ItemHdr h;
-    {
-        h.env = env0;
-        h.dst = dst0;
-        h.status = IPP_STATUS_OK;
-        h.fallback = 0;
-        h.commit = (flags & IPP_PREDICT_ONLY) ? 0 : 1;
-        h.t_lo = 0;
-        h.t_hi = v.n_tiles - 1;
-        bool ok = isfinite(ax) && isfinite(ay) && isfinite(az) && slots_ok;
-        int xl = 0, xr = 0, yu = 0, yd = 0;
-        if (ok) {
-            const double ext_x = 2 * az * v.tanx, ext_y = 2 * az * v.tany;           // cameras.py:44-45
-            const double cells_x = floor(ext_x / v.res), cells_y = floor(ext_y / v.res);  // :63-64
-            const double gx = floor(ax / v.res), gy = floor(ay / v.res);              // :66
-            const double rad_x = floor(0.5 * cells_x), rad_y = floor(0.5 * cells_y);  // :67
-            xl = (int)fmin(fmax(gx - rad_x, 0.0), (double)(v.W - 1));                 // :69-73
-            xr = (int)fmin(fmax(gx + rad_x, 0.0), (double)(v.W - 1));
-            yu = (int)fmin(fmax(gy - rad_y, 0.0), (double)(v.H - 1));
-            yd = (int)fmin(fmax(gy + rad_y, 0.0), (double)(v.H - 1));
-            ok = (xr >= xl) && (yd >= yu);
-        }
-        h.xl = xl; h.xr = xr; h.yu = yu; h.yd = yd;
-        h.rf = (az > v.rf_alt) ? 2 : 1;                                               // cameras.py:125
-        h.w = xr - xl + 1;
-        h.h = yd - yu + 1;
-        h.nx = (h.w - 1) / h.rf + 1;                                                  // sensor_models.py:57
-        h.ny = (h.h - 1) / h.rf + 1;
-        h.m = h.nx * h.ny;                                                            // mappings.py:125-126
-        h.f = h.w * h.h;
-        h.nv_d = v.coeff_a * (1.0 - exp(-v.coeff_b * az));                            // sensor_models.py:30
-        h.nv = (float)h.nv_d;
-        const double dx = ax - px, dy = ay - py, dz = az - pz;
-        const double dist = sqrt(dx * dx + dy * dy + dz * dz);                        // actions.py:15-16
-        double cost = dist;
-        if (flags & IPP_USE_FLIGHT_TIME) {                                            // actions.py:32-41
-            const double d_acc = fmin(dist * 0.5, v.vmax * v.vmax / (2 * v.amax));
-            cost = (dist - 2 * d_acc) / v.vmax + 2 * sqrt(2 * d_acc / v.amax);
-        }
-        h.cost_d = cost;
-        h.cost = (float)cost;
-        h.rank = ok ? rank_ld : 0;
-        h.sv = ok ? (float)sv : 0.f;
-        h.ls = ok ? (float)ls : 0.f;
-        if (!ok || h.m > MC || h.f > FC) h.status = IPP_STATUS_BAD_FOOTPRINT;
-        if (h.status == IPP_STATUS_OK && h.rf > 1 && !(flags & IPP_COV_ONLY)) {
-            // area resampler is only restated for shrinking scales
-            const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
-            if (h.w < ocols || h.h < orows) h.status = IPP_STATUS_BAD_FOOTPRINT;
-        }
-        if (MODE == IPP_FACTOR && h.status == IPP_STATUS_OK && h.commit && h.rank + h.m > v.rank_cap) {
-            h.status = IPP_STATUS_RANK_FULL;
-            h.commit = 0;
-        }
-        if (MODE == IPP_FACTOR && v.window_rows > 0 && ok) {
-            // the appended columns are kept on the grid rows within window_rows of the footprint (whole tiles)
-            const int row_lo = max(0, yu - v.window_rows), row_hi = min(v.H - 1, yd + v.window_rows);
-            h.t_lo = (row_lo * v.W) / v.tile_cells;
-            h.t_hi = ((row_hi + 1) * v.W - 1) / v.tile_cells;
-        }
-        h.rows = (MODE == IPP_FACTOR) ? h.rank : h.f;
-        if (h.status == IPP_STATUS_BAD_FOOTPRINT) { h.m = 0; h.f = 0; h.rows = 0; h.commit = 0; }
-    }
+    ItemHdr h = make_item_header<MC, MODE>(v, env0, dst0, slots_ok, ax, ay, az, px, py, pz, rank_ld, sv, ls, flags);
     h = uniform_hdr(h);  // every thread computed the same values: keep them in SGPRs from here on
     if (tid == 0) {
         *hs = h;
@@ -901,7 +911,9 @@ template <int MC>
 __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, const int item, unsigned flags,
                                                unsigned char* small, const float* ht, int si, int sk, float* linv_f,
                                                float* y_f, float* __restrict__ q_out, int* __restrict__ status_out,
-                                               int* obs_flag = nullptr) {
+                                               int* obs_flag = nullptr, int r_ht = -1, const float* ht2 = nullptr, int r_ht2 = 0) {
+    // r_ht >= 0: `ht` holds that many rows instead of h.rank (k_step_patch.h: only the columns that reach the footprint are
+    // staged); ht2 / r_ht2: further rows with the same strides in a second array (rows that did not fit the LDS staging)
     static_assert(MC == 9, "register layout written for MC = 9");
     constexpr int LD = MC + 1;
     constexpr int QS = (MC + 3) & ~3;
@@ -909,7 +921,7 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
     double* S = pl.S; double* zz = pl.zz; double* vv = pl.vv;
     const double* ktab = pl.ktab; const int* bfi = pl.bfi; const int* bcnt = pl.bcnt; const double* bwt = pl.bwt;
     const int lane = threadIdx.x & (kWave - 1);
-    const int m = h.m, r = h.rank;
+    const int m = h.m, r = r_ht >= 0 ? r_ht : h.rank;
     const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
     const bool cov_only = (flags & IPP_COV_ONLY) != 0;
     double* dbg = v.dbg + (size_t)item * (2 * MC * MC + 2 * MC);
@@ -954,6 +966,11 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
             a2 = fma((double)x[6], (double)y[6], a2); a3 = fma((double)x[7], (double)y[7], a3);
         }
         for (; k < r; ++k) a0 = fma((double)hi[k * sk], (double)hj[k * sk], a0);
+        if (ht2) {
+            const float* hi2 = ht2 + pi * si;
+            const float* hj2 = ht2 + pj * si;
+            for (int k2 = 0; k2 < r_ht2; ++k2) a1 = fma((double)hi2[k2 * sk], (double)hj2[k2 * sk], a1);
+        }
         mine -= (a0 + a1) + (a2 + a3);
     }
     if (pair_on) {

@@ -1,0 +1,638 @@
+// Fused factor-state env step on COMPACT COLUMN PATCHES: ONE kernel, one small workgroup (NW waves, default 2) per item.
+//
+// Storage (View::patch).  A column of U appended by a step is non-zero only on the rectangle of grid rows / columns within
+// window_rows of that step's footprint (two-dimensional windows).  Here the column IS that rectangle:
+// column k of an env is a patch of ph x pw floats, row-major with the FIXED row stride pw,
+//     U_k[row][col] = patch_k[(row - r0_k) * pw + (col - c0_k)],      (r0_k, r1_k, c0_k, c1_k) = View::colrect[env][k],
+// patch_k = cov + env * cov_slot + k * pstride.  Because every patch has the same row stride, the cells of the NEW step's
+// rectangle, enumerated in its own patch order (flat = prow * pw + pcol), sit at flat + shift_k in stored column k with the
+// wave-uniform shift_k = (r0_new - r0_k) * pw + (c0_new - c0_k): a wave's request for a stored row is 512 CONSECUTIVE bytes
+// of that column (lanes outside the column's rectangle masked), whatever the grid width -- on row-major band tiles the same
+// request crossed ~5 grid rows at a stride of W floats (12 sectors for 512 B used at 50x50, more on wider grids) and a
+// column slot was Npad floats (10 KB at 50x50, 160 KB at 200x200) instead of 2.6 KB.  The appended columns are written
+// the same way: m fully coalesced row writes per unit.
+//
+// Workgroup = NW waves, 8 / NW ... 16 / NW items resident per CU (the per-item work is a chain of dependent round trips:
+// throughput = resident items / item lifetime).  LDS diet against k_step_factor (36 KB -> ~15 KB):
+//   * HT = H_F U[F,:]^T is gathered and staged only for the columns whose rectangle reaches the footprint (the others have
+//     an exactly zero row): per such column one 64-byte RECORD  [-HT(0..11) | byte offset of its shifted patch | rectangle as
+//     two packed 16-bit pairs | k]  -- the stream reads the record (LDS broadcast) instead of a scalar load from a global
+//     scratch block (no store -> s_load round trip, no scalar-cache invalidate);
+//   * the prior table is P0(|drow| < plw, |dcol| < plw), not lut_rows x W;
+//   * records beyond View::pcap (clustered revisits) live in the item's global scratch block and are read through flat
+//     loads by the request groups that touch them (a second instantiation of the group body only).
+// Arithmetic per cell (prior term, order of the stored rows, L^-1 in the epilogue, reward sums in unit order) is the one
+// of gain_tiles<PRE, RECT> (k_gain_factor.h); the m x m algebra and the observation are the shared device functions of
+// k_prepare.h (solve_wave_fast, observe_wave).  mapping/mappings.py:178-197, planning/common/rewards.py:8-31.
+#pragma once
+#include <algorithm>
+#include <type_traits>
+#include "ipp_common.h"
+#include "k_gain.h"
+#include "k_gain_factor.h"
+#include "k_prepare.h"
+
+namespace ipp {
+
+constexpr int kPatchRec = 16;  // floats per column record
+constexpr int kPatchKP = 16;   // stored rows requested per group
+constexpr int kPatchCtl = 32;  // control words
+constexpr int kPatchMaxRank = 512;  // largest rank_cap of a patch engine (every thread tests kPatchMaxRank / threads rectangles)
+
+// Geometry of the patches for a config (host + device).
+struct PatchGeo {
+    int pw, ph, pstride, pdiv, plw, punits;
+};
+inline PatchGeo patch_geometry(int W, int H, int R) {
+    PatchGeo g;
+    // widest rectangle: 2 R + 5 columns (the widest unclipped footprint of m <= 9 blocks is 5 cells) with both ends moved out
+    // to even columns; tallest: 2 R + 6 rows (a 6-row footprint only exists clipped at the border: fewer rows then)
+    g.pw = std::min((W + 1) & ~1, ((2 * R + 5 + 2) / 2) * 2);
+    g.ph = std::min(H, 2 * R + 6);
+    g.pstride = (g.pw * g.ph + 15) & ~15;
+    g.pdiv = (65536 + g.pw - 1) / g.pw;
+    g.plw = std::min(std::max(W, H), R + 7);
+    g.punits = (g.ph * g.pw + 2 * kWave - 1) / (2 * kWave);
+    return g;
+}
+
+struct PatchLds {
+    float* rec; float* Ls; float* ys; float* lut; unsigned char* small; double* red; int* ctl; int* fb_yx; float* fb_w;
+    unsigned short* ridx; double* unit_red;
+    static constexpr int LQ = 96;  // L^-1 (81) | y (9) | pad
+    __host__ __device__ static size_t small_bytes() { return (prep_small_bytes<9>() + 15) & ~(size_t)15; }
+    __host__ __device__ static size_t bytes(int cap, int lut_floats, int waves, int units, int rank_cap) {
+        size_t b = (size_t)cap * kPatchRec * 4 + LQ * 4 + (size_t)((lut_floats + 3) & ~3) * 4 + small_bytes();
+        b += 4 * 8 + kPatchCtl * 4 + 2 * 4 * 9 * 4;
+        b += (((size_t)waves * (rank_cap + kPatchKP) * 2) + 15) & ~(size_t)15;
+        b += (size_t)units * 8;
+        return (b + 15) & ~(size_t)15;
+    }
+    __device__ __forceinline__ PatchLds(unsigned char* base, int cap, int lut_floats, int waves, int units, int rank_cap) {
+        rec = reinterpret_cast<float*>(base);
+        Ls = rec + (size_t)cap * kPatchRec;
+        ys = Ls + 81;
+        lut = Ls + LQ;
+        small = reinterpret_cast<unsigned char*>(lut + ((lut_floats + 3) & ~3));
+        red = reinterpret_cast<double*>(small + small_bytes());
+        ctl = reinterpret_cast<int*>(red + 4);
+        fb_yx = ctl + kPatchCtl;
+        fb_w = reinterpret_cast<float*>(fb_yx + 4 * 9);
+        ridx = reinterpret_cast<unsigned short*>(fb_w + 4 * 9);
+        unit_red = reinterpret_cast<double*>(ridx + ((((size_t)waves * (rank_cap + kPatchKP)) + 7) & ~(size_t)7));
+    }
+};
+
+template <bool ONE>
+__device__ __forceinline__ void patch_sync() {
+    if (ONE) wave_lds_sync(); else __syncthreads();
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
+    View v, const int* __restrict__ env_ids, int n_items, const double* __restrict__ action,
+    const double* __restrict__ prev_action, const float* __restrict__ meas_noise, unsigned flags,
+    int* __restrict__ status_out, float* __restrict__ reward_out, AutoReset ar) {
+    constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
+    constexpr int RJ = kPatchMaxRank / NT;                 // rectangles per thread, loaded with the inputs
+    constexpr int OW = (NW > 1) ? 1 : 0;                   // the wave that evaluates the observation
+    constexpr bool ONE = (NW == 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
+    const PatchLds lds(smem_sp, v.pcap, v.plw * v.plw, NW, v.punits, v.rank_cap);
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = launch_item(v, blockIdx.x, n_items);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (tid == 0) IPP_MARK(item, 0);
+    int* next_unit = lds.ctl; int* done_waves = lds.ctl + 1; int* solve_flag = lds.ctl + 2; int* obs_flag = lds.ctl + 3;
+    int* wcnt = lds.ctl + 8;  // [RJ][NW] contributing columns found by wave w among its columns j
+
+    // ------------------------------------------------------------------ batch 1: everything that does not depend on the footprint
+    const int env0 = env_ids ? env_ids[item] : item + v.env_base;
+    const bool slots_ok = env0 >= 0 && env0 < v.cap;
+    const int envc = slots_ok ? env0 : 0;
+    const double ax = action[3 * item + 0], ay = action[3 * item + 1], az = action[3 * item + 2];
+    const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
+    const int rank_ld = v.rank[envc];
+    const double sv_d = v.prior[2 * envc + 0], ls_d = v.prior[2 * envc + 1];
+    const int otid = tid - kWave * OW;
+    const float eps_ld = (meas_noise && otid >= 0 && otid < MC) ? meas_noise[(size_t)item * MC + otid] : 0.f;
+    const int* __restrict__ rects = v.colrect + (size_t)envc * v.rank_cap;
+    unsigned rc_pre[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int k = tid + j * NT;
+        rc_pre[j] = (k < v.rank_cap) ? (unsigned)rects[k] : 0u;
+    }
+
+    // ------------------------------------------------------------------ header (every thread; uniform)
+    ItemHdr h = make_item_header<MC, IPP_FACTOR>(v, env0, env0, slots_ok, ax, ay, az, px, py, pz, rank_ld, sv_d, ls_d, flags);
+    const int R = v.window_rows;
+    // rectangle of this step = its patch: rows / columns within R of the footprint, the column range widened to even columns
+    int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
+    int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
+    if (h.m > 0 && (r1n - r0n + 1 > v.ph || c1n - c0n + 1 > v.pw)) {  // (cannot happen for footprints of <= MC blocks: patch_geometry)
+        h.status = IPP_STATUS_BAD_FOOTPRINT; h.m = 0; h.f = 0; h.rows = 0; h.commit = 0;
+    }
+    h = uniform_hdr(h);
+    r0n = uni(r0n); r1n = uni(r1n); c0n = uni(c0n); c1n = uni(c1n);
+    const int hn = r1n - r0n + 1, wn = c1n - c0n + 1;
+    const PrepLds<MC> pl(lds.small);
+    if (tid == 0) {
+        *pl.hs = h;
+        *next_unit = 0; *done_waves = 0; *solve_flag = 0; *obs_flag = 0;
+        lds.red[0] = 0.0; lds.red[1] = 0.0;
+    }
+    const int m = h.m, f = h.f, r = h.rank;
+    if (m == 0) {  // bad footprint: no step, but a scheduled reset still happens
+        if (tid == 0) {
+            v.hdr[item] = h;
+            if (status_out) status_out[item] = h.status;
+            reward_out[item] = 0.f;
+        }
+        patch_sync<ONE>();  // (every thread holds its copy of prev_action)
+        if ((flags & IPP_UPDATE_PREV) && tid == 0) {
+            double* pw = const_cast<double*>(prev_action);
+            pw[3 * item + 0] = ax; pw[3 * item + 1] = ay; pw[3 * item + 2] = az;
+        }
+        if (ar.src && tid < kWave) {
+            const int k = __builtin_amdgcn_readfirstlane(ar.src[item]);
+            if (k >= 0 && h.env >= 0 && h.env < v.cap) wave_reset_env(v, ar, h.env, k, tid);
+        }
+        return;
+    }
+    if (tid == 0) IPP_MARK(item, 3);
+    const bool cov_only = (flags & IPP_COV_ONLY) != 0;
+    const float* mean_env = v.mean + (size_t)h.env * v.Npad;
+    const float* gt_env = v.gt + (size_t)h.env * v.Npad;
+    float* slot = v.cov + (size_t)h.env * v.cov_slot;
+    float* ovf = v.q + (size_t)item * v.q_item;  // records that do not fit the LDS staging (global scratch block of the item)
+    const int cap = v.pcap, pw = v.pw;
+
+    // ------------------------------------------------------------------ batch 2: inputs of the observation (lanes of wave OW)
+    ObsRegs oregs;
+    {
+        const int ly = max(otid, 0) / h.w, lx = max(otid, 0) - ly * h.w;
+        oregs.gt = (!cov_only && otid >= 0 && otid < f) ? gt_env[(h.yu + ly) * v.W + h.xl + lx] : 0.f;  // simulations/__init__.py:24-25
+        const Block mob = block_of(min(max(otid, 0), m - 1), h.nx, h.rf, h.w, h.h);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int aa = min(a, mob.count() - 1);
+            const int cell = (h.yu + mob.y0 + aa / mob.bw) * v.W + h.xl + mob.x0 + aa % mob.bw;
+            oregs.mean[a] = (!cov_only && otid >= 0 && otid < m && a < mob.count()) ? mean_env[cell] : 0.f;  // H x, mappings.py:195
+        }
+        oregs.eps = eps_ld;
+    }
+
+    // ------------------------------------------------------------------ columns that reach the footprint, in increasing k
+    // (a column whose rectangle misses the footprint has an exactly zero row of H U^T: it cannot change this step)
+    bool con[RJ];
+    unsigned long long bal[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int k = tid + j * NT;
+        const unsigned rc = rc_pre[j];
+        const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
+        con[j] = k < r && r0k <= h.yd && r1k >= h.yu && c0k <= h.xr && c1k >= h.xl;
+        bal[j] = __ballot(con[j]);
+        if (!ONE && lane == 0) wcnt[j * NW + wave] = __popcll(bal[j]);
+    }
+    fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
+    if (tid < m) {
+        const Block myb = block_of(tid, h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+        pl.bcnt[tid] = myb.count();
+        pl.bwt[tid] = myb.weight;
+        for (int a = 0; a < 4; ++a) {
+            const int aa = min(a, myb.count() - 1);
+            const int ly = myb.y0 + aa / myb.bw, lx = myb.x0 + aa % myb.bw;
+            pl.bfi[4 * tid + a] = ly * h.w + lx;
+        }
+    }
+    patch_sync<ONE>();
+    int pos[RJ];
+    int n_c = 0;
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        int before = 0, all = 0;
+        if (ONE) {
+            all = __popcll(bal[j]);
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int c = wcnt[j * NW + w];
+                before += (w < wave) ? c : 0;
+                all += c;
+            }
+        }
+        pos[j] = n_c + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
+        n_c += all;
+    }
+
+    // ------------------------------------------------------------------ gather HT = H_F U[F,:]^T for the contributing columns
+    // The OWNER of a column gathers it: lanes <-> columns, the footprint's blocks and cells are wave-uniform loop counters,
+    // every request is an unconditional buffer load whose offset is pushed out of range where the column is not stored.
+    const auto slot_rs = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 0x7ffffff0, 0x00020000);
+    // (cells and weights of the measurement blocks from the LDS tables filled in front of the barrier above: evaluating
+    // block_of per request site -- divisions by nx, bw -- was 5000 instructions of a 17000-instruction kernel)
+    auto gather_issue = [&](unsigned rc, int k, bool on, float (&l)[MC][4]) {
+        const unsigned r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
+        const int base = k * v.pstride - (int)r0k * pw - (int)c0k;  // patch_k[(fy - r0k) * pw + (fx - c0k)] = slot[base + fy * pw + fx]
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) l[i][a] = 0.f;
+            if (i < m) {  // wave-uniform
+                const int cnt = uni(pl.bcnt[i]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a < cnt) {  // wave-uniform
+                        const unsigned yx = (unsigned)uni(lds.fb_yx[4 * i + a]);
+                        const unsigned fy = yx >> 16, fx = yx & 0xffffu;
+                        const bool in = on && fy >= r0k && fy <= r1k && fx >= c0k && fx <= c1k;
+                        const unsigned voff = in ? (unsigned)(base + (int)(fy * (unsigned)pw + fx)) * 4u : 0xffffffffu;
+                        l[i][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto gather_store = [&](unsigned rc, int k, bool on, int a_pos, const float (&l)[MC][4]) {
+        if (!on) return;
+        float rec[kPatchRec];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rec[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            if (i < m) {
+                const int cnt = uni(pl.bcnt[i]);
+                float t = l[i][0];
+                if (cnt > 1) t += l[i][1];
+                if (cnt > 2) t += l[i][2] + l[i][3];
+                rec[i] = -(t * lds.fb_w[4 * i]);  // block weight; sign of the downdate folded in
+            }
+        }
+        const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
+        const int shift = (r0n - r0k) * pw + (c0n - c0k);
+        rec[12] = __int_as_float((k * v.pstride + shift) * 4);                            // byte offset of the shifted patch in the slot
+        rec[13] = __int_as_float(r0k | (c0k << 16));                                      // rectangle: first row | first column << 16
+        rec[14] = __int_as_float((r1k - r0k) | ((c1k - c0k) << 16));                      //            rows - 1 | columns - 1 << 16
+        rec[15] = __int_as_float(k);
+        if (a_pos < cap) {
+            float4* dst = reinterpret_cast<float4*>(lds.rec + (size_t)a_pos * kPatchRec);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+        } else {
+            float4* dst = reinterpret_cast<float4*>(ovf + (size_t)(a_pos - cap) * kPatchRec);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+        }
+    };
+    {
+        float l0[MC][4];
+        gather_issue(rc_pre[0], tid, con[0], l0);
+        // ---- under the round trip: prior table, footprint tables of the m x m algebra, the padding record
+        {
+            const float s3 = (float)(kSqrt3 * v.res) / h.ls;
+            const int lw = v.plw;
+            for (int i = tid; i < lw * lw; i += NT) {
+                const int dr = i / lw, dc = i - dr * lw;
+                lds.lut[i] = matern_f(dr, dc, s3, h.sv);
+            }
+            if (tid < f) pl.ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv_d, ls_d);
+        }
+        gather_store(rc_pre[0], tid, con[0], pos[0], l0);
+    }
+#pragma unroll 1
+    for (int j = 1; j < RJ; ++j) {
+        if (j * NT >= r) break;
+        // (a select chain on the wave-uniform j: a register array cannot be indexed dynamically)
+        unsigned rc = rc_pre[RJ - 1];
+        bool on = con[RJ - 1];
+        int ap = pos[RJ - 1];
+#pragma unroll
+        for (int q = 1; q < RJ - 1; ++q)
+            if (j == q) { rc = rc_pre[q]; on = con[q]; ap = pos[q]; }
+        if (__ballot(on) == 0ull) continue;
+        float l[MC][4];
+        gather_issue(rc, tid + j * NT, on, l);
+        gather_store(rc, tid + j * NT, on, ap, l);
+    }
+    if ((flags & IPP_UPDATE_PREV) && tid == 0) {
+        // (every thread took its copy of prev_action in batch 1, in front of the barrier above)
+        double* pwr = const_cast<double*>(prev_action);
+        pwr[3 * item + 0] = ax; pwr[3 * item + 1] = ay; pwr[3 * item + 2] = az;
+    }
+    const int n_lds = min(n_c, cap), n_ovf = n_c - n_lds;
+    if (n_ovf > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // overflow records are read back by the other waves
+    patch_sync<ONE>();
+    if (tid == 0) IPP_MARK(item, 1);
+
+    // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
+    // v_readlane: no LDS round trip per stored row)
+    const int n_fast = min(n_lds, 2 * kWave);
+    int mcofs[2];
+    unsigned mlo[2], mex[2];
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int a = p2 * kWave + lane;
+        mcofs[p2] = 0; mlo[p2] = 0x0000ffffu; mex[p2] = 0u;  // (empty rectangle)
+        if (a < n_fast) {
+            const float4 mt = *reinterpret_cast<const float4*>(lds.rec + (size_t)a * kPatchRec + 12);
+            mcofs[p2] = __float_as_int(mt.x); mlo[p2] = __float_as_uint(mt.y); mex[p2] = __float_as_uint(mt.z);
+        }
+    }
+
+    // ------------------------------------------------------------------ m x m algebra (wave 0) / observation (wave OW)
+    if (ONE) {
+        observe_wave<MC>(v, h, flags, lds.small, oregs);
+        const int status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.rec, 1, kPatchRec, lds.Ls, lds.ys, nullptr, status_out,
+                                               nullptr, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
+        wave_lds_sync();
+        if (lane == 0) *solve_flag = (status == IPP_STATUS_NOT_PD) ? 2 : 1;
+        wave_lds_sync();
+        if (lane == 0) IPP_MARK(item, 7);
+    } else if (wave == 0) {
+        const int status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.rec, 1, kPatchRec, lds.Ls, lds.ys, nullptr, status_out,
+                                               obs_flag, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) IPP_MARK(item, 7);
+    } else if (wave == OW) {
+        observe_wave<MC>(v, h, flags, lds.small, oregs);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(obs_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+    // ------------------------------------------------------------------ units of the new patch: 64 lanes x 2 consecutive cells
+    const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut;
+    const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
+    unsigned short* ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
+    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
+    const int n_units = (hn * pw + 2 * kWave - 1) / (2 * kWave);
+    const int lw = v.plw;
+    unsigned long long units = 0;
+    bool solved = false, dead = false;
+    float* mean_rw = v.mean + (size_t)h.env * v.Npad;
+    float* diag_rw = v.diag + (size_t)h.env * v.Npad;
+    typedef float rowv __attribute__((ext_vector_type(VEC)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+    for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(next_unit, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const int flat = 2 * (u * kWave + lane);
+        const int prow = (int)(((unsigned)flat * (unsigned)v.pdiv) >> 16), pcol = flat - prow * pw;
+        const bool lane_valid = prow < hn && pcol < wn;
+        const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
+        const int cell0 = rrow * v.W + rcol;  // (clamped for the masked lanes: any valid address)
+        float md_in[2][VEC];
+        load_vec<VEC>(mean_rw + cell0, md_in[0]);
+        load_vec<VEC>(diag_rw + cell0, md_in[1]);
+        const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> 16);
+        const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> 16));
+        const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
+        const unsigned flat4 = lane_valid ? (unsigned)flat * 4u : 0xffffffffu;  // byte offset of the lane's cells in a (shifted) patch; masked lanes out of range
+
+        // ---- ordered compaction of the records whose rectangle meets the rows of this unit (lane a <-> record a; the
+        // rectangles of the first 128 records sit in this lane's registers)
+        int nact = 0, nact_fast = 0;
+        for (int a0 = 0; a0 < n_c; a0 += kWave) {
+            const int a = a0 + lane;
+            bool on = false;
+            if (a < n_c) {
+                unsigned lo, ex;
+                if (a < n_fast) { lo = (a0 == 0) ? mlo[0] : mlo[1]; ex = (a0 == 0) ? mex[0] : mex[1]; }
+                else if (a < cap) { lo = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 13]); ex = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 14]); }
+                else { lo = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 13]); ex = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 14]); }
+                const int r0k = lo & 0xffff, r1k = r0k + (int)(ex & 0xffff);
+                on = r1k >= urow0 && r0k <= urow1;
+            }
+            const unsigned long long mask = __ballot(on);
+            if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)a;
+            nact += __popcll(mask);
+            if (a0 < n_fast) nact_fast += __popcll(mask & ((a0 + kWave <= n_fast) ? ~0ull : ((1ull << (n_fast - a0)) - 1ull)));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // group tail: entries past nact repeat the first active record with their requests masked off (0 * finite = 0)
+        if (nact > 0 && lane < KP) ridx[nact + lane] = ridx[0];
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- base term from the analytic prior: acc[.][b] = sum_{f in block b} w_f P0[cell, F_f]  (Wc L, L^-1 in the epilogue)
+        float acc[VEC][MC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+#pragma unroll
+            for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+        {
+            auto base_term = [&](auto nfc_tag) {
+                constexpr int NFC = decltype(nfc_tag)::value;
+#pragma unroll
+                for (int b = 0; b < MC; ++b) {
+                    if (b < m) {
+                        float cb[VEC];
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
+#pragma unroll
+                        for (int a = 0; a < NFC; ++a) {
+                            const int yx = fb_yx[4 * b + a];
+                            const float wa = fb_w[4 * b + a];
+                            const int fy = yx >> 16, fx = yx & 0xffff;
+#pragma unroll
+                            for (int c = 0; c < VEC; ++c) {
+                                const int dr = abs(rrow - fy), dc = abs(rcol + c - fx);
+                                cb[c] = fmaf(wa, lut[__umul24(dr, lw) + dc], cb[c]);
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
+                    }
+                }
+            };
+            if (h.rf == 1) base_term(std::integral_constant<int, 1>{});
+            else base_term(std::integral_constant<int, 4>{});
+        }
+
+        // ---- stream the stored rows: acc += patch_k[flat + shift_k] * (-HT[k,:])
+        // FAST: every record of the group is one of the first 128 and lies in one 64-record page: its patch offset and rectangle
+        // come out of this wave's registers through v_readlane with the record index as the (scalar) lane select, -HT from the
+        // LDS record.  Else (more than 128 contributing columns, or records in the global overflow block): generic pointers.
+        auto group = [&](int a0, auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const int ev = ridx[a0 + (lane & (KP - 1))];
+            rowv uu[KP];
+            int es[KP];
+            const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
+            const int pc = page ? mcofs[1] : mcofs[0];
+            const unsigned pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const int e = __builtin_amdgcn_readlane(ev, i);
+                es[i] = e;
+                int cofs;
+                unsigned lo, ex;
+                if (FAST) {
+                    cofs = __builtin_amdgcn_readlane(pc, e & 63);
+                    lo = (unsigned)__builtin_amdgcn_readlane((int)pl_, e & 63);
+                    ex = (unsigned)__builtin_amdgcn_readlane((int)pe, e & 63);
+                } else {
+                    const float* rp = (e < cap) ? (const float*)(lds.rec + (size_t)e * kPatchRec) : (const float*)(ovf + (size_t)(e - cap) * kPatchRec);
+                    const float4 mt = *reinterpret_cast<const float4*>(rp + 12);
+                    cofs = __builtin_amdgcn_readfirstlane(__float_as_int(mt.x));
+                    lo = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.y));
+                    ex = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.z));
+                }
+                const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
+                // (bitwise: a short-circuit && on the lane's validity wrapped every row in an exec-mask region)
+                const bool ok = (int)(a0 + i < nact) &
+                                (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slot) + cofs, 0, 0x7ffffff0, 0x00020000);
+                uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, 2));  // (aux 2: nt)
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
+                float qv[12];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+                    qv[4 * q] = t.x; qv[4 * q + 1] = t.y; qv[4 * q + 2] = t.z; qv[4 * q + 3] = t.w;
+                }
+#pragma unroll
+                for (int j = 0; j < MC; ++j)
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(uu[i][c], qv[j], acc[c][j]);
+            }
+        };
+        for (int a0 = 0; a0 < nact; a0 += KP) {
+            const int last = min(a0 + KP, nact) - 1;  // (list positions < nact_fast hold records < n_fast, in increasing order)
+            const bool fast = last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6);
+            if (__builtin_amdgcn_readfirstlane((int)fast)) group(a0, std::true_type{});
+            else group(a0, std::false_type{});
+        }
+
+        // ---- wait (first unit only) for L^-1 and y, then Wc = (P[:,F] H_F^T) L^-1 in place (column j needs the entries b <= j)
+        if (!solved) {
+            while (__hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+            solved = true;
+            dead = __hip_atomic_load(solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
+        }
+#pragma unroll
+        for (int j = MC - 1; j >= 0; --j) {
+            float t[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) t[c] = 0.f;
+#pragma unroll
+            for (int b = 0; b <= j; ++b) {
+                const float l = Ls[b * MC + j];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) t[c] = fmaf(acc[c][b], l, t[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc[c][j] = t[c];
+        }
+        const bool commit = h.commit && !dead;
+
+        // ---- epilogue: masked trace reduction, diag -= |Wc_i|^2, mean += Wc_i y, append the m new rows
+        float dred[VEC], dmean[VEC];
+        double part = 0.0;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float w2 = 0.f, dm = 0.f;
+#pragma unroll
+            for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
+#pragma unroll
+            for (int j = 0; j < MC; ++j) dm = fmaf(acc[c][j], ys[j], dm);
+            if (!lane_valid) {
+                w2 = 0.f; dm = 0.f;
+#pragma unroll
+                for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+            }
+            dred[c] = w2;
+            dmean[c] = dm;
+            // rewards.py:11 mask from the pre-step mean and pre-step diag(P); rewards.py:23-30 trace reduction
+            const bool in_mask = !adaptive || ((double)md_in[0][c] + v.kf * (double)md_in[1][c] >= v.thr);
+            if (lane_valid && in_mask) part += (double)w2;
+        }
+        part = wave_sum(part);
+        if (lane == 0) lds.unit_red[u] = part;
+        const int in_cells = __popcll(__ballot(lane_valid)) * VEC;
+        // (stored rows + m new rows + mean and diag read and written) floats per touched cell
+        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells;
+        if (commit && lane_valid) {
+            float outv[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) outv[c] = md_in[1][c] - dred[c];
+            store_vec<VEC>(diag_rw + cell0, outv);
+            if (!cov_only) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) outv[c] = md_in[0][c] + dmean[c];
+                store_vec<VEC>(mean_rw + cell0, outv);
+            }
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+                if (j < m) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
+                    store_stream<VEC>(slot + (size_t)(r + j) * v.pstride + flat, outv);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ------------------------------------------------------------------ per-item results (last wave to arrive)
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds.red);
+    if (lane == 0 && units) atomicAdd(cnt, units);
+    int reset_k = -1;
+    if (ar.src) reset_k = __builtin_amdgcn_readfirstlane(ar.src[item]);
+    // this wave's stores have landed before the last wave rewrites the env's planes (explicit wait, not an agent-scope
+    // release fence: that one also writes the XCD's L2 back, once per wave of every resetting item)
+    if (reset_k >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int arrived = 0;
+    if (lane == 0) arrived = atomicAdd(done_waves, 1);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived == 0 && lane == 0) IPP_MARK(item, 6);
+    if (arrived != NW - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dead = __hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without units never looked)
+    const bool commit_item = h.commit && !dead;
+    if (lane == 0) {
+        IPP_MARK(item, 2);
+        double tot = 0.0;
+        for (int t = 0; t < n_units; ++t) tot += lds.unit_red[t];  // unit order: bit-reproducible whatever wave took which unit
+        reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
+        if (commit_item) v.rank[h.env] = r + m;
+        unsigned long long* slotc = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
+        if (cnt[0]) atomicAdd(slotc, cnt[0]);
+    }
+    if (commit_item && lane < m) {
+        v.colspan[(size_t)h.env * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
+        v.colrect[(size_t)h.env * v.rank_cap + r + lane] = (int)rect_pack(r0n, r1n, c0n, c1n);
+    }
+    if (reset_k >= 0) wave_reset_env(v, ar, h.env, reset_k, lane);  // (after the rank store above, same lane 0)
+}
+
+// Patch-layout factor state -> dense P = P0 - U U^T (ipp_read_cov_dense: tests, np.diag(state), feature planes).
+__global__ __launch_bounds__(256) void k_read_cov_patch(View v, int env, float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.N || j >= v.N) return;
+    const double sv = v.prior[2 * env + 0], ls = v.prior[2 * env + 1];
+    const int ri = i / v.W, ci = i - ri * v.W, rj = j / v.W, cj = j - rj * v.W;
+    double acc = matern_d(ri - rj, ci - cj, v.res, sv, ls);
+    const float* U = v.cov + (size_t)env * v.cov_slot;
+    const int r = v.rank[env];
+    for (int k = 0; k < r; ++k) {
+        const unsigned rc = (unsigned)v.colrect[(size_t)env * v.rank_cap + k];
+        if (!rect_has(rc, ri, ci) || !rect_has(rc, rj, cj)) continue;
+        const int r0 = rc & 0xff, c0 = (rc >> 16) & 0xff;
+        const float* p = U + (size_t)k * v.pstride;
+        acc -= (double)p[(ri - r0) * v.pw + (ci - c0)] * (double)p[(rj - r0) * v.pw + (cj - c0)];
+    }
+    out[(size_t)i * v.N + j] = (float)acc;
+}
+
+}  // namespace ipp

@@ -107,7 +107,7 @@ class VecIPPEnv:
         # to the separate launch, 19.4-19.5 vs 19.3-20.3 M env-steps/s at window 12)
         self._fused_reset = bool(fused_reset and stagger and state == "factor" and
                                  (not shuffle_prior_cov or fused_reset == "always") and
-                                 self.engine.info.tile_threads == 256 and self.engine.info.window_rows > 0 and
+                                 self.engine.info.fused_step == 1 and self.engine.info.window_rows > 0 and
                                  4 * B * self.episode_steps <= (64 << 20))
         self._reset_src_by_phase = {}
         self._prior_ring = {}
