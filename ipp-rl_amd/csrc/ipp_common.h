@@ -162,7 +162,7 @@ struct View {
     int patch;       // 1: patch layout (then rect_meta == 1 and colrect holds every column's rectangle)
     int pw, ph;      // patch width (cells, even) and height (rows)
     int pstride;     // floats per stored column: ph * pw rounded up to 16
-    int pdiv;        // ceil(65536 / pw): flat / pw == (flat * pdiv) >> 16 for every flat index of a patch
+    int pdiv;        // ceil(2^18 / pw): flat / pw == (flat * pdiv) >> 18 for every flat index of a patch
     int plw;         // the prior table of the patch kernel is P0(|drow| < plw, |dcol| < plw)
     int pcap;        // column records per item kept in LDS (the rest in the item's global scratch block)
     int punits;      // most (64 lanes x 2 cells) units of one patch

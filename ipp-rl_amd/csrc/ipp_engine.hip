@@ -128,6 +128,8 @@ bool patch_layout(const ipp_config& c, int MC) {
     if (c.x_dim % 2 != 0 || c.x_dim > 256 || c.y_dim > 256) return false;
     if (!(c.x_dim > 2 * c.window_rows + 13)) return false;
     if (c.rank_cap > kPatchMaxRank) return false;
+    if (c.window_rows > 25) return false;  // (prior table of (R + 7)^2 floats and patches of (2 R + 6) x (2 R + 7) cells: small windows only)
+    if (!patch_division_exact(patch_geometry(c.x_dim, c.y_dim, c.window_rows))) return false;
     for (const char* name : {"IPP_RECT_META", "IPP_RECT", "IPP_CLIP_COLS", "IPP_FUSED", "IPP_PIPE", "IPP_VEC", "IPP_STEP_CHUNKS"})
         if (getenv(name)) return false;
     if (const char* p = getenv("IPP_PATCH")) return atoi(p) != 0;
@@ -704,8 +706,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         v.clip_cols = 1;
         v.rect_meta = 1;
         v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.pdiv = L.pg.pdiv; v.plw = L.pg.plw; v.punits = L.pg.punits;
-        for (int flat = 0; flat < v.ph * v.pw + 2 * kWave; ++flat)  // (the multiply-shift division of the kernel's flat index)
-            if ((int)(((unsigned)flat * (unsigned)v.pdiv) >> 16) != flat / v.pw) { delete e; return fail(-3, "patch index division is inexact for pw = %d", v.pw); }
         // column records in LDS: what fits the share of a workgroup when 16 waves of the kernel are resident per CU
         const size_t budget = (size_t)160 * 1024 / (16 / L.patch_waves);
         const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
@@ -782,7 +782,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
             e->pipe = e->pipe && pp && atoi(pp) != 0;
             if (e->pipe) v.rect_meta = 0;  // (the pipelined kernel's consumers do not stage the rectangles)
         }
-        if (v.T == kWave)
+        if (v.T == kWave && !e->patch)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;
         e->gain_lds = (e->gain_lds + 15) & ~(size_t)15;

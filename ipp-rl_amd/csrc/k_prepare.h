@@ -170,7 +170,7 @@ __device__ __forceinline__ void prep_sync() {
 struct ObsRegs { float gt, eps, mean[4]; };
 template <int MC> struct PrepLds;
 template <int MC>
-__device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, unsigned flags, unsigned char* small, const ObsRegs& o);
+__device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, unsigned flags, unsigned char* small, const ObsRegs o);
 
 template <int MC, int MODE, int NT, bool FRONT_ONLY, typename Mid, bool CHAIN = false, bool WAVE = false, bool DEFER = false>
 __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int item, const int* __restrict__ env_ids,
@@ -843,7 +843,7 @@ __device__ __forceinline__ int solve_wave(const View& v, const ItemHdr& h, const
 // LDS scratch (zz, vv).  simulations/simulations.py:26-34, sensor_manipulations.py:7-57, mappings.py:195.
 // The caller publishes the result to the solving wave (solve_wave_fast, obs_flag).
 template <int MC>
-__device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, unsigned flags, unsigned char* small, const ObsRegs& o) {
+__device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, unsigned flags, unsigned char* small, const ObsRegs o) {
     const PrepLds<MC> pl(small);
     double* L = pl.L; double* zz = pl.zz; double* vv = pl.vv; double* sub = pl.sub;
     const int lane = threadIdx.x & (kWave - 1);

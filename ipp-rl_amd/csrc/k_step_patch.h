@@ -35,8 +35,9 @@
 namespace ipp {
 
 constexpr int kPatchRec = 16;  // floats per column record
-constexpr int kPatchKP = 16;   // stored rows requested per group
+constexpr int kPatchKP = 8;    // stored rows requested per group
 constexpr int kPatchCtl = 32;  // control words
+constexpr int kPatchDivShift = 18;  // flat / pw == (flat * pdiv) >> 18, pdiv = ceil(2^18 / pw) (verified per engine: patch_division_exact)
 constexpr int kPatchMaxRank = 512;  // largest rank_cap of a patch engine (every thread tests kPatchMaxRank / threads rectangles)
 
 // Geometry of the patches for a config (host + device).
@@ -50,10 +51,16 @@ inline PatchGeo patch_geometry(int W, int H, int R) {
     g.pw = std::min((W + 1) & ~1, ((2 * R + 5 + 2) / 2) * 2);
     g.ph = std::min(H, 2 * R + 6);
     g.pstride = (g.pw * g.ph + 15) & ~15;
-    g.pdiv = (65536 + g.pw - 1) / g.pw;
+    g.pdiv = ((1 << kPatchDivShift) + g.pw - 1) / g.pw;
     g.plw = std::min(std::max(W, H), R + 7);
     g.punits = (g.ph * g.pw + 2 * kWave - 1) / (2 * kWave);
     return g;
+}
+
+inline bool patch_division_exact(const PatchGeo& g) {
+    for (int flat = 0; flat < g.ph * g.pw + 2 * kWave; ++flat)
+        if ((int)(((unsigned)flat * (unsigned)g.pdiv) >> kPatchDivShift) != flat / g.pw) return false;
+    return true;
 }
 
 struct PatchLds {
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         }
     }
     patch_sync<ONE>();
+    if (tid == 0) IPP_MARK(item, 4);
     int pos[RJ];
     int n_c = 0;
 #pragma unroll
@@ -300,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
             }
             if (tid < f) pl.ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv_d, ls_d);
         }
+        if (tid == 0) IPP_MARK(item, 5);
         gather_store(rc_pre[0], tid, con[0], pos[0], l0);
     }
 #pragma unroll 1
@@ -327,21 +336,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
     patch_sync<ONE>();
     if (tid == 0) IPP_MARK(item, 1);
 
-    // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
-    // v_readlane: no LDS round trip per stored row)
-    const int n_fast = min(n_lds, 2 * kWave);
-    int mcofs[2];
-    unsigned mlo[2], mex[2];
-#pragma unroll
-    for (int p2 = 0; p2 < 2; ++p2) {
-        const int a = p2 * kWave + lane;
-        mcofs[p2] = 0; mlo[p2] = 0x0000ffffu; mex[p2] = 0u;  // (empty rectangle)
-        if (a < n_fast) {
-            const float4 mt = *reinterpret_cast<const float4*>(lds.rec + (size_t)a * kPatchRec + 12);
-            mcofs[p2] = __float_as_int(mt.x); mlo[p2] = __float_as_uint(mt.y); mex[p2] = __float_as_uint(mt.z);
-        }
-    }
-
     // ------------------------------------------------------------------ m x m algebra (wave 0) / observation (wave OW)
     if (ONE) {
         observe_wave<MC>(v, h, flags, lds.small, oregs);
@@ -363,6 +357,21 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         if (lane == 0) __hip_atomic_store(obs_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
+    // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
+    // v_readlane: no LDS round trip per stored row)
+    const int n_fast = min(n_lds, 2 * kWave);
+    int mcofs[2];
+    unsigned mlo[2], mex[2];
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int a = p2 * kWave + lane;
+        mcofs[p2] = 0; mlo[p2] = 0x0000ffffu; mex[p2] = 0u;  // (empty rectangle)
+        if (a < n_fast) {
+            const float4 mt = *reinterpret_cast<const float4*>(lds.rec + (size_t)a * kPatchRec + 12);
+            mcofs[p2] = __float_as_int(mt.x); mlo[p2] = __float_as_uint(mt.y); mex[p2] = __float_as_uint(mt.z);
+        }
+    }
+
     // ------------------------------------------------------------------ units of the new patch: 64 lanes x 2 consecutive cells
     const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut;
     const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
@@ -372,8 +381,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
     const int lw = v.plw;
     unsigned long long units = 0;
     bool solved = false, dead = false;
-    float* mean_rw = v.mean + (size_t)h.env * v.Npad;
-    float* diag_rw = v.diag + (size_t)h.env * v.Npad;
+    const int env_u = h.env;
+    const bool rf1 = (h.rf == 1), commit_u = h.commit != 0;
+    float* mean_rw = v.mean + (size_t)env_u * v.Npad;
+    float* diag_rw = v.diag + (size_t)env_u * v.Npad;
     typedef float rowv __attribute__((ext_vector_type(VEC)));
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -383,15 +394,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= n_units) break;
         const int flat = 2 * (u * kWave + lane);
-        const int prow = (int)(((unsigned)flat * (unsigned)v.pdiv) >> 16), pcol = flat - prow * pw;
+        const int prow = (int)(((unsigned)flat * (unsigned)v.pdiv) >> kPatchDivShift), pcol = flat - prow * pw;
         const bool lane_valid = prow < hn && pcol < wn;
         const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
         const int cell0 = rrow * v.W + rcol;  // (clamped for the masked lanes: any valid address)
         float md_in[2][VEC];
         load_vec<VEC>(mean_rw + cell0, md_in[0]);
         load_vec<VEC>(diag_rw + cell0, md_in[1]);
-        const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> 16);
-        const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> 16));
+        const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> kPatchDivShift);
+        const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> kPatchDivShift));
         const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
         const unsigned flat4 = lane_valid ? (unsigned)flat * 4u : 0xffffffffu;  // byte offset of the lane's cells in a (shifted) patch; masked lanes out of range
 
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                     }
                 }
             };
-            if (h.rf == 1) base_term(std::integral_constant<int, 1>{});
+            if (rf1) base_term(std::integral_constant<int, 1>{});
             else base_term(std::integral_constant<int, 4>{});
         }
 
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
 #pragma unroll
             for (int c = 0; c < VEC; ++c) acc[c][j] = t[c];
         }
-        const bool commit = h.commit && !dead;
+        const bool commit = commit_u && !dead;
 
         // ---- epilogue: masked trace reduction, diag -= |Wc_i|^2, mean += Wc_i y, append the m new rows
         float dred[VEC], dmean[VEC];
@@ -571,6 +582,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                 for (int c = 0; c < VEC; ++c) outv[c] = md_in[0][c] + dmean[c];
                 store_vec<VEC>(mean_rw + cell0, outv);
             }
+        }
+        // the m new rows: every lane of the patch's rows stores (the padding columns pcol >= wn get zeros that no reader looks
+        // at): whole 512-byte runs instead of row segments with holes, i.e. no partially written sectors
+        if (commit && prow < hn) {
+            float outv[VEC];
 #pragma unroll
             for (int j = 0; j < MC; ++j)
                 if (j < m) {
@@ -598,21 +614,23 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
     if (arrived != NW - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     dead = __hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without units never looked)
-    const bool commit_item = h.commit && !dead;
+    const bool commit_item = commit_u && !dead;
+    const double cost_d = pl.hs->cost_d;  // (the header's other words are re-read from LDS: kept in SGPRs they stay live across the whole kernel)
+    const int t_span = pl.hs->t_lo | (pl.hs->t_hi << 16);
     if (lane == 0) {
         IPP_MARK(item, 2);
         double tot = 0.0;
         for (int t = 0; t < n_units; ++t) tot += lds.unit_red[t];  // unit order: bit-reproducible whatever wave took which unit
-        reward_out[item] = dead ? NAN : (float)(tot / (h.cost_d + 1.0));  // rewards.py:31
-        if (commit_item) v.rank[h.env] = r + m;
+        reward_out[item] = dead ? NAN : (float)(tot / (cost_d + 1.0));  // rewards.py:31
+        if (commit_item) v.rank[env_u] = r + m;
         unsigned long long* slotc = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
         if (cnt[0]) atomicAdd(slotc, cnt[0]);
     }
     if (commit_item && lane < m) {
-        v.colspan[(size_t)h.env * v.rank_cap + r + lane] = h.t_lo | (h.t_hi << 16);
-        v.colrect[(size_t)h.env * v.rank_cap + r + lane] = (int)rect_pack(r0n, r1n, c0n, c1n);
+        v.colspan[(size_t)env_u * v.rank_cap + r + lane] = t_span;
+        v.colrect[(size_t)env_u * v.rank_cap + r + lane] = (int)rect_pack(r0n, r1n, c0n, c1n);
     }
-    if (reset_k >= 0) wave_reset_env(v, ar, h.env, reset_k, lane);  // (after the rank store above, same lane 0)
+    if (reset_k >= 0) wave_reset_env(v, ar, env_u, reset_k, lane);  // (after the rank store above, same lane 0)
 }
 
 // Patch-layout factor state -> dense P = P0 - U U^T (ipp_read_cov_dense: tests, np.diag(state), feature planes).

@@ -126,7 +126,7 @@ def _engines(dim, B):
         cfg = EngineConfig(x_dim=dim, y_dim=dim)
         win = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, window_rows=-1, fixed_prior=True)
         exact = IPPEngine(cfg, capacity=B, state="factor", rank_cap=360, window_rows=0)
-        assert win.info.window_rows == 10 and win.info.tile_threads == 256
+        assert win.info.window_rows == 10 and win.info.fused_step == 1
         _PAIR[key] = (cfg, win, exact)
     return _PAIR[key]
 
