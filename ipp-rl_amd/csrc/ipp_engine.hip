@@ -707,7 +707,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         v.rect_meta = 1;
         v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.pdiv = L.pg.pdiv; v.plw = L.pg.plw; v.punits = L.pg.punits;
         // column records in LDS: what fits the share of a workgroup when 16 waves of the kernel are resident per CU
-        const size_t budget = (size_t)160 * 1024 / (16 / L.patch_waves);
+        size_t budget = (size_t)160 * 1024 / (16 / L.patch_waves);
+        if (const char* wg = getenv("IPP_PATCH_WGS")) { if (atoi(wg) > 0) budget = (size_t)160 * 1024 / atoi(wg) / 16 * 16; }  // A/B: workgroups per CU to leave room for
         const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
         int pcap = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;
         if (const char* pc = getenv("IPP_PATCH_CAP")) pcap = std::max(8, atoi(pc));  // A/B experiments, overflow tests
@@ -1483,6 +1484,18 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
         std::vector<unsigned long long> tl(n);
         HIP_TRY(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_timeline), n * 8));
         if (FILE* f = fopen(path, "wb")) { fwrite(tl.data(), 8, n, f); fclose(f); }
+    }
+    {
+        unsigned long long wp[16];
+        HIP_TRY(hipMemcpyFromSymbol(wp, HIP_SYMBOL(g_wphase), sizeof wp));
+        if (wp[10]) {
+            const double u = (double)wp[10], w = (double)std::max<unsigned long long>(wp[11], 1);
+            fprintf(stderr, "[k_step_patch wave phases, shader clocks] per unit: setup+compaction %.0f  prior term %.0f  stream %.0f  solve wait %.0f  "
+                            "epilogue %.0f  stores %.0f | per wave: prologue %.0f  algebra/observation %.0f  results %.0f | units %.0f waves %.0f groups/unit %.2f\n",
+                    wp[0] / u, wp[1] / u, wp[2] / u, wp[3] / u, wp[4] / u, wp[5] / u, wp[6] / w, wp[7] / w, wp[8] / w, u, w, wp[9] / u);
+        }
+        memset(wp, 0, sizeof wp);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wphase), wp, sizeof wp));
     }
 #endif
     if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, (size_t)kCountSlots * 128, s));

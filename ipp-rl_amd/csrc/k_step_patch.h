@@ -35,7 +35,16 @@
 namespace ipp {
 
 constexpr int kPatchRec = 16;  // floats per column record
-constexpr int kPatchKP = 8;    // stored rows requested per group
+#ifndef IPP_PATCH_KP
+#define IPP_PATCH_KP 12
+#endif
+#ifndef IPP_PATCH_ABLATE
+#define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads
+#endif
+#ifndef IPP_PATCH_MINW
+#define IPP_PATCH_MINW 4
+#endif
+constexpr int kPatchKP = IPP_PATCH_KP;   // stored rows requested per group
 constexpr int kPatchCtl = 32;  // control words
 constexpr int kPatchDivShift = 18;  // flat / pw == (flat * pdiv) >> 18, pdiv = ceil(2^18 / pw) (verified per engine: patch_division_exact)
 constexpr int kPatchMaxRank = 512;  // largest rank_cap of a patch engine (every thread tests kPatchMaxRank / threads rectangles)
@@ -90,13 +99,32 @@ struct PatchLds {
     }
 };
 
+// acc += q[lane J of this lane's row of 16] * u: the row's -HT values live in the LANES of one register (lane l holds value
+// l & 15, read from the LDS record with one ds_read_b32 per stored row while the row requests are in flight) and reach the FMAs
+// through the DPP row broadcast -- no LDS read and no wait inside the FMA chain (three broadcast ds_read_b128 per row with a
+// wait in front of their first use cost ~4 us per unit: the row loop was a chain of exposed LDS latencies)
+template <int J>
+__device__ __forceinline__ void fmac_bc(float& acc, float q, float u) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q), "v"(u), "n"(J));
+}
+template <int VEC, int MC>
+__device__ __forceinline__ void fmac_row(float (&acc)[VEC][MC], float q, const float (&u)[VEC]) {
+    static_assert(MC == 9, "unrolled for MC = 9");
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        fmac_bc<0>(acc[c][0], q, u[c]); fmac_bc<1>(acc[c][1], q, u[c]); fmac_bc<2>(acc[c][2], q, u[c]);
+        fmac_bc<3>(acc[c][3], q, u[c]); fmac_bc<4>(acc[c][4], q, u[c]); fmac_bc<5>(acc[c][5], q, u[c]);
+        fmac_bc<6>(acc[c][6], q, u[c]); fmac_bc<7>(acc[c][7], q, u[c]); fmac_bc<8>(acc[c][8], q, u[c]);
+    }
+}
+
 template <bool ONE>
 __device__ __forceinline__ void patch_sync() {
     if (ONE) wave_lds_sync(); else __syncthreads();
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
+__global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     View v, const int* __restrict__ env_ids, int n_items, const double* __restrict__ action,
     const double* __restrict__ prev_action, const float* __restrict__ meas_noise, unsigned flags,
     int* __restrict__ status_out, float* __restrict__ reward_out, AutoReset ar) {
@@ -110,6 +138,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
     const int item = launch_item(v, blockIdx.x, n_items);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (tid == 0) IPP_MARK(item, 0);
+    IPP_WT_DECL;
     int* next_unit = lds.ctl; int* done_waves = lds.ctl + 1; int* solve_flag = lds.ctl + 2; int* obs_flag = lds.ctl + 3;
     int* wcnt = lds.ctl + 8;  // [RJ][NW] contributing columns found by wave w among its columns j
 
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                         const unsigned fy = yx >> 16, fx = yx & 0xffffu;
                         const bool in = on && fy >= r0k && fy <= r1k && fx >= c0k && fx <= c1k;
                         const unsigned voff = in ? (unsigned)(base + (int)(fy * (unsigned)pw + fx)) * 4u : 0xffffffffu;
-                        l[i][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
+                        l[i][a] = (IPP_PATCH_ABLATE & 32) ? __uint_as_float(voff) * 1e-30f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
                     }
                 }
             }
@@ -335,6 +364,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
     if (n_ovf > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // overflow records are read back by the other waves
     patch_sync<ONE>();
     if (tid == 0) IPP_MARK(item, 1);
+    IPP_WT(6);
 
     // ------------------------------------------------------------------ m x m algebra (wave 0) / observation (wave OW)
     if (ONE) {
@@ -357,6 +387,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         if (lane == 0) __hip_atomic_store(obs_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
+    IPP_WT(7);
     // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
     // v_readlane: no LDS round trip per stored row)
     const int n_fast = min(n_lds, 2 * kWave);
@@ -399,8 +430,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
         const int cell0 = rrow * v.W + rcol;  // (clamped for the masked lanes: any valid address)
         float md_in[2][VEC];
-        load_vec<VEC>(mean_rw + cell0, md_in[0]);
-        load_vec<VEC>(diag_rw + cell0, md_in[1]);
+        if (IPP_PATCH_ABLATE & 128) { md_in[0][0] = md_in[0][1] = 0.5f; md_in[1][0] = md_in[1][1] = 1.f; }
+        else { load_vec<VEC>(mean_rw + cell0, md_in[0]); load_vec<VEC>(diag_rw + cell0, md_in[1]); }
         const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> kPatchDivShift);
         const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> kPatchDivShift));
         const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
@@ -418,7 +449,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                 else if (a < cap) { lo = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 13]); ex = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 14]); }
                 else { lo = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 13]); ex = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 14]); }
                 const int r0k = lo & 0xffff, r1k = r0k + (int)(ex & 0xffff);
-                on = r1k >= urow0 && r0k <= urow1;
+                on = (IPP_PATCH_ABLATE & 64) ? true : (r1k >= urow0 && r0k <= urow1);
             }
             const unsigned long long mask = __ballot(on);
             if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)a;
@@ -429,6 +460,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         // group tail: entries past nact repeat the first active record with their requests masked off (0 * finite = 0)
         if (nact > 0 && lane < KP) ridx[nact + lane] = ridx[0];
         __builtin_amdgcn_wave_barrier();
+        IPP_WT(0);
 
         // ---- base term from the analytic prior: acc[.][b] = sum_{f in block b} w_f P0[cell, F_f]  (Wc L, L^-1 in the epilogue)
         float acc[VEC][MC];
@@ -461,17 +493,19 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                     }
                 }
             };
-            if (rf1) base_term(std::integral_constant<int, 1>{});
+            if (IPP_PATCH_ABLATE & 4) { acc[0][0] = (float)rrow; acc[1][0] = (float)rcol; }
+            else if (rf1) base_term(std::integral_constant<int, 1>{});
             else base_term(std::integral_constant<int, 4>{});
         }
 
+        IPP_WT(1);
         // ---- stream the stored rows: acc += patch_k[flat + shift_k] * (-HT[k,:])
         // FAST: every record of the group is one of the first 128 and lies in one 64-record page: its patch offset and rectangle
         // come out of this wave's registers through v_readlane with the record index as the (scalar) lane select, -HT from the
         // LDS record.  Else (more than 128 contributing columns, or records in the global overflow block): generic pointers.
         auto group = [&](int a0, auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
-            const int ev = ridx[a0 + (lane & (KP - 1))];
+            const int ev = ridx[a0 + min(lane, KP - 1)];  // (lane i < KP holds the i-th record of the group)
             rowv uu[KP];
             int es[KP];
             const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
@@ -499,22 +533,22 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                 const bool ok = (int)(a0 + i < nact) &
                                 (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
                 const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slot) + cofs, 0, 0x7ffffff0, 0x00020000);
-                uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, 2));  // (aux 2: nt)
+                if (IPP_PATCH_ABLATE & 1) uu[i] = (rowv)(__int_as_float(cofs) * 1e-30f + (ok ? 1.f : 0.f));
+                else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, 2));  // (aux 2: nt)
+            }
+            // -HT of the group's rows, value l & 15 in lane l (read while the requests are in flight)
+            float qr[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
+                qr[i] = rp[lane & 15];
             }
             __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
-                const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
-                float qv[12];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
-                    qv[4 * q] = t.x; qv[4 * q + 1] = t.y; qv[4 * q + 2] = t.z; qv[4 * q + 3] = t.w;
-                }
-#pragma unroll
-                for (int j = 0; j < MC; ++j)
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) acc[c][j] = fmaf(uu[i][c], qv[j], acc[c][j]);
+                if (IPP_PATCH_ABLATE & 16) { acc[0][0] = fmaf(uu[i][0], qr[i], acc[0][0]); acc[1][0] = fmaf(uu[i][1], qr[i], acc[1][0]); continue; }
+                const float ur[VEC] = {uu[i][0], uu[i][1]};
+                fmac_row<VEC, MC>(acc, qr[i], ur);
             }
         };
         for (int a0 = 0; a0 < nact; a0 += KP) {
@@ -524,14 +558,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
             else group(a0, std::false_type{});
         }
 
+        IPP_WT(2);
+        IPP_WT_COUNT(9, (nact + KP - 1) / KP);
+        IPP_WT_COUNT(10, 1);
         // ---- wait (first unit only) for L^-1 and y, then Wc = (P[:,F] H_F^T) L^-1 in place (column j needs the entries b <= j)
         if (!solved) {
             while (__hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
             solved = true;
             dead = __hip_atomic_load(solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
         }
+        IPP_WT(3);
 #pragma unroll
-        for (int j = MC - 1; j >= 0; --j) {
+        for (int j = MC - 1; j >= ((IPP_PATCH_ABLATE & 8) ? MC : 0); --j) {
             float t[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) t[c] = 0.f;
@@ -572,7 +610,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         const int in_cells = __popcll(__ballot(lane_valid)) * VEC;
         // (stored rows + m new rows + mean and diag read and written) floats per touched cell
         units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells;
-        if (commit && lane_valid) {
+        IPP_WT(4);
+        if (commit && lane_valid && !((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) outv[c] = md_in[1][c] - dred[c];
@@ -585,7 +624,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         }
         // the m new rows: every lane of the patch's rows stores (the padding columns pcol >= wn get zeros that no reader looks
         // at): whole 512-byte runs instead of row segments with holes, i.e. no partially written sectors
-        if (commit && prow < hn) {
+        if (commit && prow < hn && !((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) {
             float outv[VEC];
 #pragma unroll
             for (int j = 0; j < MC; ++j)
@@ -596,7 +635,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
                 }
         }
         __builtin_amdgcn_wave_barrier();
+        IPP_WT(5);
     }
+    IPP_WT(0);
+    IPP_WT_COUNT(11, 1);
 
     // ------------------------------------------------------------------ per-item results (last wave to arrive)
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds.red);
@@ -611,7 +653,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
     if (lane == 0) arrived = atomicAdd(done_waves, 1);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
     if (arrived == 0 && lane == 0) IPP_MARK(item, 6);
-    if (arrived != NW - 1) return;
+    if (arrived != NW - 1) { IPP_WT_FLUSH(lane); return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     dead = __hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;  // (a wave without units never looked)
     const bool commit_item = commit_u && !dead;
@@ -631,6 +673,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_step_patch(
         v.colrect[(size_t)env_u * v.rank_cap + r + lane] = (int)rect_pack(r0n, r1n, c0n, c1n);
     }
     if (reset_k >= 0) wave_reset_env(v, ar, env_u, reset_k, lane);  // (after the rank store above, same lane 0)
+    IPP_WT(8);
+    IPP_WT_FLUSH(lane);
 }
 
 // Patch-layout factor state -> dense P = P0 - U U^T (ipp_read_cov_dense: tests, np.diag(state), feature planes).

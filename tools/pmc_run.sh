@@ -6,7 +6,9 @@ out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 python3 bench.py --print-args "$@" > "$out/bench_args.json"
-if [ "$PMC_SETS" = "traffic" ]; then  # HBM bytes only (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+if [ -n "$PMC_CUSTOM" ]; then  # ';'-separated counter sets (diagnostics)
+  IFS=';' read -ra sets <<< "$PMC_CUSTOM"
+elif [ "$PMC_SETS" = "traffic" ]; then  # HBM bytes only (FETCH_SIZE and WRITE_SIZE do not fit one pass)
   sets=("FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum")
 else
   sets=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES"
