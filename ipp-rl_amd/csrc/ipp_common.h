@@ -27,15 +27,23 @@
 constexpr int kTimelineItems = 65536;
 __device__ unsigned long long g_timeline[8 * kTimelineItems];  // per item: start, end of phase A, end, header done, observation done, gather done
 #define IPP_MARK(item, k) do { if ((item) < kTimelineItems) g_timeline[8 * (item) + (k)] = wall_clock64(); } while (0)
-// per-wave phase clocks of k_step_patch (shader clock, s_memtime): a wave sums the time between its ticks per phase in
-// scalar registers and adds the sums to g_wphase when it exits; ipp_streamed_bytes prints and clears them
+// per-wave phase clocks of k_step_patch (shader clock, s_memtime; -DIPP_WAVE_CLOCKS=1 on top of IPP_TIMELINE: the clock reads
+// serialise the wave and make the kernel several times slower -- proportions only): a wave sums the time between its ticks per
+// phase in scalar registers and adds the sums to g_wphase when it exits; ipp_streamed_bytes prints and clears them
 __device__ unsigned long long g_wphase[16];
+#ifndef IPP_WAVE_CLOCKS
+#define IPP_WAVE_CLOCKS 0
+#endif
+#endif
+#if IPP_TIMELINE && IPP_WAVE_CLOCKS
 #define IPP_WT_DECL unsigned long long wt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wt_last_ = clock64()
 #define IPP_WT(k) do { const unsigned long long n_ = clock64(); wt_[k] += n_ - wt_last_; wt_last_ = n_; } while (0)
 #define IPP_WT_COUNT(k, n) do { wt_[k] += (n); } while (0)
 #define IPP_WT_FLUSH(lane) do { if ((lane) == 0) for (int q_ = 0; q_ < 12; ++q_) if (wt_[q_]) atomicAdd(&g_wphase[q_], wt_[q_]); } while (0)
 #else
+#if !IPP_TIMELINE
 #define IPP_MARK(item, k) ((void)0)
+#endif
 #define IPP_WT_DECL ((void)0)
 #define IPP_WT(k) ((void)0)
 #define IPP_WT_COUNT(k, n) ((void)0)

@@ -118,6 +118,41 @@ __device__ __forceinline__ void fmac_row(float (&acc)[VEC][MC], float q, const f
     }
 }
 
+// Wc[.][J] = sum_{b <= J} (Wc L)[.][b] * Linv[b][J]: row b of L^-1 sits in the lanes of lrow[b] (value J in lane J of every row of 16)
+template <int J, int VEC, int MC>
+__device__ __forceinline__ void linv_col(float (&acc)[VEC][MC], const float (&lrow)[MC]) {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        float t = 0.f;
+#pragma unroll
+        for (int b = 0; b <= J; ++b) fmac_bc<J>(t, lrow[b], acc[c][b]);
+        acc[c][J] = t;
+    }
+}
+template <int MC>
+__device__ __forceinline__ float dot_lanes(const float (&a)[MC], float yreg) {  // sum_j a[j] * y[j], y[j] in lane j of every row of 16
+    static_assert(MC == 9, "unrolled for MC = 9");
+    float d = 0.f;
+    fmac_bc<0>(d, yreg, a[0]); fmac_bc<1>(d, yreg, a[1]); fmac_bc<2>(d, yreg, a[2]); fmac_bc<3>(d, yreg, a[3]); fmac_bc<4>(d, yreg, a[4]);
+    fmac_bc<5>(d, yreg, a[5]); fmac_bc<6>(d, yreg, a[6]); fmac_bc<7>(d, yreg, a[7]); fmac_bc<8>(d, yreg, a[8]);
+    return d;
+}
+// Sum over the wave without LDS permutes (six dependent ds_bpermute round trips per unit): quads, half rows and rows through
+// DPP, the four row sums through v_readlane.  Every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x += dpp_mov_f64<0xB1>(x);   // quad_perm [1, 0, 3, 2]
+    x += dpp_mov_f64<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+    x += dpp_mov_f64<0x141>(x);  // row_half_mirror
+    x += dpp_mov_f64<0x140>(x);  // row_mirror
+    return (bcast_lane(x, 0) + bcast_lane(x, 16)) + (bcast_lane(x, 32) + bcast_lane(x, 48));
+}
+
 template <bool ONE>
 __device__ __forceinline__ void patch_sync() {
     if (ONE) wave_lds_sync(); else __syncthreads();
@@ -568,19 +603,15 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
             dead = __hip_atomic_load(solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
         }
         IPP_WT(3);
+        // L^-1 row b in the lanes of lrow[b], y in the lanes of yreg: ten LDS reads in flight together, the 90 + 18 FMAs take their
+        // coefficients through the DPP row broadcast (45 + 9 dependent broadcast reads before)
+        float lrow[MC], yreg;
 #pragma unroll
-        for (int j = MC - 1; j >= ((IPP_PATCH_ABLATE & 8) ? MC : 0); --j) {
-            float t[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) t[c] = 0.f;
-#pragma unroll
-            for (int b = 0; b <= j; ++b) {
-                const float l = Ls[b * MC + j];
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) t[c] = fmaf(acc[c][b], l, t[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) acc[c][j] = t[c];
+        for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
+        yreg = ys[min(lane & 15, MC - 1)];
+        if (!(IPP_PATCH_ABLATE & 8)) {
+            linv_col<8>(acc, lrow); linv_col<7>(acc, lrow); linv_col<6>(acc, lrow); linv_col<5>(acc, lrow); linv_col<4>(acc, lrow);
+            linv_col<3>(acc, lrow); linv_col<2>(acc, lrow); linv_col<1>(acc, lrow); linv_col<0>(acc, lrow);
         }
         const bool commit = commit_u && !dead;
 
@@ -592,8 +623,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
             float w2 = 0.f, dm = 0.f;
 #pragma unroll
             for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
-#pragma unroll
-            for (int j = 0; j < MC; ++j) dm = fmaf(acc[c][j], ys[j], dm);
+            dm = dot_lanes<MC>(acc[c], yreg);
             if (!lane_valid) {
                 w2 = 0.f; dm = 0.f;
 #pragma unroll
@@ -605,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
             const bool in_mask = !adaptive || ((double)md_in[0][c] + v.kf * (double)md_in[1][c] >= v.thr);
             if (lane_valid && in_mask) part += (double)w2;
         }
-        part = wave_sum(part);
+        part = wave_sum_dpp(part);
         if (lane == 0) lds.unit_red[u] = part;
         const int in_cells = __popcll(__ballot(lane_valid)) * VEC;
         // (stored rows + m new rows + mean and diag read and written) floats per touched cell
