@@ -70,6 +70,8 @@ def build_parser():
                     help="scheduled episode resets inside the step launch (ipp_step_autoreset; VecIPPEnv's default)")
     ap.add_argument("--no-fused-resets", dest="fused_resets", action="store_false",
                     help="A/B: the scheduled resets as their own launch after every step")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps steps each (barrier + sync around every one); `value` is the median region")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
     return ap
 
@@ -261,7 +263,7 @@ def pmc_traffic(kernel_name, key):
 # --------------------------------------------------------------------------------------------- the measurement
 def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_envs, episode_steps, state="factor",
                      window_rows=-1, shuffle_prior=False, tile_threads=0, predict_only=False, fused_resets=True,
-                     steps=80, warmup=8, timed=True):
+                     steps=80, warmup=8, timed=True, regions=1):
     """One workload: build the batched env, pre-roll to the stationary rank mix, W warm-up steps, the timed region
     (all ranks), then the roofline leg (same steps again with HIP events on the streaming kernel's dispatches).
     Returns a dict of plain numbers."""
@@ -274,7 +276,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
                     stagger=True, tile_threads=tile_threads, window_rows=window_rows, fused_reset=fused_resets,
                     shuffle_prior_cov=shuffle_prior)
     eng = env.engine
-    n_total = T + warmup + 2 * steps
+    n_total = T + warmup + (regions + 1) * steps
     # synthetic inputs resident in HBM before the timed region
     actions = torch.stack([
         torch.as_tensor(cell_centre_actions(cfg, t, env_lo, env_lo + B, total_envs, ALTITUDES), dtype=torch.float64)
@@ -296,7 +298,11 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
             t_idx += 1
 
     run_steps(warmup)
-    per_rank, elapsed_max = timed_region(run_steps, steps, torch.cuda.synchronize, ranks)
+    # `regions` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + device sync on both sides; the
+    # reported region is the MEDIAN one (by the max-over-ranks time), the spread goes into the record
+    timed_regions = [timed_region(run_steps, steps, torch.cuda.synchronize, ranks) for _ in range(max(1, regions))]
+    order_r = sorted(range(len(timed_regions)), key=lambda i: timed_regions[i][1])
+    per_rank, elapsed_max = timed_regions[order_r[len(order_r) // 2]]
     bad = int((env.status != 0).sum().item())
     bad_rewards = int((~torch.isfinite(env.reward)).sum().item())
 
@@ -346,6 +352,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "grid": grid, "envs_local": B, "episode_steps": T, "state": state, "predict_only": bool(predict_only),
         "window_rows": int(eng.info.window_rows), "tile_threads": int(eng.info.tile_threads),
         "per_rank_s": per_rank, "elapsed_max_s": elapsed_max, "steps": steps, "warmup": warmup,
+        "region_elapsed_max_s": [r[1] for r in timed_regions],
         "mean_rank_after_step": mean_rank_after, "bad_status": bad, "bad_rewards": bad_rewards,
         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
         "bytes_per_launch": bytes_per_launch, "mask_reread_bytes_per_launch": mask_reread if state == "factor" else 0.0,
@@ -495,7 +502,11 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
 def extra_record(name, rec, total_envs):
     return {"name": name, "value": aggregate_rate(total_envs, rec["steps"], rec["elapsed_max_s"]), "unit": "env-steps/s",
             "ms_per_step": 1e3 * rec["elapsed_max_s"] / rec["steps"], "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"],
-            "achieved_gbs": rec["achieved_gbs"], "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "window_rows": rec["window_rows"],
+            "achieved_gbs": rec["achieved_gbs"], "frac": rec["achieved_gbs"] / HBM_PEAK_GBS,
+            "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / rec["steps"]) / 1e9 / HBM_PEAK_GBS,
+            "frac_definition": "frac: algorithmic bytes / the dominant kernel's average duration; step_frac: the same bytes / the whole step period "
+                               "(every launch of the step, resets and ground-truth generation included)",
+            "window_rows": rec["window_rows"],
             "mean_rank_after_step": rec["mean_rank_after_step"], "arena_gb": rec["arena_gb"],
             "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"]}
 
@@ -527,7 +538,7 @@ def main(argv=None):
                                 episode_steps=T, state=args.state, window_rows=args.window_rows,
                                 shuffle_prior=args.shuffle_prior, tile_threads=args.tile_threads,
                                 predict_only=args.predict_only, fused_resets=args.fused_resets, steps=args.steps,
-                                warmup=args.warmup)
+                                warmup=args.warmup, regions=args.regions)
     if rank == 0:
         traffic, traffic_source = pmc_traffic(rec["kernel"], workload_key(args))
         out = {
@@ -553,22 +564,28 @@ def main(argv=None):
                 "prior": "shuffled per episode (window sized for 1.2 l)" if args.shuffle_prior else "fixed (example.yaml)",
                 "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"],
                 "rng": "device Philox4x32-10 keyed on the global env id",
+                "timed_regions": len(rec["region_elapsed_max_s"]),
+                "region_ms_per_step": [1e3 * t / args.steps for t in rec["region_elapsed_max_s"]],
+                "region_ms_per_step_min_max": [1e3 * min(rec["region_elapsed_max_s"]) / args.steps, 1e3 * max(rec["region_elapsed_max_s"]) / args.steps],
+                "value_is": "median of the timed regions (each exactly `steps` steps, max over ranks)",
                 "per_rank_ms_per_step": [1e3 * t / args.steps for t in rec["per_rank_s"]],
                 "per_rank_env_steps_per_s": [B * args.steps / t for t in rec["per_rank_s"]],
             },
             "roofline": {
                 "bound": "hbm", "achieved": rec["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_over_algorithmic": (traffic / rec["bytes_per_launch"]) if traffic and rec["bytes_per_launch"] else None,
+                "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "launches": rec["launches"],
                 "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
                 "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device: "
                                                 "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
-                                                "cells of the rectangle within window_rows of the footprint in BOTH directions (the new columns are stored on "
-                                                "that rectangle only and carry it as metadata: nothing is written to, or read from, the rest of the row band)",
-                "note": "a step moves ~1/5 of the bytes it moved on row-band windows (two-dimensional windows, then rectangle metadata "
-                        "instead of stored zeros) in ~0.55 of the time: the kernel is bound by latency (a workgroup's prologue is half of "
-                        "its life, a rectangle is 4-6 wave-sized units), not by HBM; traffic exceeds the algorithmic bytes because the "
-                        "64-byte sectors of the grid rows a rectangle crosses are fetched whole (DESIGN.md sections 2, 5)",
+                                                "cells of the rectangle within window_rows of the footprint in BOTH directions (a stored column IS that "
+                                                "rectangle, as a compact patch; the padding columns a patch row may have are neither counted nor read)",
+                "note": "columns of U are stored as compact patches of their rectangles (k_step_patch.h): a wave's request for a stored row is 512 "
+                        "consecutive bytes, the new rows are written as whole runs; the kernel is bound by the per-item chain of dependent round "
+                        "trips and by instruction issue (prologue + m x m algebra are ~1/2 of an item's wave-time), not by HBM: the same row "
+                        "stream without arithmetic runs at 5.1 TB/s (tools/probes/patch_probe.hip, profiles/r03_patch_probe.txt)",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],

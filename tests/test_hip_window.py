@@ -17,20 +17,25 @@ def host(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
 
-def engine(dim, window_rows, tile_threads=256, capacity=2):
+def engine(dim, window_rows, tile_threads=256, capacity=2, fixed_prior=False):
     from ipp_rl_amd import EngineConfig, IPPEngine
 
     return IPPEngine(EngineConfig(x_dim=dim, y_dim=dim), capacity=capacity, state="factor", rank_cap=400,
-                     window_rows=window_rows, tile_threads=tile_threads)
+                     window_rows=window_rows, tile_threads=tile_threads, fixed_prior=fixed_prior)
 
 
+# (window_rows, fixed_prior, tile_threads): window 12 on every kernel family -- one wave per item (64), split prologue + gain
+# (128), fused band / rectangle tiles (256), compact patches (0 = the engine's choice: k_step_patch) -- and the HEADLINE
+# configuration of bench.py, the minimum window of a fixed prior (-1 -> 10 rows) on the patch kernel, pinned to the golden
+# episodes directly
 @pytest.mark.parametrize("name", ["episode_rf1_50_s0", "episode_mixed_50_s1"])
-@pytest.mark.parametrize("tile_threads", [64, 128, 256])
-def test_window12_episode_vs_golden(golden, name, tile_threads):
+@pytest.mark.parametrize("window_rows,fixed_prior,tile_threads", [(12, False, 64), (12, False, 128), (12, False, 256), (12, False, 0), (-1, True, 0)])
+def test_window12_episode_vs_golden(golden, name, window_rows, fixed_prior, tile_threads):
     g = golden(name)
     dim = g["gt"].shape[0]
-    eng = engine(dim, 12, tile_threads)
-    assert eng.info.window_rows == 12
+    eng = engine(dim, window_rows, tile_threads, fixed_prior=fixed_prior)
+    assert eng.info.window_rows == (12 if window_rows == 12 else 10)
+    assert eng.info.patch_layout == (1 if tile_threads == 0 else 0)
     eng.reset(env_ids=[0], white_noise=g["white"][None])
     prev = np.array([2.0, 2.0, 14.0])
     worst = dict(reward=0.0, mean=0.0, diag=0.0)
@@ -48,7 +53,7 @@ def test_window12_episode_vs_golden(golden, name, tile_threads):
     full = float(np.sum(4.0 * N * (r_before + g["m"]) + 16.0 * N))
     P = host(eng.read_cov(0))
     err_rows = np.max(np.abs(P[g["sample_rows"]] - g["P_final_rows"]))
-    print(f"[window 12, T={tile_threads}, {name}] worst {worst} P rows {err_rows:.2e}; streamed {streamed / full:.2f} of full-column bytes")
+    print(f"[window {eng.info.window_rows}, T={tile_threads}, {name}] worst {worst} P rows {err_rows:.2e}; streamed {streamed / full:.2f} of full-column bytes")
     assert max(worst.values()) < TOL and err_rows < TOL
     assert streamed < 0.8 * full
 
