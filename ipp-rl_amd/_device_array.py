@@ -11,9 +11,13 @@ A DeviceCov is what those calls now return: an array-LIKE object (it implements 
 and arithmetic) that owns one dense state slot of the compat engine.  Passed back into a map operation it is used in
 place on the device (the step writes a NEW slot, like the reference allocates a new P'); np.diag / np.trace / .diagonal()
 read the engine's cached diagonal (10 KB); anything else -- str(), slicing, arithmetic, pickling, deepcopy -- materialises
-the float64 matrix on the host once and caches it.  Writing through it (state[~mask, :] = 0, features.py:98-99) lands in
-the host copy and detaches the device slot, so the next map operation uploads the modified matrix: aliasing semantics of
-the reference are kept.  Slots are recycled when their DeviceCov is garbage-collected; when all are in use the least
+the float64 matrix on the host once and caches it.  Writing through it (state[~mask, :] = 0, features.py:98-99; ufuncs with
+out=state; np.fill_diagonal / np.copyto / np.put / np.place / np.putmask on it) lands in the host copy and detaches the
+device slot, so the next map operation uploads the modified matrix: aliasing semantics of the reference are kept.  While a
+device slot is attached, every array or view that ESCAPES (np.asarray(state), state[i], state.T, state.ravel(), iteration)
+is READ-ONLY: a write through it would change the cached host copy only and the next map operation would silently use the
+stale device copy -- it raises "assignment destination is read-only" instead; once detached, the host matrix is the
+state and is handed out writable like any ndarray.  Slots are recycled when their DeviceCov is garbage-collected; when all are in use the least
 recently used state is moved to the host.
 """
 from __future__ import annotations
@@ -23,6 +27,9 @@ from collections import OrderedDict
 from typing import Optional
 
 import numpy as np
+
+
+_MUTATING = (np.fill_diagonal, np.copyto, np.put, np.place, np.putmask)  # array functions that write into their first argument
 
 
 class SlotStore:
@@ -115,6 +122,22 @@ class DeviceCov:
             self._store.downloads += 1
         return self._host
 
+    def _view(self) -> np.ndarray:
+        """The matrix as callers may see it: the host copy itself once the device slot is gone, a read-only view of the cache
+        while the device copy is the live one."""
+        host = self._materialise()
+        if self._slot is None:
+            return host
+        ro = host.view()
+        ro.flags.writeable = False
+        return ro
+
+    def _writable(self) -> np.ndarray:
+        """The host matrix as the one live copy (for in-place writes): the device slot is dropped."""
+        host = self._materialise()
+        self._detach()
+        return host
+
     def device_slot(self, store: SlotStore) -> Optional[int]:
         """Slot holding this state in `store`'s engine, uploading the host copy if it was evicted or modified; None when
         the object belongs to another engine (the caller then treats it as a plain array)."""
@@ -133,13 +156,13 @@ class DeviceCov:
     ndim = 2
     dtype = np.dtype(np.float64)
     size = property(lambda self: self._n * self._n)
-    T = property(lambda self: self._materialise().T)
+    T = property(lambda self: self._view().T)
 
     def __len__(self):
         return self._n
 
     def __array__(self, dtype=None, copy=None):
-        a = self._materialise()
+        a = self._view()
         if dtype is not None and np.dtype(dtype) != a.dtype:
             return a.astype(dtype)
         return a.copy() if copy else a
@@ -156,28 +179,28 @@ class DeviceCov:
             return self.diagonal()
         if func is np.trace and len(args) == 1 and not kwargs and args[0] is self:
             return float(self.diagonal().sum())
+        if func in _MUTATING and args and isinstance(args[0], DeviceCov):  # in-place writes into the state: host copy, slot dropped
+            args = (args[0]._writable(),) + tuple(args[1:])
         args = tuple(np.asarray(a) if isinstance(a, DeviceCov) else a for a in args)
-        kwargs = {k: (np.asarray(v) if isinstance(v, DeviceCov) else v) for k, v in kwargs.items()}
+        kwargs = {k: ((v._writable() if k == "out" else np.asarray(v)) if isinstance(v, DeviceCov) else v) for k, v in kwargs.items()}
         return func(*args, **kwargs)
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         inputs = tuple(np.asarray(a) if isinstance(a, DeviceCov) else a for a in inputs)
-        if "out" in kwargs:
-            kwargs["out"] = tuple(np.asarray(o) if isinstance(o, DeviceCov) else o for o in kwargs["out"])
+        if "out" in kwargs:  # (written in place: the host copy becomes the state)
+            kwargs["out"] = tuple(o._writable() if isinstance(o, DeviceCov) else o for o in kwargs["out"])
         return getattr(ufunc, method)(*inputs, **kwargs)
 
     def __getitem__(self, idx):
-        return self._materialise()[idx]
+        return self._view()[idx]
 
     def __setitem__(self, idx, value):
         # callers that write into a state (features.py:98-99) change the host copy; the device copy is dropped so that
         # the next map operation sees the modification
-        host = self._materialise()
-        self._detach()
-        host[idx] = value
+        self._writable()[idx] = value
 
     def __iter__(self):
-        return iter(self._materialise())
+        return iter(self._view())
 
     def copy(self, order="C"):
         return self._materialise().copy(order=order)
@@ -189,7 +212,7 @@ class DeviceCov:
         return self._materialise().flatten(order=order)
 
     def ravel(self, order="C"):
-        return self._materialise().ravel(order=order)
+        return self._view().ravel(order=order)
 
     def __repr__(self):
         return repr(self._materialise())
@@ -218,6 +241,18 @@ class DeviceCov:
         locals()[_n] = _binary(_n)
     del _n, _binary
     __hash__ = None  # like ndarray
+
+    def _inplace(name):  # noqa: N805
+        def op(self, other):
+            getattr(self._writable(), name)(np.asarray(other) if isinstance(other, DeviceCov) else other)
+            return self
+
+        op.__name__ = name
+        return op
+
+    for _n in ("__iadd__", "__isub__", "__imul__", "__itruediv__"):
+        locals()[_n] = _inplace(_n)
+    del _n, _inplace
 
     def __neg__(self):
         return -self._materialise()

@@ -31,7 +31,15 @@ from .engine import EngineConfig, IPPEngine
 
 _ENGINES: Dict[Tuple, IPPEngine] = {}
 _STORES: Dict[int, "SlotStore"] = {}  # id(engine) -> device state slots handed out as DeviceCov objects
-STATE_SLOTS = int(os.environ.get("IPP_COMPAT_SLOTS", "16"))  # dense states kept on the device per compat engine
+STATE_SLOTS = int(os.environ.get("IPP_COMPAT_SLOTS", "16"))  # most dense states kept on the device per compat engine
+STATE_BYTES = int(float(os.environ.get("IPP_COMPAT_STATE_GB", "4")) * (1 << 30))  # ... and the device memory they may take
+
+
+def state_slots_for(n_cells: int) -> int:
+    """Dense state slots of a compat engine: IPP_COMPAT_SLOTS (16) while they fit IPP_COMPAT_STATE_GB (4 GB), at least 2: a
+    slot is N x Npad fp32 -- 25 MB at 50x50, 0.4 GB at 100x100, 6.4 GB at 200x200 (16 of those would be 115 GB)."""
+    per_slot = 4 * n_cells * (n_cells + 1024)
+    return int(max(2, min(STATE_SLOTS, STATE_BYTES // max(1, per_slot))))
 
 
 def config_key(cfg: EngineConfig) -> Tuple:
@@ -48,10 +56,16 @@ def compat_engine(cfg: EngineConfig) -> IPPEngine:
     eng = _ENGINES.get(key)
     if eng is None:
         m_cap = 9 if cfg.resolution >= 2 else 25
-        eng = IPPEngine(cfg, capacity=2 + STATE_SLOTS, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap,
-                        score_scratch=True)
+        slots = state_slots_for(cfg.n_cells)
+        try:
+            eng = IPPEngine(cfg, capacity=2 + slots, state="dense", rank_cap=1, max_batch=2, max_measurements=m_cap,
+                            score_scratch=True)
+        except Exception as exc:  # (the arena is one torch allocation: an out-of-memory error lands here)
+            raise _ffi.IppError(f"compat engine for a {cfg.x_dim}x{cfg.y_dim} map ({2 + slots} dense state slots of "
+                                f"{4 * cfg.n_cells * cfg.n_cells / 1e9:.2f} GB) could not be created: {exc}; lower "
+                                f"IPP_COMPAT_SLOTS (now {STATE_SLOTS}) or IPP_COMPAT_STATE_GB (now {STATE_BYTES / (1 << 30):g})") from exc
         _ENGINES[key] = eng
-        _STORES[id(eng)] = SlotStore(eng, 2, STATE_SLOTS)
+        _STORES[id(eng)] = SlotStore(eng, 2, slots)
     return eng
 
 

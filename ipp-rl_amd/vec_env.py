@@ -169,7 +169,12 @@ class VecIPPEnv:
         """Device [n, 2] prior scales for the next episode of the envs of a scheduled reset group; drawn PRIOR_RING
         episodes at a time so that the host work and the upload are off the per-step path."""
         ids = self._reset_ids_host[phase]
-        epi = int(self.episode[ids[0]]) if len(ids) else 0
+        epis = self.episode[ids] if len(ids) else np.zeros(0, dtype=np.int64)
+        if len(ids) and not np.all(epis == epis[0]):
+            # a hand-made reset(env_ids=subset) moved some counters of this group: every env draws for ITS OWN episode index
+            # (the prior then matches the ground truth's episode and does not depend on which env is first in the shard)
+            return self.torch.as_tensor(self._prior_scale(ids, epis), dtype=self.torch.float64, device=self.device)
+        epi = int(epis[0]) if len(ids) else 0
         hit = self._prior_ring.get(phase)
         if hit is None or not (hit[0] <= epi < hit[0] + self.PRIOR_RING):
             block = np.stack([self._prior_scale(ids, epi + k) for k in range(self.PRIOR_RING)])
@@ -298,12 +303,19 @@ class VecIPPEnv:
             if self._blk_waited != b:
                 main.wait_event(self._blk_ready[set_])
                 self._blk_waited = b
-            if self._blk_tag[1 - set_] != b + 1:  # the next block's fields are generated while this block runs
+            # the next block's fields are generated while this block runs -- only when an env cannot reset twice inside the two
+            # blocks (2 K <= episode_steps): with one-step episodes block b + 1 would be staged before block b's reset has moved
+            # the episode counters and would repeat its ground truths; it is then staged when its first step arrives
+            if self._blk_tag[1 - set_] != b + 1 and 2 * K <= self.episode_steps:
                 self._stage_block(b + 1)
             p = self._phase_ending_at(self.t)
             n = int(self._reset_ids_by_phase[p].numel())
             scheduled = (p, set_ * K + j, n) if n > 0 else None
             blk = (set_, j == K - 1)
+        elif self._reset_ids_by_phase is not None:
+            # a step outside the reset schedule: the `free` event of the running block would never be recorded (it rides on the
+            # block's last scheduled step) and the side stream could refill a buffer set that resets are still reading
+            self._invalidate_staging()
         if meas_noise is None:
             if self._noise_pos == 0:
                 # plane p of the ring = step (fills * NOISE_RING + p); row = global env id

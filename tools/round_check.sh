@@ -26,8 +26,10 @@ PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_w12 --shuffle-prior > $O/pmc_run_w
 python tools/pmc_summary.py $O/pmc_w12 40 > $O/pmc_summary_w12.json 2>>$O/pmc_summary.err
 PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
 python tools/pmc_summary.py $O/pmc_cfg2 16 > $O/pmc_summary_cfg2.json 2>>$O/pmc_summary.err
-# WRITE_SIZE / FETCH_SIZE calibration on known byte counts (tools/probes/write_probe.hip)
+# WRITE_SIZE / FETCH_SIZE calibration on known byte counts (tools/probes/write_probe.hip; the binary is git-ignored: build it here)
+hipcc --offload-arch=gfx950 -O3 tools/probes/write_probe.hip -o tools/probes/write_probe || echo "write_probe build failed"
 for c in WRITE_SIZE FETCH_SIZE; do
+  [ -x tools/probes/write_probe ] || continue
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/wp_$c -o wp -- ./tools/probes/write_probe 1024 > $O/wp_$c.log 2>&1
 done
 python - <<'PY' > $O/write_probe_calibration.txt 2>&1
