@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/ipp_engine.h"
 
@@ -37,7 +38,9 @@ __device__ unsigned long long g_wphase[16];
 #endif
 #if IPP_TIMELINE && IPP_WAVE_CLOCKS
 #define IPP_WT_DECL unsigned long long wt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long wt_last_ = clock64()
-#define IPP_WT(k) do { const unsigned long long n_ = clock64(); wt_[k] += n_ - wt_last_; wt_last_ = n_; } while (0)
+// (IPP_WAVE_CLOCKS is a bit mask of the ticks to keep: interval k = time since the previous KEPT tick; two ticks per unit keep the
+// perturbation small -- e.g. 0x1c6: stream = interval 2)
+#define IPP_WT(k) do { if ((IPP_WAVE_CLOCKS >> (k)) & 1) { const unsigned long long n_ = clock64(); wt_[k] += n_ - wt_last_; wt_last_ = n_; } } while (0)
 #define IPP_WT_COUNT(k, n) do { wt_[k] += (n); } while (0)
 #define IPP_WT_FLUSH(lane) do { if ((lane) == 0) for (int q_ = 0; q_ < 12; ++q_) if (wt_[q_]) atomicAdd(&g_wphase[q_], wt_[q_]); } while (0)
 #else
@@ -297,6 +300,78 @@ __device__ __forceinline__ float wave_max(float x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, kWave));
     return x;
+}
+
+__device__ __forceinline__ double bcast_lane(double x, int src) {  // src: wave-uniform constant
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- DPP row broadcasts: coefficients that are the same for every cell (a row of -HT, a row of L^-1, y) live in the LANES of one
+// register (value j in lane j of every row of 16 lanes) and reach the FMAs through `row_newbcast`, instead of broadcast LDS reads
+// (or scalar loads) in front of every use.
+// acc += q[lane J of this lane's row of 16] * u: the row's -HT values live in the LANES of one register (lane l holds value
+// l & 15, read from the LDS record with one ds_read_b32 per stored row while the row requests are in flight) and reach the FMAs
+// through the DPP row broadcast -- no LDS read and no wait inside the FMA chain (three broadcast ds_read_b128 per row with a
+// wait in front of their first use cost ~4 us per unit: the row loop was a chain of exposed LDS latencies)
+template <int J>
+__device__ __forceinline__ void fmac_bc(float& acc, float q, float u) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q), "v"(u), "n"(J));
+}
+template <int VEC, int MC>
+__device__ __forceinline__ void fmac_row(float (&acc)[VEC][MC], float q, const float (&u)[VEC]) {
+    static_assert(MC == 9, "unrolled for MC = 9");
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        fmac_bc<0>(acc[c][0], q, u[c]); fmac_bc<1>(acc[c][1], q, u[c]); fmac_bc<2>(acc[c][2], q, u[c]);
+        fmac_bc<3>(acc[c][3], q, u[c]); fmac_bc<4>(acc[c][4], q, u[c]); fmac_bc<5>(acc[c][5], q, u[c]);
+        fmac_bc<6>(acc[c][6], q, u[c]); fmac_bc<7>(acc[c][7], q, u[c]); fmac_bc<8>(acc[c][8], q, u[c]);
+    }
+}
+
+// Wc[.][J] = sum_{b <= J} (Wc L)[.][b] * Linv[b][J]: row b of L^-1 sits in the lanes of lrow[b] (value J in lane J of every row of 16)
+template <int J, int VEC, int MC>
+__device__ __forceinline__ void linv_col(float (&acc)[VEC][MC], const float (&lrow)[MC]) {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        float t = 0.f;
+#pragma unroll
+        for (int b = 0; b <= J; ++b) fmac_bc<J>(t, lrow[b], acc[c][b]);
+        acc[c][J] = t;
+    }
+}
+template <int MC>
+__device__ __forceinline__ float dot_lanes(const float (&a)[MC], float yreg) {  // sum_j a[j] * y[j], y[j] in lane j of every row of 16
+    static_assert(MC == 9, "unrolled for MC = 9");
+    float d = 0.f;
+    fmac_bc<0>(d, yreg, a[0]); fmac_bc<1>(d, yreg, a[1]); fmac_bc<2>(d, yreg, a[2]); fmac_bc<3>(d, yreg, a[3]); fmac_bc<4>(d, yreg, a[4]);
+    fmac_bc<5>(d, yreg, a[5]); fmac_bc<6>(d, yreg, a[6]); fmac_bc<7>(d, yreg, a[7]); fmac_bc<8>(d, yreg, a[8]);
+    return d;
+}
+// Sum over the wave without LDS permutes (six dependent ds_bpermute round trips per unit): quads, half rows and rows through
+// DPP, the four row sums through v_readlane.  Every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x += dpp_mov_f64<0xB1>(x);   // quad_perm [1, 0, 3, 2]
+    x += dpp_mov_f64<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+    x += dpp_mov_f64<0x141>(x);  // row_half_mirror
+    x += dpp_mov_f64<0x140>(x);  // row_mirror
+    return (bcast_lane(x, 0) + bcast_lane(x, 16)) + (bcast_lane(x, 32) + bcast_lane(x, 48));
+}
+
+// compile-time loop (template arguments from loop counters)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 // Matern nu=3/2 prior between two cells (mapping/mappings.py:242-258 == analytic kernel).

@@ -263,8 +263,12 @@ int plan(const ipp_config& c, Layout& L) {
         L.off_grfhp = o; o += up(tab);
         L.off_grfamp = o; o += up(tab);
     }
-    L.off_grfraw = o; o += up(mb * np * 4);
-    L.off_grfraw2 = o; o += up(mb * np * 4);
+    {   // un-normalised fields of the convolution path (k_grf_conv + k_grf_norm): even square grids up to 256 run the Hartley /
+        // DFT kernels, which normalise in place (2 x 1.3 GB of the configs[2] arena)
+        const bool conv = !(c.x_dim == c.y_dim && c.x_dim % 2 == 0 && c.x_dim >= 4 && c.x_dim <= 256) || getenv("IPP_GRF_CONV") != nullptr;
+        L.off_grfraw = o; o += conv ? up(mb * np * 4) : 0;
+        L.off_grfraw2 = o; o += conv ? up(mb * np * 4) : 0;
+    }
     L.off_sc_hdr = L.off_sc_ext = L.off_sc_mask = L.off_sc_G = L.off_sc_P = o;
     if (c.score_scratch) {  // ipp_score_actions (k_score.h)
         L.off_sc_hdr = o; o += up(mb * sizeof(ScoreHdr));
@@ -556,8 +560,16 @@ bool grf_hartley_tables_host(int n, int np, double c, std::vector<double>& hp, s
 template <int TT>
 void launch_grf_hartley(const View& v, int n, const float* white, const int32_t* env_ids, float* gt_out, hipStream_t s) {
     constexpr int NW = (TT > 4 && TT < 8) ? 8 : 4;  // (TT = 8 with one tile per wave spills 112 registers at the 168 it may use)
-    hipLaunchKernelGGL((k_grf_hartley<TT, NW>), dim3(n), dim3(64 * NW), grf_hartley_lds_bytes(TT), s, v, env_ids, n, white,
-                       (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
+    // the grid sizes of BASELINE.json contract over ceil(n / 4) steps instead of the padded 4 TT (k_grf_hartley.h, KS)
+    if (TT == 4 && v.W == 50)
+        hipLaunchKernelGGL((k_grf_hartley<4, 4, 13>), dim3(n), dim3(256), grf_hartley_lds_bytes(4), s, v, env_ids, n, white,
+                           (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
+    else if (TT == 7 && v.W == 100)
+        hipLaunchKernelGGL((k_grf_hartley<7, 8, 25>), dim3(n), dim3(512), grf_hartley_lds_bytes(7), s, v, env_ids, n, white,
+                           (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
+    else
+        hipLaunchKernelGGL((k_grf_hartley<TT, NW>), dim3(n), dim3(64 * NW), grf_hartley_lds_bytes(TT), s, v, env_ids, n, white,
+                           (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
 }
 
 int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
@@ -873,6 +885,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                 const void* fn[] = {(const void*)&k_grf_hartley<1, 4>, (const void*)&k_grf_hartley<2, 4>, (const void*)&k_grf_hartley<3, 4>, (const void*)&k_grf_hartley<4, 4>,
                                     (const void*)&k_grf_hartley<5, 8>, (const void*)&k_grf_hartley<6, 8>, (const void*)&k_grf_hartley<7, 8>, (const void*)&k_grf_hartley<8, 4>};
                 (void)hipFuncSetAttribute(fn[tt - 1], hipFuncAttributeMaxDynamicSharedMemorySize, hl);
+                if (n == 50) (void)hipFuncSetAttribute((const void*)&k_grf_hartley<4, 4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
+                if (n == 100) (void)hipFuncSetAttribute((const void*)&k_grf_hartley<7, 8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
             }
         }
         if (e->grf_dft) {

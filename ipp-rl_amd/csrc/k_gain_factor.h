@@ -353,6 +353,14 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         // ---- base term from the analytic prior: Wc0[i,:] = sum_b (sum_{f in block b} w_f P0[i, F_f]) L_inv[b,:]
         unsigned inmask = (1u << VEC) - 1u;  // cells of this lane inside the column range of the step
         float acc[VEC][MC];
+        // MC = 9: rows of L^-1 and y in the lanes of ten registers (value j in lane j of every row of 16 lanes), see fmac_bc
+        constexpr int kLR = (MC == 9) ? MC : 1;
+        float lrow[kLR], yreg = 0.f;
+        if constexpr (MC == 9 && !PRE) {
+#pragma unroll
+            for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
+            yreg = ys[min(lane & 15, MC - 1)];
+        }
 #pragma unroll
         for (int c = 0; c < VEC; ++c)
 #pragma unroll
@@ -420,9 +428,23 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                             for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
                         }
                     }
-                } else {
+                } else if constexpr (MC == 9) {
                     // L^-1 is upper triangular (solve_wave_fast: column j of inv(C^T) has rows i <= j): block b feeds the
-                    // columns j >= b only, 45 instead of 81 FMAs per cell (b unrolled: acc[.][j] needs static indices)
+                    // columns j >= b only, 45 instead of 81 FMAs per cell; row b of L^-1 sits in the lanes of lrow[b] and reaches
+                    // the FMAs through the DPP row broadcast (45 dependent broadcast LDS reads per tile before)
+                    static_for<0, MC>([&](auto bc) {
+                        constexpr int B = decltype(bc)::value;
+                        if (B < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                            float cb[VEC];
+                            block_term(B, cb);
+                            static_for<B, MC>([&](auto jc) {
+                                constexpr int J = decltype(jc)::value;
+#pragma unroll
+                                for (int c = 0; c < VEC; ++c) fmac_bc<J>(acc[c][J], lrow[B], cb[c]);
+                            });
+                        }
+                    });
+                } else {
 #pragma unroll
                     for (int b = 0; b < MC; ++b) {
                         if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
@@ -554,19 +576,27 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 if (lane == 0) atomicAdd(&v.counters[6], wall_clock64() - w0_);
 #endif
             }
+            if constexpr (MC == 9) {
 #pragma unroll
-            for (int j = MC - 1; j >= 0; --j) {
-                float t[VEC];
+                for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
+                yreg = ys[min(lane & 15, MC - 1)];
+                linv_col<8>(acc, lrow); linv_col<7>(acc, lrow); linv_col<6>(acc, lrow); linv_col<5>(acc, lrow); linv_col<4>(acc, lrow);
+                linv_col<3>(acc, lrow); linv_col<2>(acc, lrow); linv_col<1>(acc, lrow); linv_col<0>(acc, lrow);
+            } else {
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) t[c] = 0.f;
+                for (int j = MC - 1; j >= 0; --j) {
+                    float t[VEC];
 #pragma unroll
-                for (int b = 0; b <= j; ++b) {
-                    const float l = Ls[b * MC + j];
+                    for (int c = 0; c < VEC; ++c) t[c] = 0.f;
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) t[c] = fmaf(acc[c][b], l, t[c]);
+                    for (int b = 0; b <= j; ++b) {
+                        const float l = Ls[b * MC + j];
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) t[c] = fmaf(acc[c][b], l, t[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) acc[c][j] = t[c];
                 }
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) acc[c][j] = t[c];
             }
         }
         const bool commit = h.commit && !dead;
@@ -589,8 +619,12 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             float w2 = 0.f, dm = 0.f;
 #pragma unroll
             for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
+            if constexpr (MC == 9) {
+                dm = dot_lanes<MC>(acc[c], yreg);
+            } else {
 #pragma unroll
-            for (int j = 0; j < MC; ++j) dm = fmaf(acc[c][j], ys[j], dm);
+                for (int j = 0; j < MC; ++j) dm = fmaf(acc[c][j], ys[j], dm);
+            }
             if (!valid) {
                 w2 = 0.f; dm = 0.f;
 #pragma unroll
@@ -603,7 +637,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                                        : (!adaptive || ((double)mean_in[c] + v.kf * (double)diag_in[c] >= v.thr));
             if (valid && in_mask) part += (double)w2;
         }
-        part = wave_sum(part);
+        part = wave_sum_dpp(part);
         if (lane == 0) lds.tile_red[tidx] = part;
         const int valid_cells = rect ? __popcll(__ballot(lane_valid)) * VEC : max(0, min(kWaveTile, v.N - tile * kWaveTile));
         // 4 N (r + m) + 16 N per committed step = (stored rows + m new rows + mean and diag read and

@@ -36,8 +36,11 @@ __host__ __device__ inline size_t grf_hartley_lds_bytes(int tt) {
 // Y = H X for the row tiles {wave, wave + NW} of Y (NW waves per workgroup, OW = ceil(TT / NW) <= 2 owned tiles):
 // hreg[o][ks] = H[16 (wave + NW o) + (lane & 15)][4 ks + (lane >> 4)]
 // (A fragments; H symmetric, so loaded as row k of H at 16 consecutive columns), X in LDS with leading dimension ld.
-template <int TT, int NW, int OW>
-__device__ __forceinline__ void grf_gemm(const double (&hreg)[OW][4 * TT], const double* X, int ld, int wave, int lane,
+// KS: steps of 4 along the contraction index, ceil(n / 4) <= 4 TT: the rows / columns n .. NP-1 of H and X are zero padding, and
+// the bound is a template parameter (a run-time bound -- a uniform branch per step -- broke the schedule: 64x64 0.10 -> 0.13 ms):
+// n = 100 contracts over 100 instead of 112 (-11 % of the MFMAs), n = 50 over 52 instead of 64 (-19 %)
+template <int TT, int NW, int OW, int KS>
+__device__ __forceinline__ void grf_gemm(const double (&hreg)[OW][KS], const double* X, int ld, int wave, int lane,
                                          v4f64 (&acc)[OW][TT]) {
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -46,8 +49,7 @@ __device__ __forceinline__ void grf_gemm(const double (&hreg)[OW][4 * TT], const
         for (int t = 0; t < TT; ++t) acc[o][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const bool two = OW > 1 && wave + NW < TT;  // second owned tile (wave-uniform)
 #pragma unroll
-    for (int ks = 0; ks < 4 * TT; ++ks) {  // (fully unrolled: hreg needs static indices; stopping at ceil(n / 4) steps
-                                           // with a uniform branch per step broke the schedule: 64x64 0.10 -> 0.13 ms)
+    for (int ks = 0; ks < KS; ++ks) {  // (fully unrolled: hreg needs static indices)
         const double* xr = X + (4 * ks + l4) * ld + l15;  // B[k][col]: 4 rows x 16 consecutive columns
         double xf[TT];
 #pragma unroll
@@ -79,7 +81,7 @@ __device__ __forceinline__ void grf_store_t(double* X, int ld, int wave, int lan
     }
 }
 
-template <int TT, int NW>
+template <int TT, int NW, int KS = 4 * TT>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 3 : 1))) void k_grf_hartley(View v, const int* __restrict__ env_ids, int n_items,
                                                      const float* __restrict__ white, const double* __restrict__ Hp,
                                                      const double* __restrict__ ampp, float* __restrict__ gt_out) {
@@ -111,31 +113,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
         for (int i = tid; i < padc * NP; i += NT) X[(n + i / NP) * LD + i % NP] = 0.0;
     }
     // this wave's fragments of H, once for the four GEMMs
-    double hreg[OW][4 * TT];
+    double hreg[OW][KS];
     {
         const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
         for (int o = 0; o < OW; ++o) {
             const int c = 16 * min(wave + NW * o, TT - 1) + l15;  // (waves beyond TT own nothing: their results are dropped)
 #pragma unroll
-            for (int ks = 0; ks < 4 * TT; ++ks) hreg[o][ks] = Hp[(size_t)(4 * ks + l4) * NP + c];
+            for (int ks = 0; ks < KS; ++ks) hreg[o][ks] = Hp[(size_t)(4 * ks + l4) * NP + c];
         }
     }
     __syncthreads();
     v4f64 acc[OW][TT];
-    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y1 = H w
+    grf_gemm<TT, NW, OW, KS>(hreg, X, LD, wave, lane, acc);        // Y1 = H w
     __syncthreads();
     grf_store_t<TT, NW, OW>(X, LD, wave, lane, acc, nullptr);  // X = Y1^T
     __syncthreads();
-    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y2 = H Y1^T = (H w H)^T
+    grf_gemm<TT, NW, OW, KS>(hreg, X, LD, wave, lane, acc);        // Y2 = H Y1^T = (H w H)^T
     __syncthreads();
     grf_store_t<TT, NW, OW>(X, LD, wave, lane, acc, ampp);     // X = amp .* (H w H)
     __syncthreads();
-    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y3
+    grf_gemm<TT, NW, OW, KS>(hreg, X, LD, wave, lane, acc);        // Y3
     __syncthreads();
     grf_store_t<TT, NW, OW>(X, LD, wave, lane, acc, nullptr);
     __syncthreads();
-    grf_gemm<TT, NW, OW>(hreg, X, LD, wave, lane, acc);        // Y4 = field^T, in registers
+    grf_gemm<TT, NW, OW, KS>(hreg, X, LD, wave, lane, acc);        // Y4 = field^T, in registers
 
     // ---- min-max normalisation to [0, 1] (ground_truths.py:31), fp64 like the reference
     double lo = INFINITY, hi = -INFINITY;

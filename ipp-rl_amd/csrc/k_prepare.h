@@ -901,11 +901,6 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
     wave_lds_sync();
 }
 
-__device__ __forceinline__ double bcast_lane(double x, int src) {  // src: wave-uniform constant
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-    return __hiloint2double(hi, lo);
-}
 
 template <int MC>
 __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, const int item, unsigned flags,

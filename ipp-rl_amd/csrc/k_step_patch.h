@@ -41,6 +41,9 @@ constexpr int kPatchRec = 16;  // floats per column record
 #ifndef IPP_PATCH_ABLATE
 #define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads
 #endif
+#ifndef IPP_PATCH_AUX
+#define IPP_PATCH_AUX 2  // cache policy bits of the row requests (2: nt)
+#endif
 #ifndef IPP_PATCH_MINW
 #define IPP_PATCH_MINW 4
 #endif
@@ -98,60 +101,6 @@ struct PatchLds {
         unit_red = reinterpret_cast<double*>(ridx + ((((size_t)waves * (rank_cap + kPatchKP)) + 7) & ~(size_t)7));
     }
 };
-
-// acc += q[lane J of this lane's row of 16] * u: the row's -HT values live in the LANES of one register (lane l holds value
-// l & 15, read from the LDS record with one ds_read_b32 per stored row while the row requests are in flight) and reach the FMAs
-// through the DPP row broadcast -- no LDS read and no wait inside the FMA chain (three broadcast ds_read_b128 per row with a
-// wait in front of their first use cost ~4 us per unit: the row loop was a chain of exposed LDS latencies)
-template <int J>
-__device__ __forceinline__ void fmac_bc(float& acc, float q, float u) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(q), "v"(u), "n"(J));
-}
-template <int VEC, int MC>
-__device__ __forceinline__ void fmac_row(float (&acc)[VEC][MC], float q, const float (&u)[VEC]) {
-    static_assert(MC == 9, "unrolled for MC = 9");
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        fmac_bc<0>(acc[c][0], q, u[c]); fmac_bc<1>(acc[c][1], q, u[c]); fmac_bc<2>(acc[c][2], q, u[c]);
-        fmac_bc<3>(acc[c][3], q, u[c]); fmac_bc<4>(acc[c][4], q, u[c]); fmac_bc<5>(acc[c][5], q, u[c]);
-        fmac_bc<6>(acc[c][6], q, u[c]); fmac_bc<7>(acc[c][7], q, u[c]); fmac_bc<8>(acc[c][8], q, u[c]);
-    }
-}
-
-// Wc[.][J] = sum_{b <= J} (Wc L)[.][b] * Linv[b][J]: row b of L^-1 sits in the lanes of lrow[b] (value J in lane J of every row of 16)
-template <int J, int VEC, int MC>
-__device__ __forceinline__ void linv_col(float (&acc)[VEC][MC], const float (&lrow)[MC]) {
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        float t = 0.f;
-#pragma unroll
-        for (int b = 0; b <= J; ++b) fmac_bc<J>(t, lrow[b], acc[c][b]);
-        acc[c][J] = t;
-    }
-}
-template <int MC>
-__device__ __forceinline__ float dot_lanes(const float (&a)[MC], float yreg) {  // sum_j a[j] * y[j], y[j] in lane j of every row of 16
-    static_assert(MC == 9, "unrolled for MC = 9");
-    float d = 0.f;
-    fmac_bc<0>(d, yreg, a[0]); fmac_bc<1>(d, yreg, a[1]); fmac_bc<2>(d, yreg, a[2]); fmac_bc<3>(d, yreg, a[3]); fmac_bc<4>(d, yreg, a[4]);
-    fmac_bc<5>(d, yreg, a[5]); fmac_bc<6>(d, yreg, a[6]); fmac_bc<7>(d, yreg, a[7]); fmac_bc<8>(d, yreg, a[8]);
-    return d;
-}
-// Sum over the wave without LDS permutes (six dependent ds_bpermute round trips per unit): quads, half rows and rows through
-// DPP, the four row sums through v_readlane.  Every lane returns the total.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum_dpp(double x) {
-    x += dpp_mov_f64<0xB1>(x);   // quad_perm [1, 0, 3, 2]
-    x += dpp_mov_f64<0x4E>(x);   // quad_perm [2, 3, 0, 1]
-    x += dpp_mov_f64<0x141>(x);  // row_half_mirror
-    x += dpp_mov_f64<0x140>(x);  // row_mirror
-    return (bcast_lane(x, 0) + bcast_lane(x, 16)) + (bcast_lane(x, 32) + bcast_lane(x, 48));
-}
 
 template <bool ONE>
 __device__ __forceinline__ void patch_sync() {
@@ -569,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                                 (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
                 const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slot) + cofs, 0, 0x7ffffff0, 0x00020000);
                 if (IPP_PATCH_ABLATE & 1) uu[i] = (rowv)(__int_as_float(cofs) * 1e-30f + (ok ? 1.f : 0.f));
-                else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, 2));  // (aux 2: nt)
+                else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, IPP_PATCH_AUX));  // (aux 2: nt)
             }
             // -HT of the group's rows, value l & 15 in lane l (read while the requests are in flight)
             float qr[KP];

@@ -313,9 +313,11 @@ class VecIPPEnv:
             scheduled = (p, set_ * K + j, n) if n > 0 else None
             blk = (set_, j == K - 1)
         elif self._reset_ids_by_phase is not None:
-            # a step outside the reset schedule: the `free` event of the running block would never be recorded (it rides on the
-            # block's last scheduled step) and the side stream could refill a buffer set that resets are still reading
-            self._invalidate_staging()
+            # a step outside the reset schedule (auto_reset=False): its staged fields stay unused, but when it is the LAST step of
+            # its block the block's `free` event is still recorded below -- else the side stream would refill this buffer set
+            # behind an older event while resets of the main stream may still be reading it
+            b_, j_ = divmod(self.t, self._blk_K)
+            blk = (b_ % 2, j_ == self._blk_K - 1) if self._blk_tag[b_ % 2] == b_ else None
         if meas_noise is None:
             if self._noise_pos == 0:
                 # plane p of the ring = step (fills * NOISE_RING + p); row = global env id

@@ -1,0 +1,61 @@
+"""
+GPU test of the factor state's refusal of a non-positive-definite S (IPP_STATUS_NOT_PD = 2; mapping/mappings.py:200-215 is
+the reference's inverse fallback, which the factor form cannot represent -- DESIGN.md section 4, INTEGRATION.md divergences):
+the status and a NaN reward come back for THAT env only, its state is left as it was (no columns appended), and the other envs
+of the same launch are bit-identical to a launch without it -- on the patch kernel (the batched driver's path) and on the
+band-tile kernels.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ALTS = [float(a) for a in range(5, 15)]
+
+
+@pytest.mark.parametrize("patch", [1, 0])
+def test_not_pd_env_is_reported_and_isolated(patch):
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from ipp_rl_amd.vec_env import cell_centre_actions
+
+    old = os.environ.get("IPP_PATCH")
+    os.environ["IPP_PATCH"] = str(patch)
+    try:
+        cfg = EngineConfig(x_dim=50, y_dim=50)
+        B, bad = 12, 5
+        engines = [IPPEngine(cfg, capacity=B, state="factor", rank_cap=90, window_rows=-1, fixed_prior=True) for _ in range(2)]
+    finally:
+        if old is None:
+            os.environ.pop("IPP_PATCH", None)
+        else:
+            os.environ["IPP_PATCH"] = old
+    assert engines[0].info.patch_layout == patch
+    rs = np.random.RandomState(3)
+    gt = torch.as_tensor(rs.uniform(size=(B, 2500)), dtype=torch.float32, device="cuda")
+    for e in engines:
+        e.reset(gt=gt)
+    # engine 1: env `bad` gets a prior the column window was not sized for -> its planes are NaN -> S is not positive definite
+    too_long = np.array([[cfg.signal_variance, cfg.length_scale * 1.1]])
+    engines[1].reset(env_ids=[bad], prior_scale=too_long, gt=gt[bad:bad + 1])
+    prev = [torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1) for _ in range(2)]
+    for t in range(6):
+        a = torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, ALTS), dtype=torch.float64, device="cuda")
+        noise = torch.as_tensor(rs.normal(size=(B, 9)), dtype=torch.float32, device="cuda")
+        out = []
+        for e, p in zip(engines, prev):
+            r, s = e.step(a, p, meas_noise=noise)
+            out.append((r.clone(), s.clone()))
+        (r0, s0), (r1, s1) = out
+        assert int(s0.abs().sum()) == 0
+        assert int(s1[bad]) == 2 and bool(torch.isnan(r1[bad]))           # IPP_STATUS_NOT_PD, reward NaN
+        others = [i for i in range(B) if i != bad]
+        assert int(s1[others].abs().sum()) == 0
+        assert torch.equal(r0[others], r1[others])                          # neighbours of the launch: bit-identical
+        prev = [a, a.clone()]
+    assert int(engines[1].rank(bad)) == 0                                   # the refused steps appended nothing
+    for i in (0, bad - 1, bad + 1, B - 1):
+        assert torch.equal(engines[0].read_mean(i), engines[1].read_mean(i))
+        assert torch.equal(engines[0].read_diag(i), engines[1].read_diag(i))
+        assert int(engines[0].rank(i)) == int(engines[1].rank(i))
