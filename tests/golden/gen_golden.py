@@ -586,6 +586,73 @@ def gen_mcts():
     save("mcts", **out)
 
 
+def gen_mcts_mission():
+    """Recorded searches of the reference's classic MCTS planner (planning/mcts_mission.py: run_simulations_proxy on a root
+    with a generic state): eps-greedy rollouts on an adaptive mission and generalised cost-benefit rollouts on a
+    non-adaptive one.  The build's ClassicMCTS (ipp-rl_amd/planning/mcts_mission.py) must rebuild the same trees from the
+    same seeds (np.random.seed(worker_id * 42 + 1) inside the proxy, random.seed(py_seed) for the UCT ties)."""
+    import random
+
+    from planning import mcts_mission as ref_mm
+
+    out = {}
+    cases = [
+        # name, grid, adaptive, gcb, root steps, sims, (min, max, spacing), budget, horizon, greedy radius [m], seed
+        ("eps10", 10, True, False, 3, 40, (8, 14, 6), 60.0, 3, 9.0, 3),
+        ("gcb10", 10, False, True, 2, 24, (8, 14, 6), 50.0, 3, 9.0, 5),
+    ]
+    for name, dim, adaptive, gcb, root_steps, sims, (amin, amax, aspc), budget, horizon, radius, seed in cases:
+        params = load_params(dim, dim)
+        gm, sensor, sim, mapping = build(params, seed=seed)
+        uav = {"max_v": 2, "max_a": 2}
+        rs = np.random.RandomState(200 + seed)
+        prev = np.array([2.0, 2.0, 14.0])
+        root_actions, root_eps = [], []
+        for _ in range(root_steps):  # the root: a few executed rf = 1 measurements, so that mean and covariance are generic
+            a = np.array([4.0 * rs.randint(0, dim) + 2.0, 4.0 * rs.randint(0, dim) + 2.0, 8.0])
+            st = np.random.get_state()
+            z = sensor.take_measurement(a, verbose=False)
+            np.random.set_state(st)
+            eps = np.random.normal(0, 1, z.shape)
+            mapping.update_grid_map(a, z)
+            root_actions.append(a)
+            ep = np.zeros(9)
+            ep[: eps.size] = eps.ravel()
+            root_eps.append(ep)
+            prev = a
+        hp = dict(k=4.0, alpha=0.75, epsilon_expand=0.2, epsilon_rollout=0.5, gamma=0.95, c=2.0)
+        mis = ref_mm.MCTSMission(mapping, uav, dist_to_boundaries=10, min_altitude=amin, max_altitude=amax, budget=budget,
+                                 altitude_spacing=aspc, num_simulations=sims, gamma=hp["gamma"], c=hp["c"], episode_horizon=horizon,
+                                 k=hp["k"], alpha=hp["alpha"], epsilon_expand=hp["epsilon_expand"], epsilon_rollout=hp["epsilon_rollout"],
+                                 max_greedy_radius=radius, use_gcb_rollout=gcb, adaptive=adaptive, value_threshold=0.4, interval_factor=0)
+        root = ref_mm.Node(state=gm.cov_matrix.copy(), parent=None, action=prev.copy())
+        py_seed = 50 + seed
+        random.seed(py_seed)
+        mis.run_simulations_proxy(root, budget, horizon, sims, 0)
+
+        def count(n):
+            return 1 + sum(count(c) for c in n.children)
+
+        best = ref_mm.MCTSMission.select_best_child(root)
+        out.update({
+            f"{name}_dim": dim, f"{name}_adaptive": adaptive, f"{name}_gcb": gcb, f"{name}_sims": sims, f"{name}_budget": budget,
+            f"{name}_horizon": horizon, f"{name}_alts": np.array([amin, amax, aspc], dtype=np.float64), f"{name}_radius": radius,
+            f"{name}_py_seed": py_seed, f"{name}_gt": sim.ground_truth_map, f"{name}_root_actions": np.array(root_actions),
+            f"{name}_root_eps": np.array(root_eps), f"{name}_root_mean": gm.mean, f"{name}_root_diag": np.diag(gm.cov_matrix),
+            f"{name}_prev": prev, f"{name}_root_visits": root.visits, f"{name}_root_value_sum": root.value_sum,
+            f"{name}_child_actions": np.array([c.action for c in root.children]),
+            f"{name}_child_visits": np.array([c.visits for c in root.children]),
+            f"{name}_child_value_sums": np.array([c.value_sum for c in root.children], dtype=np.float64),
+            f"{name}_child_children": np.array([len(c.children) for c in root.children]),
+            f"{name}_tree_nodes": count(root), f"{name}_tree_depth": mis.get_depth(root), f"{name}_best_action": best.action,
+        })
+        print(f"  mcts_mission {name}: {count(root)} tree nodes, depth {mis.get_depth(root)}, {len(root.children)} root children, "
+              f"root value sum {root.value_sum:.4f}, best {best.action}")
+    for k2, v2 in dict(k=4.0, alpha=0.75, epsilon_expand=0.2, epsilon_rollout=0.5, gamma=0.95, c=2.0).items():
+        out[f"hyper_{k2}"] = v2
+    save("mcts_mission", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("writing golden vectors to", OUT)
@@ -605,6 +672,7 @@ def main():
     gen_costs()
     gen_features()
     gen_mcts()
+    gen_mcts_mission()
     shapes = sorted(set(RESIZE_CALLS))
     print("cv2.resize stub was called with (src shape, dsize):", shapes)
 
