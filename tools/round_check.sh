@@ -26,6 +26,11 @@ PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_w12 --shuffle-prior > $O/pmc_run_w
 python tools/pmc_summary.py $O/pmc_w12 40 > $O/pmc_summary_w12.json 2>>$O/pmc_summary.err
 PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
 python tools/pmc_summary.py $O/pmc_cfg2 16 > $O/pmc_summary_cfg2.json 2>>$O/pmc_summary.err
+# address-pattern probe of the column layouts (GB/s + FETCH_SIZE per pattern: the FETCH_SIZE calibration on the step kernel's own
+# request shapes) and the occupancy timeline of one k_step_patch launch (needs `make -C ipp-rl_amd/csrc timeline` before gpurun)
+hipcc --offload-arch=gfx950 -O3 tools/probes/patch_probe.hip -o tools/probes/patch_probe || echo "patch_probe build failed"
+[ -x tools/probes/patch_probe ] && bash tools/probe_run.sh > $O/probe_run.log 2>&1 && cp gpurun_out/probe/patch_probe.txt $O/patch_probe.txt
+[ -f tools/probes/libipp_timing.so ] && TL_WAVES=2 bash tools/tl_patch.sh > $O/tl_patch.log 2>&1 && cp gpurun_out/ab/timeline.txt $O/timeline.txt
 # WRITE_SIZE / FETCH_SIZE calibration on known byte counts (tools/probes/write_probe.hip; the binary is git-ignored: build it here)
 hipcc --offload-arch=gfx950 -O3 tools/probes/write_probe.hip -o tools/probes/write_probe || echo "write_probe build failed"
 for c in WRITE_SIZE FETCH_SIZE; do
