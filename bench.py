@@ -431,6 +431,7 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
     p_ms, p_n = eng.profile_read(2)  # launches >= 2048 items run as k_tree_prepare + k_tree_gain (else the fused k_tree_step)
     eng.profile(False)
     split = p_n > 0
+    patch_tree = bool(int(eng.info.patch_layout))
     gbs = (counted / max(k_n, 1)) / ((k_ms + (p_ms if split else 0.0)) * 1e-3) / 1e9 if k_ms > 0 else 0.0
     eng.close()
     del eng
@@ -438,7 +439,8 @@ def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, roo
     return {"name": f"BASELINE configs[4]: {roots} roots x {sims} sims, {grid}x{grid} grid, depth {depth}, GRF ground truth "
                     f"(predict steps at tree nodes, ipp_tree_step; {wave} simulations per root per launch)",
             "value": n_steps / dt, "unit": "tree-steps/s", "ms_per_search": dt * 1e3, "root_rank": root_rank,
-            "launch_items": n_items, "all_status_ok": ok, "kernel": "k_tree_prepare + k_tree_gain" if split else "k_tree_step",
+            "launch_items": n_items, "all_status_ok": ok,
+            "kernel": "k_tree_patch" if patch_tree else ("k_tree_prepare + k_tree_gain" if split else "k_tree_step"),
             "kernel_ms_avg": k_ms + (p_ms if split else 0.0), "prepare_ms_avg": p_ms if split else None, "achieved_gbs": gbs,
             "frac": gbs / HBM_PEAK_GBS}
 

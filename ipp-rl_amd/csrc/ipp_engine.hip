@@ -26,6 +26,7 @@
 #include "k_score.h"
 #include "k_plane.h"
 #include "k_tree.h"
+#include "k_tree_patch.h"
 #include "k_mcts.h"
 #include "k_prepare.h"
 
@@ -124,7 +125,15 @@ uint64_t q_item_floats(const Layout& L) {
 // switches of the band-tile kernels selects those kernels instead; IPP_PATCH=0 does so explicitly.
 bool patch_layout(const ipp_config& c, int MC) {
     if (c.state_repr != IPP_FACTOR || c.window_rows <= 0 || MC != 9) return false;
-    if (c.tile_threads != 0 || c.node_capacity > 0 || c.score_scratch) return false;
+    if (c.tile_threads != 0 || c.score_scratch) return false;
+    if (c.node_capacity > 0) {
+        // tree nodes on patches (k_tree_patch.h): the records address column patches by 32-bit offsets in 8-byte units from
+        // View::cov: root slots + node blocks must lie within 32 GB of it
+        const PatchGeo g = patch_geometry(c.x_dim, c.y_dim, c.window_rows);
+        const double reach = 4.0 * g.pstride * ((double)c.capacity * c.rank_cap + (double)c.node_capacity * 10.0) + 4.0 * c.max_batch * (c.rank_cap * 16.0 + 4096.0) * 4;
+        if (reach > 30e9) return false;
+        if (const char* tp = getenv("IPP_TREE_PATCH")) { if (atoi(tp) == 0) return false; }  // A/B: band-tile tree kernels
+    }
     if (c.x_dim % 2 != 0 || c.x_dim > 256 || c.y_dim > 256) return false;
     if (!(c.x_dim > 2 * c.window_rows + 13)) return false;
     if (c.rank_cap > kPatchMaxRank) return false;
@@ -280,7 +289,7 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_tr_cov = L.off_tr_diag = L.off_tr_meta = L.off_sc_ndiag = o;
     if (c.node_capacity > 0) {  // ipp_tree_step (k_tree.h)
         if (c.state_repr != IPP_FACTOR) return fail(-1, "node_capacity needs IPP_FACTOR");
-        const uint64_t nc = c.node_capacity, wc = (uint64_t)L.win_tiles * 64 * L.VEC;  // a node lives on its step's tile span
+        const uint64_t nc = c.node_capacity, wc = L.patch ? (uint64_t)L.pg.pstride : (uint64_t)L.win_tiles * 64 * L.VEC;  // a node lives on its step's tile span / patch
         L.off_tr_cov = o; o += up(nc * L.MC * wc * 4 + 4096);
         L.off_tr_diag = o; o += up(nc * wc * 4 + 4096);
         L.off_tr_meta = o; o += up(nc * kNodeMeta * 4);
@@ -748,7 +757,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         e->tv.node_cov = reinterpret_cast<float*>(base + L.off_tr_cov);
         e->tv.node_diag = reinterpret_cast<float*>(base + L.off_tr_diag);
         e->tv.node_meta = reinterpret_cast<int*>(base + L.off_tr_meta);
-        e->tv.win_cells = L.win_tiles * 64 * L.VEC;
+        e->tv.win_cells = L.patch ? L.pg.pstride : L.win_tiles * 64 * L.VEC;
         e->node_diag_scratch = cfg->score_scratch ? reinterpret_cast<float*>(base + L.off_sc_ndiag) : nullptr;
     }
     e->scoring = cfg->score_scratch != 0;
@@ -1150,6 +1159,14 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     HIP_TRY(hipSetDevice(e->device));
     e->last_n = n;
     const View& v = e->v;
+    if (e->patch) {  // tree nodes as patches: one fused kernel for every launch size (k_tree_patch.h)
+        if (e->patch_waves == 4)
+            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward);
+        else
+            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (v.meas_cap == 9 && e->tree_split_min > 0 && n >= e->tree_split_min) {
         timed_launch(e, 2, k_tree_prepare<9>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action,
                      prev_action, flags, status);
@@ -1257,8 +1274,11 @@ int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream) 
     if (!e || !out) return fail(-1, "null argument");
     if (node_id < 0 || node_id >= e->tv.node_cap) return fail(-1, "node_id %d outside [0, %d)", node_id, e->tv.node_cap);
     HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_tree_read_diag, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
-                       node_id, out);
+    if (e->patch)
+        hipLaunchKernelGGL(k_tree_read_diag_patch, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv, node_id, out);
+    else
+        hipLaunchKernelGGL(k_tree_read_diag, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
+                           node_id, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

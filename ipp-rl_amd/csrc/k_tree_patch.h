@@ -1,0 +1,526 @@
+// Tree-search predict step on COMPACT COLUMN PATCHES (the patch counterpart of k_tree.h; SURVEY 8(f) rank 1;
+// planning/mcts_zero/mcts.py:166-265, planning/mcts_mission.py:228-230: every tree level is one covariance-only predict step
+// from the parent node's state, whose result becomes the child's state).
+//
+// State of a node = the root env's columns + the <= MC columns of every node on the path (TreeView, k_tree.h); with
+// View::patch every one of them is a patch of its rectangle: the root's in its env slot, a node's in
+// node_cov[id][j][pstride], and the node's diagonal on its rectangle in node_diag[id][pstride] (elsewhere the diagonal is
+// the deepest covering ancestor's, else the root env's).  The kernel is k_step_patch (k_step_patch.h) on that chain:
+// one 2-wave workgroup per item, contributing columns compacted into LDS records, the row stream with DPP-broadcast
+// coefficients -- with three differences: a column's patch address is a 64-bit offset from View::cov in units of 8 bytes
+// (root slots and node storage are different regions of the arena), there is no observation / mean update (covariance
+// only: the second wave starts streaming at once), and the results go to the NEW node's block; the root slot is never
+// written.  Band-tile engines (scoring scratch, wide windows, odd grids) keep k_tree_step / k_tree_prepare + k_tree_gain.
+#pragma once
+#include "k_step_patch.h"
+#include "k_tree.h"
+
+namespace ipp {
+
+constexpr long long kTreePatchGuard = 65536;  // bytes in front of View::cov that the shifted patch offsets may reach into (address math only)
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
+    View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
+    int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
+    int* __restrict__ status_out, float* __restrict__ reward_out) {
+    constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
+    constexpr int RJ = kPatchMaxRank / NT;
+    static_assert(NW == 2 || NW == 4, "two or four waves per item");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tp2[];
+    const PatchLds lds(smem_tp2, v.pcap, v.plw * v.plw, NW, v.punits, v.rank_cap);
+    if ((int)blockIdx.x >= n_items) return;
+    const int item = xcd_item(blockIdx.x, n_items);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (tid == 0) IPP_MARK(item, 0);
+    int* next_unit = lds.ctl; int* done_waves = lds.ctl + 1; int* solve_flag = lds.ctl + 2;
+    int* wcnt = lds.ctl + 8;  // [RJ][NW]
+
+    // ------------------------------------------------------------------ batch 1: root, path, inputs, the root's rectangles
+    const int root0 = root_ids[item];
+    const bool slots_ok = root0 >= 0 && root0 < v.cap;
+    const int root = slots_ok ? root0 : 0;
+    const double ax = action[3 * item + 0], ay = action[3 * item + 1], az = action[3 * item + 2];
+    const double px = prev_action[3 * item + 0], py = prev_action[3 * item + 1], pz = prev_action[3 * item + 2];
+    const int r_root = uni(v.rank[root]);
+    const double sv_d = v.prior[2 * root + 0], ls_d = v.prior[2 * root + 1];
+    int pid[kTreeDepth];
+#pragma unroll
+    for (int d = 0; d < kTreeDepth; ++d) pid[d] = uni(path_ids[(size_t)item * kTreeDepth + d]);
+    const int new_id = new_ids ? uni(new_ids[item]) : -1;
+    const int* __restrict__ rects = v.colrect + (size_t)root * v.rank_cap;
+    unsigned rc_pre[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int k = tid + j * NT;
+        rc_pre[j] = (k < v.rank_cap) ? (unsigned)rects[k] : 0u;
+    }
+    // ------------------------------------------------------------------ round 2: the path nodes' records (m, rectangle)
+    int pm[kTreeDepth], poff[kTreeDepth];
+    unsigned prc[kTreeDepth];
+    int n_cols = r_root, depth = 0, parent_id = -1;
+#pragma unroll
+    for (int d = 0; d < kTreeDepth; ++d) {
+        const int idc = min(max(pid[d], 0), tv.node_cap - 1);
+        pm[d] = uni(tv.node_meta[kNodeMeta * idc]);
+        prc[d] = (unsigned)uni(tv.node_meta[kNodeMeta * idc + 4]);
+    }
+#pragma unroll
+    for (int d = 0; d < kTreeDepth; ++d) {
+        const bool valid = pid[d] >= 0 && pid[d] < tv.node_cap;  // (valid ids first, -1 padded: TreeNodePool.path)
+        poff[d] = valid ? n_cols : 0x7fffffff;
+        if (!valid) { pm[d] = 0; prc[d] = 0x000000ffu; }  // (empty rectangle: r0 = 255 > r1 = 0)
+        n_cols += pm[d];
+        depth += valid ? 1 : 0;
+        parent_id = valid ? pid[d] : parent_id;
+    }
+
+    // ------------------------------------------------------------------ header
+    const bool expand = new_id >= 0 && new_id < tv.node_cap && !(flags & IPP_PREDICT_ONLY);
+    const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
+    ItemHdr h = make_item_header<MC, IPP_FACTOR>(v, root0, root0, slots_ok, ax, ay, az, px, py, pz, n_cols, sv_d, ls_d, flags_eff);
+    const int R = v.window_rows;
+    int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
+    int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
+    if (h.m > 0 && (r1n - r0n + 1 > v.ph || c1n - c0n + 1 > v.pw || n_cols > min(kPatchMaxRank, v.rank_cap))) {  // (the chain must fit the record lists)
+        h.status = IPP_STATUS_BAD_FOOTPRINT; h.m = 0; h.f = 0; h.rows = 0; h.commit = 0;
+    }
+    h = uniform_hdr(h);
+    r0n = uni(r0n); r1n = uni(r1n); c0n = uni(c0n); c1n = uni(c1n);
+    const int hn = r1n - r0n + 1, wn = c1n - c0n + 1;
+    const PrepLds<MC> pl(lds.small);
+    if (tid == 0) {
+        *pl.hs = h;
+        *next_unit = 0; *done_waves = 0; *solve_flag = 0;
+        lds.red[0] = 0.0; lds.red[1] = 0.0;
+    }
+    if (tid < MC) { pl.zz[tid] = 0.0; pl.vv[tid] = 0.0; }  // (covariance only: no observation)
+    const int m = h.m, f = h.f, r = h.rank;
+    if (m == 0) {
+        if (tid == 0) {
+            v.hdr[item] = h;
+            if (status_out) status_out[item] = h.status;
+            reward_out[item] = 0.f;
+        }
+        return;
+    }
+    if (tid == 0) IPP_MARK(item, 3);
+    const char* base0 = reinterpret_cast<const char*>(v.cov) - kTreePatchGuard;  // offsets of the records are relative to this
+    const long long root_off = (long long)root * (long long)v.cov_slot * 4 + kTreePatchGuard;
+    const long long node_off = (reinterpret_cast<const char*>(tv.node_cov) - reinterpret_cast<const char*>(v.cov)) + kTreePatchGuard;
+    float* ovf = v.q + (size_t)item * v.q_item;
+    const int cap = v.pcap, pw = v.pw;
+
+    // ------------------------------------------------------------------ the chain's columns of this thread: rectangle + byte offset
+    // column k < r_root: root column k; else column k - poff[d] of path node d
+    unsigned rcs[RJ];
+    long long offs[RJ];
+    bool con[RJ];
+    unsigned long long bal[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int k = tid + j * NT;
+        unsigned rc = rc_pre[j];
+        long long off = root_off + (long long)k * v.pstride * 4;
+#pragma unroll
+        for (int d = 0; d < kTreeDepth; ++d)
+            if (k >= poff[d]) {  // (poff increases along the path; invalid entries are INT_MAX)
+                rc = prc[d];
+                off = node_off + ((long long)pid[d] * MC + (k - poff[d])) * (long long)v.pstride * 4;
+            }
+        rcs[j] = rc;
+        offs[j] = off;
+        const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
+        con[j] = k < r && r0k <= h.yd && r1k >= h.yu && c0k <= h.xr && c1k >= h.xl;
+        bal[j] = __ballot(con[j]);
+        if (lane == 0) wcnt[j * NW + wave] = __popcll(bal[j]);
+    }
+    if (tid < MC) {  // measurement blocks of the footprint as flat (cell, weight) tables
+        const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+        for (int a = 0; a < 4; ++a) {
+            const int aa = min(a, bb.count() - 1);
+            const int ly = bb.y0 + aa / bb.bw, lx = bb.x0 + aa % bb.bw;
+            lds.fb_yx[4 * tid + a] = ((h.yu + ly) << 16) | (h.xl + lx);
+            lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
+            if (tid < m) pl.bfi[4 * tid + a] = ly * h.w + lx;
+        }
+        if (tid < m) { pl.bcnt[tid] = bb.count(); pl.bwt[tid] = bb.weight; }
+    }
+    __syncthreads();
+    if (tid == 0) IPP_MARK(item, 4);
+    int pos[RJ];
+    int n_c = 0;
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int c = wcnt[j * NW + w];
+            before += (w < wave) ? c : 0;
+            all += c;
+        }
+        pos[j] = n_c + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
+        n_c += all;
+    }
+
+    // ------------------------------------------------------------------ gather HT for the contributing columns (owner lanes)
+    auto gather_issue = [&](unsigned rc, long long off, bool on, float (&l)[MC][4]) {
+        const unsigned r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
+        // patch_k[(fy - r0k) * pw + (fx - c0k)]; lanes without a column (and cells outside it) read the arena's first float
+        const float* patch = reinterpret_cast<const float*>(base0 + (on ? off : kTreePatchGuard)) - ((int)r0k * pw + (int)c0k) * (on ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) l[i][a] = 0.f;
+            if (i < m) {  // wave-uniform
+                const int cnt = uni(pl.bcnt[i]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a < cnt) {  // wave-uniform
+                        const unsigned yx = (unsigned)uni(lds.fb_yx[4 * i + a]);
+                        const unsigned fy = yx >> 16, fx = yx & 0xffffu;
+                        const bool in = on && fy >= r0k && fy <= r1k && fx >= c0k && fx <= c1k;
+                        const float val = in ? patch[(int)(fy * (unsigned)pw + fx)] : patch[on ? (int)(r0k * (unsigned)pw + c0k) : 0];
+                        l[i][a] = in ? val : 0.f;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto gather_store = [&](unsigned rc, long long off, bool on, int a_pos, const float (&l)[MC][4]) {
+        if (!on) return;
+        float rec[kPatchRec];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rec[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            if (i < m) {
+                const int cnt = uni(pl.bcnt[i]);
+                float t = l[i][0];
+                if (cnt > 1) t += l[i][1];
+                if (cnt > 2) t += l[i][2] + l[i][3];
+                rec[i] = -(t * lds.fb_w[4 * i]);
+            }
+        }
+        const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
+        const int shift = (r0n - r0k) * pw + (c0n - c0k);
+        rec[12] = __uint_as_float((unsigned)((off + (long long)shift * 4) >> 3));          // shifted patch: offset from base0 in 8-byte units
+        rec[13] = __int_as_float(r0k | (c0k << 16));
+        rec[14] = __int_as_float((r1k - r0k) | ((c1k - c0k) << 16));
+        rec[15] = 0.f;
+        if (a_pos < cap) {
+            float4* dst = reinterpret_cast<float4*>(lds.rec + (size_t)a_pos * kPatchRec);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+        } else {
+            float4* dst = reinterpret_cast<float4*>(ovf + (size_t)(a_pos - cap) * kPatchRec);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+        }
+    };
+    {
+        float l0[MC][4];
+        gather_issue(rcs[0], offs[0], con[0], l0);
+        {
+            const float s3 = (float)(kSqrt3 * v.res) / h.ls;
+            const int lw = v.plw;
+            for (int i = tid; i < lw * lw; i += NT) {
+                const int dr = i / lw, dc = i - dr * lw;
+                lds.lut[i] = matern_f(dr, dc, s3, h.sv);
+            }
+            if (tid < f) pl.ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv_d, ls_d);
+        }
+        if (tid == 0) IPP_MARK(item, 5);
+        gather_store(rcs[0], offs[0], con[0], pos[0], l0);
+    }
+#pragma unroll 1
+    for (int j = 1; j < RJ; ++j) {
+        if (j * NT >= r) break;
+        unsigned rc = rcs[RJ - 1];
+        long long off = offs[RJ - 1];
+        bool on = con[RJ - 1];
+        int ap = pos[RJ - 1];
+#pragma unroll
+        for (int q = 1; q < RJ - 1; ++q)
+            if (j == q) { rc = rcs[q]; off = offs[q]; on = con[q]; ap = pos[q]; }
+        if (__ballot(on) == 0ull) continue;
+        float l[MC][4];
+        gather_issue(rc, off, on, l);
+        gather_store(rc, off, on, ap, l);
+    }
+    const int n_lds = min(n_c, cap), n_ovf = n_c - n_lds;
+    if (n_ovf > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) IPP_MARK(item, 1);
+
+    // ------------------------------------------------------------------ m x m algebra by wave 0; every other wave streams at once
+    if (wave == 0) {
+        const int status = solve_wave_fast<MC>(v, h, item, flags_eff, lds.small, lds.rec, 1, kPatchRec, lds.Ls, lds.ys, nullptr, status_out,
+                                               nullptr, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) IPP_MARK(item, 7);
+    }
+    const int n_fast = min(n_lds, 2 * kWave);
+    unsigned mcofs[2], mlo[2], mex[2];
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int a = p2 * kWave + lane;
+        mcofs[p2] = 0u; mlo[p2] = 0x0000ffffu; mex[p2] = 0u;
+        if (a < n_fast) {
+            const float4 mt = *reinterpret_cast<const float4*>(lds.rec + (size_t)a * kPatchRec + 12);
+            mcofs[p2] = __float_as_uint(mt.x); mlo[p2] = __float_as_uint(mt.y); mex[p2] = __float_as_uint(mt.z);
+        }
+    }
+
+    // ------------------------------------------------------------------ units of the new node's patch
+    const float* Ls = lds.Ls; const float* lut = lds.lut;
+    const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
+    unsigned short* ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
+    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
+    const int n_units = (hn * pw + 2 * kWave - 1) / (2 * kWave);
+    const int lw = v.plw;
+    unsigned long long units = 0;
+    bool solved = false, dead = false;
+    const bool rf1 = (h.rf == 1), commit_u = h.commit != 0 && expand;
+    const float* mean_ro = v.mean + (size_t)root * v.Npad;
+    const float* diag_root = v.diag + (size_t)root * v.Npad;
+    float* new_cols = tv.node_cov + (size_t)max(new_id, 0) * MC * v.pstride;
+    float* new_diag = tv.node_diag + (size_t)max(new_id, 0) * v.pstride;
+    typedef float rowv __attribute__((ext_vector_type(VEC)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+    for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(next_unit, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const int flat = 2 * (u * kWave + lane);
+        const int prow = (int)(((unsigned)flat * (unsigned)v.pdiv) >> kPatchDivShift), pcol = flat - prow * pw;
+        const bool lane_valid = prow < hn && pcol < wn;
+        const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
+        const int cell0 = rrow * v.W + rcol;
+        // mean of the ROOT env (rewards.py:11: the map's current mean) and the PARENT state's diagonal: the deepest path node
+        // whose rectangle holds the cells (column bounds are even: a lane's two cells are inside or outside together), else the root's
+        float md_in[2][VEC];
+        load_vec<VEC>(mean_ro + cell0, md_in[0]);
+        {
+            const float* src = diag_root + cell0;
+#pragma unroll
+            for (int d = 0; d < kTreeDepth; ++d) {
+                const unsigned rc = prc[d];
+                const int r0d = rc & 0xff, r1d = (rc >> 8) & 0xff, c0d = (rc >> 16) & 0xff, c1d = rc >> 24;
+                if (rrow >= r0d && rrow <= r1d && rcol >= c0d && rcol <= c1d)
+                    src = tv.node_diag + (size_t)pid[d] * v.pstride + (rrow - r0d) * pw + (rcol - c0d);
+            }
+            load_vec<VEC>(src, md_in[1]);
+        }
+        const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> kPatchDivShift);
+        const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> kPatchDivShift));
+        const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
+        const unsigned flat4 = lane_valid ? (unsigned)flat * 4u : 0xffffffffu;
+
+        int nact = 0, nact_fast = 0;
+        for (int a0 = 0; a0 < n_c; a0 += kWave) {
+            const int a = a0 + lane;
+            bool on = false;
+            if (a < n_c) {
+                unsigned lo, ex;
+                if (a < n_fast) { lo = (a0 == 0) ? mlo[0] : mlo[1]; ex = (a0 == 0) ? mex[0] : mex[1]; }
+                else if (a < cap) { lo = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 13]); ex = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 14]); }
+                else { lo = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 13]); ex = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 14]); }
+                const int r0k = lo & 0xffff, r1k = r0k + (int)(ex & 0xffff);
+                on = r1k >= urow0 && r0k <= urow1;
+            }
+            const unsigned long long mask = __ballot(on);
+            if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)a;
+            nact += __popcll(mask);
+            if (a0 < n_fast) nact_fast += __popcll(mask & ((a0 + kWave <= n_fast) ? ~0ull : ((1ull << (n_fast - a0)) - 1ull)));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nact > 0 && lane < KP) ridx[nact + lane] = ridx[0];
+        __builtin_amdgcn_wave_barrier();
+
+        float acc[VEC][MC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+#pragma unroll
+            for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+        {
+            auto base_term = [&](auto nfc_tag) {
+                constexpr int NFC = decltype(nfc_tag)::value;
+#pragma unroll
+                for (int b = 0; b < MC; ++b) {
+                    if (b < m) {
+                        float cb[VEC];
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
+#pragma unroll
+                        for (int a = 0; a < NFC; ++a) {
+                            const int yx = fb_yx[4 * b + a];
+                            const float wa = fb_w[4 * b + a];
+                            const int fy = yx >> 16, fx = yx & 0xffff;
+#pragma unroll
+                            for (int c = 0; c < VEC; ++c) {
+                                const int dr = abs(rrow - fy), dc = abs(rcol + c - fx);
+                                cb[c] = fmaf(wa, lut[__umul24(dr, lw) + dc], cb[c]);
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
+                    }
+                }
+            };
+            if (rf1) base_term(std::integral_constant<int, 1>{});
+            else base_term(std::integral_constant<int, 4>{});
+        }
+
+        auto group = [&](int a0, auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const int ev = ridx[a0 + min(lane, KP - 1)];
+            rowv uu[KP];
+            int es[KP];
+            const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
+            const unsigned pc = page ? mcofs[1] : mcofs[0], pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const int e = __builtin_amdgcn_readlane(ev, i);
+                es[i] = e;
+                unsigned cofs8, lo, ex;
+                if (FAST) {
+                    cofs8 = (unsigned)__builtin_amdgcn_readlane((int)pc, e & 63);
+                    lo = (unsigned)__builtin_amdgcn_readlane((int)pl_, e & 63);
+                    ex = (unsigned)__builtin_amdgcn_readlane((int)pe, e & 63);
+                } else {
+                    const float* rp = (e < cap) ? (const float*)(lds.rec + (size_t)e * kPatchRec) : (const float*)(ovf + (size_t)(e - cap) * kPatchRec);
+                    const float4 mt = *reinterpret_cast<const float4*>(rp + 12);
+                    cofs8 = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.x));
+                    lo = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.y));
+                    ex = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.z));
+                }
+                const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
+                const bool ok = (int)(a0 + i < nact) &
+                                (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0) + ((unsigned long long)cofs8 << 3), 0, 0x7ffffff0, 0x00020000);
+                uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, IPP_PATCH_AUX));
+            }
+            float qr[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
+                qr[i] = rp[lane & 15];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const float ur[VEC] = {uu[i][0], uu[i][1]};
+                fmac_row<VEC, MC>(acc, qr[i], ur);
+            }
+        };
+        for (int a0 = 0; a0 < nact; a0 += KP) {
+            const int last = min(a0 + KP, nact) - 1;
+            const bool fast = last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6);
+            if (__builtin_amdgcn_readfirstlane((int)fast)) group(a0, std::true_type{});
+            else group(a0, std::false_type{});
+        }
+
+        if (!solved) {
+            while (__hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+            solved = true;
+            dead = __hip_atomic_load(solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
+        }
+        float lrow[MC];
+#pragma unroll
+        for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
+        linv_col<8>(acc, lrow); linv_col<7>(acc, lrow); linv_col<6>(acc, lrow); linv_col<5>(acc, lrow); linv_col<4>(acc, lrow);
+        linv_col<3>(acc, lrow); linv_col<2>(acc, lrow); linv_col<1>(acc, lrow); linv_col<0>(acc, lrow);
+        const bool commit = commit_u && !dead;
+
+        float dred[VEC];
+        double part = 0.0;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float w2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
+            if (!lane_valid) {
+                w2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
+            }
+            dred[c] = w2;
+            const bool in_mask = !adaptive || ((double)md_in[0][c] + v.kf * (double)md_in[1][c] >= v.thr);
+            if (lane_valid && in_mask) part += (double)w2;
+        }
+        part = wave_sum_dpp(part);
+        if (lane == 0) lds.unit_red[u] = part;
+        const int in_cells = __popcll(__ballot(lane_valid)) * VEC;
+        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells;
+        if (commit && prow < hn) {  // the new node: its diagonal on its rectangle, its m columns (whole runs of the patch rows)
+            float outv[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) outv[c] = md_in[1][c] - dred[c];
+            store_vec<VEC>(new_diag + flat, outv);
+#pragma unroll
+            for (int j = 0; j < MC; ++j)
+                if (j < m) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
+                    store_stream<VEC>(new_cols + (size_t)j * v.pstride + flat, outv);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ------------------------------------------------------------------ per-item results (last wave to arrive)
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds.red);
+    if (lane == 0 && units) atomicAdd(cnt, units);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int arrived = 0;
+    if (lane == 0) arrived = atomicAdd(done_waves, 1);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived == 0 && lane == 0) IPP_MARK(item, 6);
+    if (arrived != NW - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    dead = __hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
+    if (lane == 0) {
+        IPP_MARK(item, 2);
+        double tot = 0.0;
+        for (int t = 0; t < n_units; ++t) tot += lds.unit_red[t];
+        reward_out[item] = dead ? NAN : (float)(tot / (pl.hs->cost_d + 1.0));  // rewards.py:31
+        if (commit_u && !dead) {
+            int* meta = tv.node_meta + kNodeMeta * new_id;
+            meta[0] = m;
+            meta[1] = pl.hs->t_lo | (pl.hs->t_hi << 16);
+            meta[2] = parent_id;
+            meta[3] = root;
+            meta[4] = (int)rect_pack(r0n, r1n, c0n, c1n);
+        }
+        unsigned long long* slotc = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
+        if (cnt[0]) atomicAdd(slotc, cnt[0]);
+    }
+}
+
+// diag of a node's state in the patch layout: the deepest node (from `node` upwards) whose rectangle holds the cell, else the root env's
+__global__ void k_tree_read_diag_patch(View v, TreeView tv, int node, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= v.N) return;
+    const int row = c / v.W, col = c - row * v.W;
+    int cur = node;
+    const int root = tv.node_meta[kNodeMeta * node + 3];
+    float val = 0.f;
+    bool found = false;
+    for (int hops = 0; hops <= kTreeDepth && cur >= 0; ++hops) {
+        const unsigned rc = (unsigned)tv.node_meta[kNodeMeta * cur + 4];
+        if (rect_has(rc, row, col)) {
+            val = tv.node_diag[(size_t)cur * v.pstride + (row - (int)(rc & 0xff)) * v.pw + (col - (int)((rc >> 16) & 0xff))];
+            found = true;
+            break;
+        }
+        cur = tv.node_meta[kNodeMeta * cur + 2];
+    }
+    out[c] = found ? val : v.diag[(size_t)root * v.Npad + c];
+}
+
+}  // namespace ipp
