@@ -299,7 +299,10 @@ typedef struct ipp_mcts_tables {
 int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env /*[dev] R env slots*/, const double* prev0 /*[dev] R x 3*/,
                     const double* budget0 /*[dev] R*/, int32_t depth, int32_t sim0, int32_t wave, uint64_t seed, void* stream);
 /* The n covariance steps requested at `level` (= tree depth - depth of the select call): parents' device paths,
- * ipp_tree_step, edge numerators and the new nodes' device paths.  flags as for ipp_tree_step. */
+ * ipp_tree_step, edge numerators and the new nodes' device paths.  flags as for ipp_tree_step.
+ * n < 0 (engines with ipp_info.patch_layout = 1): the count stays on the device (t->rq_count[level], written by
+ * ipp_mcts_select); the launches are sized for roots x wave items, so that the driver queues select, all levels, expand and
+ * backup of a wave of simulations without a read-back in between. */
 int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, int32_t n, uint32_t flags, void* stream);
 /* Pending leaves: valid-action sets (sets_only = 1: only those, so that the caller can ask its network with them) and
  * priors / value: prior [dev] [R W][kmax] on the valid sets or NULL = uniform; value [dev] [R W] or NULL = value_const;

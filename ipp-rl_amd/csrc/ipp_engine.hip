@@ -1145,9 +1145,9 @@ static int score_actions_impl(void* engine, int32_t env_id, const ScorePath& pat
     return 0;
 }
 
-int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
-                  const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
-                  void* stream) {
+static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
+                          const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
+                          void* stream, const int32_t* n_dev) {
     Engine* e = as_engine(engine);
     if (!e || !root_ids || !path_ids || !action || !prev_action || !reward) return fail(-1, "null argument");
     if (e->tv.node_cap <= 0) return fail(-1, "ipp_tree_step needs ipp_config.node_capacity > 0");
@@ -1161,12 +1161,13 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
     const View& v = e->v;
     if (e->patch) {  // tree nodes as patches: one fused kernel for every launch size (k_tree_patch.h)
         if (e->patch_waves == 4)
-            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward);
+            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
         else
-            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward);
+            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (n_dev) return fail(-1, "device-side item counts need the patch layout (ipp_info.patch_layout)");
     if (v.meas_cap == 9 && e->tree_split_min > 0 && n >= e->tree_split_min) {
         timed_launch(e, 2, k_tree_prepare<9>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action,
                      prev_action, flags, status);
@@ -1187,6 +1188,12 @@ int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids
                      action, prev_action, flags, e->lut_rows, status, reward);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int ipp_tree_step(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
+                  const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
+                  void* stream) {
+    return tree_step_impl(engine, root_ids, path_ids, new_ids, n, action, prev_action, flags, reward, status, stream, nullptr);
 }
 
 // ---- device-side tree search (k_mcts.h)
@@ -1232,18 +1239,23 @@ int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, 
     if (!e) return fail(-1, "null engine");
     if (level < 0 || level >= t->max_depth) return fail(-1, "level %d outside [0, %d)", level, t->max_depth);
     const int rw = t->roots * t->wave;
-    if (n < 0 || n > rw) return fail(-1, "n = %d outside [0, roots x wave = %d]", n, rw);
+    // n < 0: the level's request count stays on the device (t->rq_count[level]); the launches are sized for roots x wave items
+    // (patch engines: k_tree_patch reads the count) -- a search wave needs no read-back between select and backup
+    const bool dev_count = n < 0;
+    if (dev_count && !e->patch) return fail(-1, "n < 0 (device-side counts) needs the patch layout");
+    if (!dev_count && n > rw) return fail(-1, "n = %d outside [0, roots x wave = %d]", n, rw);
     if (n == 0) return 0;
+    const int n_grid = dev_count ? rw : n, n_arg = dev_count ? -1 : n;
     if ((int64_t)t->roots * t->dev_per_root > e->tv.node_cap)
         return fail(-1, "roots x dev_per_root = %lld device nodes exceed ipp_config.node_capacity = %d", (long long)t->roots * t->dev_per_root, e->tv.node_cap);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
     const size_t o = (size_t)level * rw;
-    hipLaunchKernelGGL(k_mcts_level_paths, dim3((n + 255) / 256), dim3(256), 0, s, *t, (int)level, (int)n);
-    if (int rc = ipp_tree_step(engine, t->rq_root + o, t->ts_paths + kMctsPath * o, t->rq_newdev + o, n, t->rq_action + 3 * o, t->rq_prev + 3 * o,
-                               flags, t->ts_reward + o, t->ts_status + o, stream))
+    hipLaunchKernelGGL(k_mcts_level_paths, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)level, n_arg);
+    if (int rc = tree_step_impl(engine, t->rq_root + o, t->ts_paths + kMctsPath * o, t->rq_newdev + o, n_grid, t->rq_action + 3 * o, t->rq_prev + 3 * o,
+                                flags, t->ts_reward + o, t->ts_status + o, stream, dev_count ? t->rq_count + level : nullptr))
         return rc;
-    hipLaunchKernelGGL(k_mcts_apply, dim3((n + 255) / 256), dim3(256), 0, s, *t, (int)level, (int)n);
+    hipLaunchKernelGGL(k_mcts_apply, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)level, n_arg);
     HIP_TRY(hipGetLastError());
     return 0;
 }

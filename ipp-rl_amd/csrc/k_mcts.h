@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
 // Inputs of the level's ipp_tree_step that depend on the previous level's results: the parents' device paths.
 __global__ void k_mcts_level_paths(ipp_mcts_tables m, int level, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 0) n = m.rq_count[level];  // (the count stays on the device: ipp_mcts_level_steps with n < 0)
     if (i >= n) return;
     const size_t r = (size_t)level * m.roots * m.wave + i;
     const int parent = m.rq_parent[r];
@@ -267,6 +268,7 @@ __global__ void k_mcts_level_paths(ipp_mcts_tables m, int level, int n) {
 __global__ void k_mcts_apply(ipp_mcts_tables m, int level, int n) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 0) n = m.rq_count[level];
     if (i >= n) return;
     const size_t r = (size_t)level * m.roots * m.wave + i;
     if (m.ts_status[r] != 0) m.err[2] = m.ts_status[r];

@@ -23,12 +23,15 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
     int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
-    int* __restrict__ status_out, float* __restrict__ reward_out) {
+    int* __restrict__ status_out, float* __restrict__ reward_out, const int* __restrict__ n_dev) {
+    // n_dev: the item count lives on the device (ipp_mcts_level_steps with n < 0: the search driver queues the levels of a
+    // wave of simulations without reading their request counts back); the grid then has n_items >= *n_dev workgroups
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
     constexpr int RJ = kPatchMaxRank / NT;
     static_assert(NW == 2 || NW == 4, "two or four waves per item");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tp2[];
     const PatchLds lds(smem_tp2, v.pcap, v.plw * v.plw, NW, v.punits, v.rank_cap);
+    if (n_dev) n_items = min(n_items, uni(*n_dev));
     if ((int)blockIdx.x >= n_items) return;
     const int item = xcd_item(blockIdx.x, n_items);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;

@@ -359,3 +359,27 @@ def test_device_search_policies_of_a_large_action_set():
         K = int(m.n_K[j])
         pruned += int((m.t_Nsa[j, :K] > 0).sum()) - len(pol)
     assert pruned > 0  # forced playouts were actually taken back somewhere
+
+
+def test_device_search_without_read_backs_equals_the_synchronised_loop(monkeypatch):
+    """Tree nodes as patches (40x40: k_tree_patch) and a stub network: with IPP_MCTS_NOSYNC=1 the driver queues select, every level
+    (ipp_mcts_level_steps with n = -1: launches sized for roots x wave items, the kernels read the request counts on the device),
+    expand and backup of each wave of simulations without a read-back; trees and statistics must equal the synchronised loop's."""
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+
+    dim, R, sims, horizon = 40, 8, 32, 4
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.25)
+    assert eng.info.patch_layout == 1
+    roots = list(range(R))
+    results = []
+    for nosync in ("0", "1"):
+        monkeypatch.setenv("IPP_MCTS_NOSYNC", nosync)
+        s = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="first", leaf_value=0.3)
+        out = s.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(3 + r) for r in roots])
+        idx, nsa, q = s.root_statistics()
+        results.append((out, idx.copy(), nsa.copy(), q.copy(), dict(s.stats)))
+    (out_a, idx_a, nsa_a, q_a, st_a), (out_b, idx_b, nsa_b, q_b, st_b) = results
+    assert np.array_equal(idx_a, idx_b) and np.array_equal(nsa_a, nsa_b) and np.array_equal(q_a, q_b)
+    assert st_a["nodes"] == st_b["nodes"] and st_a["device_steps"] == st_b["device_steps"] and st_a["inferences"] == st_b["inferences"]
+    for j in roots:
+        assert out_a[j][0] == out_b[j][0]
