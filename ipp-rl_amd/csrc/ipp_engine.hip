@@ -120,12 +120,11 @@ uint64_t q_item_floats(const Layout& L) {
     return (q + 15) & ~(uint64_t)15;
 }
 
-// Compact column patches + k_step_patch (k_step_patch.h): windowed factor engines of the batched driver (no tree / scoring
-// scratch: those kernels read row-major band tiles), grids wide enough for two-dimensional windows, MC = 9.  Any of the A/B
+// Compact column patches + k_step_patch / k_tree_patch (k_step_patch.h, k_tree_patch.h): windowed factor engines on grids wide enough for two-dimensional windows, MC = 9.  Any of the A/B
 // switches of the band-tile kernels selects those kernels instead; IPP_PATCH=0 does so explicitly.
 bool patch_layout(const ipp_config& c, int MC) {
     if (c.state_repr != IPP_FACTOR || c.window_rows <= 0 || MC != 9) return false;
-    if (c.tile_threads != 0 || c.score_scratch) return false;
+    if (c.tile_threads != 0) return false;
     if (c.node_capacity > 0) {
         // tree nodes on patches (k_tree_patch.h): the records address column patches by 32-bit offsets in 8-byte units from
         // View::cov: root slots + node blocks must lie within 32 GB of it
@@ -1337,8 +1336,12 @@ int ipp_tree_score_actions(void* engine, int32_t root_id, const int32_t* path_id
     if (path.depth) {  // the node's diagonal lives on its span only: assemble the whole one along the parent chain
         if (!e->node_diag_scratch) return fail(-1, "ipp_tree_score_actions needs ipp_config.score_scratch = 1");
         HIP_TRY(hipSetDevice(e->device));
-        hipLaunchKernelGGL(k_tree_read_diag, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
-                           path.ids[path.depth - 1], e->node_diag_scratch);
+        if (e->patch)
+            hipLaunchKernelGGL(k_tree_read_diag_patch, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
+                               path.ids[path.depth - 1], e->node_diag_scratch);
+        else
+            hipLaunchKernelGGL(k_tree_read_diag, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, e->tv,
+                               path.ids[path.depth - 1], e->node_diag_scratch);
         node_diag = e->node_diag_scratch;
     }
     return score_actions_impl(engine, root_id, path, node_diag, actions, n, prev_action, flags, reward, status, stream);

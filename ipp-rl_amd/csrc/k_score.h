@@ -138,7 +138,25 @@ __global__ __launch_bounds__(256) void k_score_densify(View v, ScoreView sv, int
             const int kk = idx / TB, c = idx - kk * TB;
             const int k = k0 + kk;
             float a = 0.f, b = 0.f;
-            if (k < r) {
+            if (k < r && v.patch) {
+                // patch layout (k_step_patch.h / k_tree_patch.h): column k is the patch of its rectangle -- the root env's in its slot,
+                // a path node's in node_cov[id][j]
+                unsigned rc = (unsigned)v.colrect[(size_t)env * v.rank_cap + min(k, v.rank_cap - 1)];
+                const float* pk = U + (size_t)k * v.pstride;
+                if (CHAIN) {
+#pragma unroll
+                    for (int d = 0; d < kTreeDepth; ++d)
+                        if (d < path.depth && k >= cc.off[d]) {
+                            rc = cc.nrect[d];
+                            pk = node_cov + ((size_t)path.ids[d] * v.meas_cap + (k - cc.off[d])) * v.pstride;
+                        }
+                }
+                const int r0 = rc & 0xff, c0 = (rc >> 16) & 0xff;
+                const int ic = min(i0 + c, v.N - 1), jc = min(j0 + c, v.N - 1);
+                const int ri = ic / v.W, ci = ic - ri * v.W, rj = jc / v.W, cj = jc - rj * v.W;
+                if (i0 + c < v.N && rect_has(rc, ri, ci)) a = pk[(ri - r0) * v.pw + (ci - c0)];
+                if (j0 + c < v.N && rect_has(rc, rj, cj)) b = pk[(rj - r0) * v.pw + (cj - c0)];
+            } else if (k < r) {
                 const int sp = CHAIN ? cc.span(k) : span[k], lo = sp & 0xffff, hi = sp >> 16;
                 const float* rowk = CHAIN ? cc.row(k) : U + (size_t)k * v.Npad;
                 unsigned rc = kRectFull;  // (View::rect_meta: nothing is stored outside a column's rectangle)
