@@ -59,3 +59,65 @@ def test_not_pd_env_is_reported_and_isolated(patch):
         assert torch.equal(engines[0].read_mean(i), engines[1].read_mean(i))
         assert torch.equal(engines[0].read_diag(i), engines[1].read_diag(i))
         assert int(engines[0].rank(i)) == int(engines[1].rank(i))
+
+
+@pytest.mark.parametrize("cap", [8, 40])
+def test_column_records_that_overflow_the_lds_staging(cap, monkeypatch):
+    """k_step_patch / k_tree_patch keep one record per contributing column in LDS (View::pcap, ~200 at the headline); the rest
+    goes to the item's global scratch block and is served by the generic request group.  With the capacity forced down to 8 / 40
+    records (IPP_PATCH_CAP) most columns of a 30-step episode of clustered revisits overflow: rewards, means, variances, dense
+    covariances and chained tree steps must equal the default engine's bit for bit."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B, T = 6, 30
+    rs = np.random.RandomState(4)
+    gt = torch.as_tensor(rs.uniform(size=(B, 2500)), dtype=torch.float32, device="cuda")
+    centre = rs.randint(10, 40, size=(B, 2))
+    acts = []
+    for t in range(T):  # revisits within two cells of a centre: nearly every stored column reaches every footprint
+        cell = np.clip(centre + rs.randint(-2, 3, size=(B, 2)), 0, 49)
+        acts.append(np.stack([4.0 * cell[:, 0] + 2.0, 4.0 * cell[:, 1] + 2.0, rs.choice(ALTS, B)], axis=1))
+    noise = rs.normal(size=(T, B, 9))
+    outs = []
+    for forced in (None, cap):
+        if forced is None:
+            monkeypatch.delenv("IPP_PATCH_CAP", raising=False)
+        else:
+            monkeypatch.setenv("IPP_PATCH_CAP", str(forced))
+        eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=9 * (T + 4), window_rows=-1, fixed_prior=True, node_capacity=3 * B,
+                        max_batch=64)
+        assert eng.info.patch_layout == 1
+        eng.reset(gt=gt)
+        prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+        rewards = []
+        for t in range(T):
+            a = torch.as_tensor(acts[t], dtype=torch.float64, device="cuda")
+            r, s = eng.step(a, prev, meas_noise=torch.as_tensor(noise[t], dtype=torch.float32, device="cuda"))
+            assert int(s.abs().sum()) == 0
+            rewards.append(r.clone())
+            prev = a
+        roots = torch.arange(B, dtype=torch.int32, device="cuda")
+        path = torch.full((B, 6), -1, dtype=torch.int32, device="cuda")
+        tree = []
+        for d in range(3):  # chained tree steps from the deep states (root columns + node columns in the records)
+            a = prev.clone()
+            a[:, 0] = torch.clamp(a[:, 0] + 4.0 * (d + 1), 2.0, 198.0)
+            a[:, 2] = ALTS[(3 * d + 2) % 10]
+            ids = torch.arange(d * B, (d + 1) * B, dtype=torch.int32, device="cuda")
+            r, s = eng.tree_step(roots, path, a, prev, ids)
+            assert int(s.abs().sum()) == 0
+            path[:, d] = ids
+            prev = a
+            tree += [r.clone(), eng.tree_diag(int(ids[0])).clone()]
+        outs.append(dict(rewards=torch.stack(rewards), mean=torch.stack([eng.read_mean(e) for e in range(B)]),
+                         diag=torch.stack([eng.read_diag(e) for e in range(B)]), cov=eng.read_cov(1).clone(), tree=tree,
+                         ranks=eng.ranks().clone()))
+        eng.close()
+    a, b = outs
+    assert int(a["ranks"].max()) > 100
+    for key in ("rewards", "mean", "diag", "cov", "ranks"):
+        assert torch.equal(a[key], b[key]), key
+    for x, y in zip(a["tree"], b["tree"]):
+        assert torch.equal(x, y)
