@@ -624,9 +624,11 @@ def main(argv=None):
             extra.append(run_tree_wave(torch, device))
         except Exception as exc:
             extra.append({"name": "BASELINE configs[4] tree wave", "error": repr(exc)})
-        for drv in ("device", "host"):
+        # (4 simulations in flight per root is what the parity tests pin; 8 halves the launches: the virtual visits keep the
+        # descents apart either way, and 1 reproduces the reference's sequential search)
+        for drv, w in (("device", 4), ("device", 8), ("host", 4)):
             try:
-                extra.append(run_mcts_driver(torch, device, driver=drv))
+                extra.append(run_mcts_driver(torch, device, driver=drv, in_flight=w))
             except Exception as exc:
                 extra.append({"name": f"tree-search driver ({drv})", "error": repr(exc)})
         out["extra"] = extra

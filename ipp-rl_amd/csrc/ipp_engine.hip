@@ -144,7 +144,7 @@ bool patch_layout(const ipp_config& c, int MC) {
     return true;
 }
 int patch_waves_wanted() {
-    if (const char* w = getenv("IPP_PATCH_WAVES")) { const int n = atoi(w); if (n == 1 || n == 2 || n == 4) return n; }
+    if (const char* w = getenv("IPP_PATCH_WAVES")) { const int n = atoi(w); if (n >= 1 && n <= 4) return n; }
     return 2;
 }
 
@@ -407,6 +407,8 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                 timed_launch(e, 0, k_step_patch<1>, dim3(n), dim3(64), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else if (e->patch_waves == 4)
                 timed_launch(e, 0, k_step_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+            else if (e->patch_waves == 3)
+                timed_launch(e, 0, k_step_patch<3>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else
                 timed_launch(e, 0, k_step_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
         }
@@ -726,8 +728,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         v.clip_cols = 1;
         v.rect_meta = 1;
         v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.pdiv = L.pg.pdiv; v.plw = L.pg.plw; v.punits = L.pg.punits;
-        // column records in LDS: what fits the share of a workgroup when 16 waves of the kernel are resident per CU
-        size_t budget = (size_t)160 * 1024 / (16 / L.patch_waves);
+        // column records in LDS: what fits the share of a workgroup when kPatchWavesPerCu waves of the kernel are resident per CU
+        size_t budget = (size_t)160 * 1024 / (kPatchWavesPerCu / L.patch_waves) / 16 * 16;
         if (const char* wg = getenv("IPP_PATCH_WGS")) { if (atoi(wg) > 0) budget = (size_t)160 * 1024 / atoi(wg) / 16 * 16; }  // A/B: workgroups per CU to leave room for
         const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
         int pcap = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;

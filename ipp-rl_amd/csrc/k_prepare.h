@@ -72,7 +72,9 @@ struct PrepLds {
 // step kernel (k_step_patch.h).
 template <int MC, int MODE>
 __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int dst0, bool slots_ok, double ax, double ay, double az,
-                                                    double px, double py, double pz, int rank_ld, double sv, double ls, unsigned flags) {
+                                                    double px, double py, double pz, int rank_ld, double sv, double ls, unsigned flags,
+                                                    bool with_cost = true) {
+    // with_cost = false (wave-uniform): the caller's wave does not use cost / cost_d (k_step_patch: only wave 0's copy is kept)
     constexpr int FC = 4 * MC;
     ItemHdr h;
     h.env = env0;
@@ -105,12 +107,15 @@ __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int
     h.f = h.w * h.h;
     h.nv_d = v.coeff_a * (1.0 - exp(-v.coeff_b * az));                            // sensor_models.py:30
     h.nv = (float)h.nv_d;
-    const double dx = ax - px, dy = ay - py, dz = az - pz;
-    const double dist = sqrt(dx * dx + dy * dy + dz * dz);                        // actions.py:15-16
-    double cost = dist;
-    if (flags & IPP_USE_FLIGHT_TIME) {                                            // actions.py:32-41
-        const double d_acc = fmin(dist * 0.5, v.vmax * v.vmax / (2 * v.amax));
-        cost = (dist - 2 * d_acc) / v.vmax + 2 * sqrt(2 * d_acc / v.amax);
+    double cost = 0.0;
+    if (with_cost) {
+        const double dx = ax - px, dy = ay - py, dz = az - pz;
+        const double dist = sqrt(dx * dx + dy * dy + dz * dz);                    // actions.py:15-16
+        cost = dist;
+        if (flags & IPP_USE_FLIGHT_TIME) {                                        // actions.py:32-41
+            const double d_acc = fmin(dist * 0.5, v.vmax * v.vmax / (2 * v.amax));
+            cost = (dist - 2 * d_acc) / v.vmax + 2 * sqrt(2 * d_acc / v.amax);
+        }
     }
     h.cost_d = cost;
     h.cost = (float)cost;
@@ -983,16 +988,26 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         for (int k = 0; k < MC; ++k) dbg[lane * MC + k] = (lane < m && k < m) ? c[k] : 0.0;
     }
     bool pd = true;
+    double rd[MC];  // 1 / C[j][j] (wave-uniform), shared by the column scaling here and by L^-1 below
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
+        rd[j] = 1.0;
         if (j < m) {  // wave-uniform
             double t = c[j];
 #pragma unroll
             for (int k = 0; k < j; ++k) t = fma(-c[k], bcast_lane(c[k], j), t);  // - C[i][k] C[j][k]
             const double d = bcast_lane(t, j);
             if (!(d > 0.0)) pd = false;
-            const double sq = sqrt(d);
-            c[j] = (lane == j) ? sq : t / sq;  // rows above the diagonal hold junk that is never read
+            // 1 / sqrt(d): hardware estimate + two Newton steps (to an ulp or two in fp64; the 27 fp64 divisions and 9
+            // square roots of the textbook form were ~5 % of the item's vector instructions)
+            double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const double e = fma(-(d * y), y, 1.0);
+                y = fma(0.5 * y, e, y);
+            }
+            rd[j] = y;
+            c[j] = (lane == j) ? d * y : t * y;  // rows above the diagonal hold junk that is never read
         }
     }
     int status = h.status;
@@ -1012,8 +1027,7 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
                         if (k <= lane) sacc = fma(cki, li[k], sacc);
                     }
                 }
-                const double cii = bcast_lane(c[i], i);
-                li[i] = (lane == i) ? 1.0 / cii : ((lane > i && lane < m) ? -sacc / cii : 0.0);
+                li[i] = (lane == i) ? rd[i] : ((lane > i && lane < m) ? -sacc * rd[i] : 0.0);
             }
         }
     } else {

@@ -36,7 +36,7 @@ namespace ipp {
 
 constexpr int kPatchRec = 16;  // floats per column record
 #ifndef IPP_PATCH_KP
-#define IPP_PATCH_KP 12
+#define IPP_PATCH_KP 8  // (8 rows in flight per wave fit 96 VGPRs: 5 waves per SIMD; 12 rows at 4 waves per SIMD measured 3 % slower)
 #endif
 #ifndef IPP_PATCH_ABLATE
 #define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads
@@ -45,8 +45,9 @@ constexpr int kPatchRec = 16;  // floats per column record
 #define IPP_PATCH_AUX 2  // cache policy bits of the row requests (2: nt)
 #endif
 #ifndef IPP_PATCH_MINW
-#define IPP_PATCH_MINW 4
+#define IPP_PATCH_MINW 5  // waves per SIMD the register allocation aims at
 #endif
+constexpr int kPatchWavesPerCu = 4 * IPP_PATCH_MINW;
 constexpr int kPatchKP = IPP_PATCH_KP;   // stored rows requested per group
 constexpr int kPatchCtl = 32;  // control words
 constexpr int kPatchDivShift = 18;  // flat / pw == (flat * pdiv) >> 18, pdiv = ceil(2^18 / pw) (verified per engine: patch_division_exact)
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     const double* __restrict__ prev_action, const float* __restrict__ meas_noise, unsigned flags,
     int* __restrict__ status_out, float* __restrict__ reward_out, AutoReset ar) {
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
-    constexpr int RJ = kPatchMaxRank / NT;                 // rectangles per thread, loaded with the inputs
+    constexpr int RJ = (kPatchMaxRank + NT - 1) / NT;      // rectangles per thread, loaded with the inputs
     constexpr int OW = (NW > 1) ? 1 : 0;                   // the wave that evaluates the observation
     constexpr bool ONE = (NW == 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
@@ -145,23 +146,33 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     }
 
     // ------------------------------------------------------------------ header (every thread; uniform)
-    ItemHdr h = make_item_header<MC, IPP_FACTOR>(v, env0, env0, slots_ok, ax, ay, az, px, py, pz, rank_ld, sv_d, ls_d, flags);
+    // Wave 0 evaluates the header (fp64 divisions, exp, square roots: ~600 vector instructions) and hands it to the other
+    // waves through LDS; they arrive at the barrier with their batch-1 loads in flight.
     const int R = v.window_rows;
-    // rectangle of this step = its patch: rows / columns within R of the footprint, the column range widened to even columns
-    int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
-    int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
-    if (h.m > 0 && (r1n - r0n + 1 > v.ph || c1n - c0n + 1 > v.pw)) {  // (cannot happen for footprints of <= MC blocks: patch_geometry)
-        h.status = IPP_STATUS_BAD_FOOTPRINT; h.m = 0; h.f = 0; h.rows = 0; h.commit = 0;
+    const PrepLds<MC> pl(lds.small);
+    ItemHdr h;
+    if (ONE || __builtin_amdgcn_readfirstlane(wave) == 0) {
+        h = make_item_header<MC, IPP_FACTOR>(v, env0, env0, slots_ok, ax, ay, az, px, py, pz, rank_ld, sv_d, ls_d, flags);
+        // rectangle of this step = its patch: rows / columns within R of the footprint, the column range widened to even columns
+        const int r0 = max(0, h.yu - R), r1 = min(v.H - 1, h.yd + R);
+        const int c0 = max(0, h.xl - R) & ~(VEC - 1), c1 = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
+        if (h.m > 0 && (r1 - r0 + 1 > v.ph || c1 - c0 + 1 > v.pw)) {  // (cannot happen for footprints of <= MC blocks: patch_geometry)
+            h.status = IPP_STATUS_BAD_FOOTPRINT; h.m = 0; h.f = 0; h.rows = 0; h.commit = 0;
+        }
+        if (tid == 0) {
+            *pl.hs = h;
+            *next_unit = 0; *done_waves = 0; *solve_flag = 0; *obs_flag = 0;
+            lds.red[0] = 0.0; lds.red[1] = 0.0;
+        }
+    }
+    if (!ONE) {
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(wave) != 0) h = *pl.hs;
     }
     h = uniform_hdr(h);
-    r0n = uni(r0n); r1n = uni(r1n); c0n = uni(c0n); c1n = uni(c1n);
+    const int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
+    const int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
     const int hn = r1n - r0n + 1, wn = c1n - c0n + 1;
-    const PrepLds<MC> pl(lds.small);
-    if (tid == 0) {
-        *pl.hs = h;
-        *next_unit = 0; *done_waves = 0; *solve_flag = 0; *obs_flag = 0;
-        lds.red[0] = 0.0; lds.red[1] = 0.0;
-    }
     const int m = h.m, f = h.f, r = h.rank;
     if (m == 0) {  // bad footprint: no step, but a scheduled reset still happens
         if (tid == 0) {

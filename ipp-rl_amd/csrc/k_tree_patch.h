@@ -81,22 +81,29 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     // ------------------------------------------------------------------ header
     const bool expand = new_id >= 0 && new_id < tv.node_cap && !(flags & IPP_PREDICT_ONLY);
     const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
-    ItemHdr h = make_item_header<MC, IPP_FACTOR>(v, root0, root0, slots_ok, ax, ay, az, px, py, pz, n_cols, sv_d, ls_d, flags_eff);
+    // (wave 0 evaluates the header, the other waves take it from LDS: k_step_patch.h)
     const int R = v.window_rows;
-    int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
-    int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
-    if (h.m > 0 && (r1n - r0n + 1 > v.ph || c1n - c0n + 1 > v.pw || n_cols > min(kPatchMaxRank, v.rank_cap))) {  // (the chain must fit the record lists)
-        h.status = IPP_STATUS_BAD_FOOTPRINT; h.m = 0; h.f = 0; h.rows = 0; h.commit = 0;
-    }
-    h = uniform_hdr(h);
-    r0n = uni(r0n); r1n = uni(r1n); c0n = uni(c0n); c1n = uni(c1n);
-    const int hn = r1n - r0n + 1, wn = c1n - c0n + 1;
     const PrepLds<MC> pl(lds.small);
-    if (tid == 0) {
-        *pl.hs = h;
-        *next_unit = 0; *done_waves = 0; *solve_flag = 0;
-        lds.red[0] = 0.0; lds.red[1] = 0.0;
+    ItemHdr h;
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {
+        h = make_item_header<MC, IPP_FACTOR>(v, root0, root0, slots_ok, ax, ay, az, px, py, pz, n_cols, sv_d, ls_d, flags_eff);
+        const int r0 = max(0, h.yu - R), r1 = min(v.H - 1, h.yd + R);
+        const int c0 = max(0, h.xl - R) & ~(VEC - 1), c1 = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
+        if (h.m > 0 && (r1 - r0 + 1 > v.ph || c1 - c0 + 1 > v.pw || n_cols > min(kPatchMaxRank, v.rank_cap))) {  // (the chain must fit the record lists)
+            h.status = IPP_STATUS_BAD_FOOTPRINT; h.m = 0; h.f = 0; h.rows = 0; h.commit = 0;
+        }
+        if (tid == 0) {
+            *pl.hs = h;
+            *next_unit = 0; *done_waves = 0; *solve_flag = 0;
+            lds.red[0] = 0.0; lds.red[1] = 0.0;
+        }
     }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(wave) != 0) h = *pl.hs;
+    h = uniform_hdr(h);
+    const int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
+    const int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
+    const int hn = r1n - r0n + 1, wn = c1n - c0n + 1;
     if (tid < MC) { pl.zz[tid] = 0.0; pl.vv[tid] = 0.0; }  // (covariance only: no observation)
     const int m = h.m, f = h.f, r = h.rank;
     if (m == 0) {
