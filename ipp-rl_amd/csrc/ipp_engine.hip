@@ -729,8 +729,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         v.rect_meta = 1;
         v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.pdiv = L.pg.pdiv; v.plw = L.pg.plw; v.punits = L.pg.punits;
         // column records in LDS: what fits the share of a workgroup when kPatchWavesPerCu waves of the kernel are resident per CU
-        size_t budget = (size_t)160 * 1024 / (kPatchWavesPerCu / L.patch_waves) / 16 * 16;
-        if (const char* wg = getenv("IPP_PATCH_WGS")) { if (atoi(wg) > 0) budget = (size_t)160 * 1024 / atoi(wg) / 16 * 16; }  // A/B: workgroups per CU to leave room for
+        // (the LDS of a workgroup is allocated in granules of 1280 bytes on gfx950: 16 KB would take 13 of the 128)
+        int wgs = kPatchWavesPerCu / L.patch_waves;
+        if (const char* wg = getenv("IPP_PATCH_WGS")) { if (atoi(wg) > 0) wgs = atoi(wg); }  // A/B: workgroups per CU to leave room for
+        const size_t budget = (size_t)160 * 1024 / wgs / 1280 * 1280;
         const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
         int pcap = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;
         if (const char* pc = getenv("IPP_PATCH_CAP")) pcap = std::max(8, atoi(pc));  // A/B experiments, overflow tests

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     // The OWNER of a column gathers it: lanes <-> columns, the footprint's blocks and cells are wave-uniform loop counters,
     // every request is an unconditional buffer load whose offset is pushed out of range where the column is not stored.
     const auto slot_rs = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 0x7ffffff0, 0x00020000);
+    const auto row_rs = __builtin_amdgcn_make_buffer_rsrc(slot - v.pstride, 0, 0x7ffffff0, 0x00020000);  // (records hold offsets from here)
     // (cells and weights of the measurement blocks from the LDS tables filled in front of the barrier above: evaluating
     // block_of per request site -- divisions by nx, bw -- was 5000 instructions of a 17000-instruction kernel)
     auto gather_issue = [&](unsigned rc, int k, bool on, float (&l)[MC][4]) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         }
         const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
         const int shift = (r0n - r0k) * pw + (c0n - c0k);
-        rec[12] = __int_as_float((k * v.pstride + shift) * 4);                            // byte offset of the shifted patch in the slot
+        rec[12] = __int_as_float((k * v.pstride + shift + v.pstride) * 4);                // byte offset of the shifted patch from one patch in front of the slot (>= 0: the scalar offset of the row requests)
         rec[13] = __int_as_float(r0k | (c0k << 16));                                      // rectangle: first row | first column << 16
         rec[14] = __int_as_float((r1k - r0k) | ((c1k - c0k) << 16));                      //            rows - 1 | columns - 1 << 16
         rec[15] = __int_as_float(k);
@@ -527,9 +528,10 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                 // (bitwise: a short-circuit && on the lane's validity wrapped every row in an exec-mask region)
                 const bool ok = (int)(a0 + i < nact) &
                                 (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
-                const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slot) + cofs, 0, 0x7ffffff0, 0x00020000);
+                // one resource for the whole item, the patch offset as the request's scalar offset (a resource per row was four
+                // scalar instructions per row)
                 if (IPP_PATCH_ABLATE & 1) uu[i] = (rowv)(__int_as_float(cofs) * 1e-30f + (ok ? 1.f : 0.f));
-                else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, IPP_PATCH_AUX));  // (aux 2: nt)
+                else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(row_rs, ok ? flat4 : 0xffffffffu, cofs, IPP_PATCH_AUX));  // (aux 2: nt)
             }
             // -HT of the group's rows, value l & 15 in lane l (read while the requests are in flight)
             float qr[KP];
