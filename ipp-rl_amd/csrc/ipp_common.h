@@ -391,15 +391,23 @@ struct Block {
     double weight;
     __device__ __forceinline__ int count() const { return bw * bh; }
 };
+// floor(n / d) for 0 <= n < 4096, 0 < d <= 64 without the ~20-instruction integer division: (n + 0.5) / d is at least
+// 0.5 / d away from an integer, far more than the rounding of the reciprocal
+__device__ __forceinline__ int div_small(int n, int d) { return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d)); }
+// cell a of a measurement block of width bw (1 or 2 cells: the resolution factor is 1 or 2): row and column inside the block
+__device__ __forceinline__ int blk_dy(int a, int bw) { return bw == 2 ? a >> 1 : a; }
+__device__ __forceinline__ int blk_dx(int a, int bw) { return bw == 2 ? a & 1 : 0; }
 __device__ __forceinline__ Block block_of(int i, int nx, int rf, int w, int h) {
     Block b;
-    const int by = i / nx, bx = i - by * nx;
+    const int by = div_small(i, nx), bx = i - by * nx;
     const int x1 = min(bx * rf + rf, w), y1 = min(by * rf + rf, h);
     b.x0 = min(bx * rf, x1);
     b.y0 = min(by * rf, y1);
     b.bw = x1 - b.x0;
     b.bh = y1 - b.y0;
-    b.weight = (b.bw * b.bh < rf * rf) ? 1.0 / rf : 1.0 / (rf * rf);
+    // (sensor_models.py:62-79: 1 / rf for clipped blocks, 1 / rf^2 for whole ones; rf is 1 or 2, both quotients are exact)
+    const double inv = (rf == 2) ? 0.5 : (rf == 1 ? 1.0 : 1.0 / rf);
+    b.weight = (b.bw * b.bh < rf * rf) ? inv : inv * inv;
     return b;
 }
 

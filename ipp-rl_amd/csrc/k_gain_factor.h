@@ -115,7 +115,7 @@ __device__ __forceinline__ void fill_block_tables(const ItemHdr& h, int* fb_yx, 
         const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, bb.count() - 1);
-            fb_yx[4 * tid + a] = ((h.yu + bb.y0 + aa / bb.bw) << 16) | (h.xl + bb.x0 + aa % bb.bw);
+            fb_yx[4 * tid + a] = ((h.yu + bb.y0 + blk_dy(aa, bb.bw)) << 16) | (h.xl + bb.x0 + blk_dx(aa, bb.bw));
             fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
         }
     }

@@ -66,6 +66,14 @@ struct PrepLds {
     }
 };
 
+// Footprint cell of a measurement block in PrepLds::bfi: flat footprint-local index | column << 8 | row << 16 (the row and
+// column used to be recovered by integer divisions by the footprint width, per pair and cell of S: ~1000 instructions of an
+// rf = 2 item)
+__device__ __forceinline__ int bfi_pack(int ly, int lx, int w) { return (ly * w + lx) | (lx << 8) | (ly << 16); }
+__device__ __forceinline__ int bfi_flat(int e) { return e & 0xff; }
+__device__ __forceinline__ int bfi_x(int e) { return (e >> 8) & 0xff; }
+__device__ __forceinline__ int bfi_y(int e) { return e >> 16; }
+
 // The item header of a step: footprint, resolution factor, noise variance, cost, rank / status bookkeeping -- computed
 // by every thread from the same inputs (fp64 like NumPy: sensors/cameras.py:34-75,122-125, sensors/models/sensor_models.py:27-36,
 // planning/common/actions.py:8-41, mapping/mappings.py:125-126).  Shared by the prologue (prepare_item_ex) and the patch
@@ -370,7 +378,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, myb.count() - 1);
             const int ly = myb.y0 + aa / myb.bw, lx = myb.x0 + aa % myb.bw;
-            bfi[4 * tid + a] = ly * h.w + lx;
+            bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
             bcell[4 * tid + a] = (h.yu + ly) * v.W + h.xl + lx;
         }
     }
@@ -526,10 +534,9 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
                 for (int c = sl; c < ci * cj; c += GL) {
                     const int fa = bfi[4 * i + (c >> sh)], fb = bfi[4 * j + (c & (cj - 1))];
                     if (MODE == IPP_FACTOR) {
-                        const int lya = fa / h.w, lxa = fa - lya * h.w, lyb = fb / h.w, lxb = fb - lyb * h.w;
-                        acc += wij * ktab[abs(lya - lyb) * h.w + abs(lxa - lxb)];
+                        acc += wij * ktab[abs(bfi_y(fa) - bfi_y(fb)) * h.w + abs(bfi_x(fa) - bfi_x(fb))];
                     } else {
-                        acc += wij * (double)big[fa * (FC + 1) + fb];
+                        acc += wij * (double)big[bfi_flat(fa) * (FC + 1) + bfi_flat(fb)];
                     }
                 }
                 if (MODE == IPP_FACTOR) {
@@ -752,8 +759,7 @@ __device__ __forceinline__ int solve_wave(const View& v, const ItemHdr& h, const
                 const double wij = bwt[i] * bwt[j];
                 for (int c = sl; c < ci * cj; c += GL) {
                     const int fa = bfi[4 * i + (c >> sh)], fb = bfi[4 * j + (c & (cj - 1))];
-                    const int lya = fa / h.w, lxa = fa - lya * h.w, lyb = fb / h.w, lxb = fb - lyb * h.w;
-                    acc += wij * ktab[abs(lya - lyb) * h.w + abs(lxa - lxb)];
+                    acc += wij * ktab[abs(bfi_y(fa) - bfi_y(fb)) * h.w + abs(bfi_x(fa) - bfi_x(fb))];
                 }
                 for (int k = sl; k < r; k += GL) acc -= (double)ht[k * QS + i] * (double)ht[k * QS + j];
             }
@@ -943,8 +949,7 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         const double wij = bwt[pi] * bwt[pj];
         for (int c = 0; c < ci * cj; ++c) {
             const int fa = bfi[4 * pi + (c >> sh)], fb = bfi[4 * pj + (c & (cj - 1))];
-            const int lya = fa / h.w, lxa = fa - lya * h.w, lyb = fb / h.w, lxb = fb - lyb * h.w;
-            mine += wij * ktab[abs(lya - lyb) * h.w + abs(lxa - lxb)];
+            mine += wij * ktab[abs(bfi_y(fa) - bfi_y(fb)) * h.w + abs(bfi_x(fa) - bfi_x(fb))];
         }
         if (pi == pj) mine += R;
     }

@@ -202,13 +202,13 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     // ------------------------------------------------------------------ batch 2: inputs of the observation (lanes of wave OW)
     ObsRegs oregs;
     {
-        const int ly = max(otid, 0) / h.w, lx = max(otid, 0) - ly * h.w;
+        const int ly = div_small(max(otid, 0), h.w), lx = max(otid, 0) - ly * h.w;
         oregs.gt = (!cov_only && otid >= 0 && otid < f) ? gt_env[(h.yu + ly) * v.W + h.xl + lx] : 0.f;  // simulations/__init__.py:24-25
         const Block mob = block_of(min(max(otid, 0), m - 1), h.nx, h.rf, h.w, h.h);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, mob.count() - 1);
-            const int cell = (h.yu + mob.y0 + aa / mob.bw) * v.W + h.xl + mob.x0 + aa % mob.bw;
+            const int cell = (h.yu + mob.y0 + blk_dy(aa, mob.bw)) * v.W + h.xl + mob.x0 + blk_dx(aa, mob.bw);
             oregs.mean[a] = (!cov_only && otid >= 0 && otid < m && a < mob.count()) ? mean_env[cell] : 0.f;  // H x, mappings.py:195
         }
         oregs.eps = eps_ld;
@@ -227,16 +227,16 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         bal[j] = __ballot(con[j]);
         if (!ONE && lane == 0) wcnt[j * NW + wave] = __popcll(bal[j]);
     }
-    fill_block_tables<MC>(h, lds.fb_yx, lds.fb_w);
-    if (tid < m) {
-        const Block myb = block_of(tid, h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
-        pl.bcnt[tid] = myb.count();
-        pl.bwt[tid] = myb.weight;
+    if (tid < MC) {  // measurement blocks of the footprint as flat (cell, weight) tables + the tables of the m x m algebra
+        const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
         for (int a = 0; a < 4; ++a) {
-            const int aa = min(a, myb.count() - 1);
-            const int ly = myb.y0 + aa / myb.bw, lx = myb.x0 + aa % myb.bw;
-            pl.bfi[4 * tid + a] = ly * h.w + lx;
+            const int aa = min(a, bb.count() - 1);
+            const int ly = bb.y0 + blk_dy(aa, bb.bw), lx = bb.x0 + blk_dx(aa, bb.bw);
+            lds.fb_yx[4 * tid + a] = ((h.yu + ly) << 16) | (h.xl + lx);
+            lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
+            if (tid < m) pl.bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
         }
+        if (tid < m) { pl.bcnt[tid] = bb.count(); pl.bwt[tid] = bb.weight; }
     }
     patch_sync<ONE>();
     if (tid == 0) IPP_MARK(item, 4);
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
             const int lw = v.plw;
             for (int i = tid; i < lw * lw; i += NT) {
-                const int dr = i / lw, dc = i - dr * lw;
+                const int dr = div_small(i, lw), dc = i - dr * lw;
                 lds.lut[i] = matern_f(dr, dc, s3, h.sv);
             }
-            if (tid < f) pl.ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv_d, ls_d);
+            if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
         gather_store(rc_pre[0], tid, con[0], pos[0], l0);

@@ -149,10 +149,10 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
         const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, bb.count() - 1);
-            const int ly = bb.y0 + aa / bb.bw, lx = bb.x0 + aa % bb.bw;
+            const int ly = bb.y0 + blk_dy(aa, bb.bw), lx = bb.x0 + blk_dx(aa, bb.bw);
             lds.fb_yx[4 * tid + a] = ((h.yu + ly) << 16) | (h.xl + lx);
             lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
-            if (tid < m) pl.bfi[4 * tid + a] = ly * h.w + lx;
+            if (tid < m) pl.bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
         }
         if (tid < m) { pl.bcnt[tid] = bb.count(); pl.bwt[tid] = bb.weight; }
     }
@@ -236,10 +236,10 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
             const int lw = v.plw;
             for (int i = tid; i < lw * lw; i += NT) {
-                const int dr = i / lw, dc = i - dr * lw;
+                const int dr = div_small(i, lw), dc = i - dr * lw;
                 lds.lut[i] = matern_f(dr, dc, s3, h.sv);
             }
-            if (tid < f) pl.ktab[tid] = matern_d(tid / h.w, tid % h.w, v.res, sv_d, ls_d);
+            if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
         gather_store(rcs[0], offs[0], con[0], pos[0], l0);
