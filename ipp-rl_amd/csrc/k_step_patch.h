@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, bb.count() - 1);
             const int ly = bb.y0 + blk_dy(aa, bb.bw), lx = bb.x0 + blk_dx(aa, bb.bw);
-            lds.fb_yx[4 * tid + a] = ((h.yu + ly) << 16) | (h.xl + lx);
+            lds.fb_yx[4 * tid + a] = (h.yu + ly) | ((h.xl + lx) << 16);  // grid row | grid column << 16 (the packing of the rectangle tests)
             lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
             if (tid < m) pl.bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
         }
@@ -258,6 +258,26 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         pos[j] = n_c + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
         n_c += all;
     }
+    // The contributing columns change hands: thread t takes the t-th of them (column index and rectangle through LDS: the
+    // index list in the row-list area of the unit loop, the rectangles in the fp64 scratch of the m x m algebra, both idle
+    // until the barrier below), so that the gather runs over n_c columns instead of all r of them -- with one column in
+    // three contributing it was 3.8 rounds of 9 .. 36 requests per item, 15 % of the kernel's vector instructions.
+    unsigned short* klist = lds.ridx;
+    unsigned* rclist = reinterpret_cast<unsigned*>(pl.S);  // (S .. ktab: 2952 bytes)
+    static_assert(4 * kPatchMaxRank <= (3 * MC * (MC + 1) + 3 * MC + 2 * 4 * MC) * 8, "rectangle list does not fit the fp64 scratch");
+#pragma unroll
+    for (int j = 0; j < RJ; ++j)
+        if (con[j]) { klist[pos[j]] = (unsigned short)(tid + j * NT); rclist[pos[j]] = rc_pre[j]; }
+    patch_sync<ONE>();
+    int ck[RJ];
+    unsigned crc[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int t = tid + j * NT;
+        ck[j] = (t < n_c) ? (int)klist[t] : 0;
+        crc[j] = (t < n_c) ? rclist[t] : 0u;
+    }
+    patch_sync<ONE>();
 
     // ------------------------------------------------------------------ gather HT = H_F U[F,:]^T for the contributing columns
     // The OWNER of a column gathers it: lanes <-> columns, the footprint's blocks and cells are wave-uniform loop counters,
@@ -267,8 +287,13 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     // (cells and weights of the measurement blocks from the LDS tables filled in front of the barrier above: evaluating
     // block_of per request site -- divisions by nx, bw -- was 5000 instructions of a 17000-instruction kernel)
     auto gather_issue = [&](unsigned rc, int k, bool on, float (&l)[MC][4]) {
-        const unsigned r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
-        const int base = k * v.pstride - (int)r0k * pw - (int)c0k;  // patch_k[(fy - r0k) * pw + (fx - c0k)] = slot[base + fy * pw + fx]
+        // rectangle as (first row | first column << 16) and (rows - 1 | columns - 1 << 16): a cell (row | column << 16) lies inside
+        // iff min(cell - first, extent) == cell - first in both halves (two packed instructions instead of four compares); a lane
+        // without a contributing column gets a rectangle nothing lies in
+        const unsigned first = on ? (rc & 0x00ff00ffu) : 0xffffffffu;
+        const unsigned extent = on ? (((rc >> 8) & 0x00ff00ffu) - (rc & 0x00ff00ffu)) : 0u;
+        const int base4 = (k * v.pstride - (int)(rc & 0xff) * pw - (int)((rc >> 16) & 0xff)) * 4;  // patch_k[(fy - r0k) * pw + (fx - c0k)] = slot[base + fy * pw + fx]
+        typedef unsigned short us2g __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
 #pragma unroll
@@ -279,9 +304,10 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                 for (int a = 0; a < 4; ++a) {
                     if (a < cnt) {  // wave-uniform
                         const unsigned yx = (unsigned)uni(lds.fb_yx[4 * i + a]);
-                        const unsigned fy = yx >> 16, fx = yx & 0xffffu;
-                        const bool in = on && fy >= r0k && fy <= r1k && fx >= c0k && fx <= c1k;
-                        const unsigned voff = in ? (unsigned)(base + (int)(fy * (unsigned)pw + fx)) * 4u : 0xffffffffu;
+                        const int cell4 = (int)((yx & 0xffffu) * (unsigned)pw + (yx >> 16)) * 4;  // (scalar)
+                        const us2g d = __builtin_bit_cast(us2g, yx) - __builtin_bit_cast(us2g, first);
+                        const bool in = __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2g, extent))) == __builtin_bit_cast(unsigned, d);
+                        const unsigned voff = in ? (unsigned)(base4 + cell4) : 0xffffffffu;
                         l[i][a] = (IPP_PATCH_ABLATE & 32) ? __uint_as_float(voff) * 1e-30f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
                     }
                 }
@@ -322,7 +348,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
     };
     {
         float l0[MC][4];
-        gather_issue(rc_pre[0], tid, con[0], l0);
+        const bool any0 = wave * kWave < n_c;  // (wave-uniform)
+        if (any0) gather_issue(crc[0], ck[0], tid < n_c, l0);
         // ---- under the round trip: prior table, footprint tables of the m x m algebra, the padding record
         {
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
@@ -334,22 +361,21 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
             if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
-        gather_store(rc_pre[0], tid, con[0], pos[0], l0);
+        if (any0) gather_store(crc[0], ck[0], tid < n_c, tid, l0);
     }
 #pragma unroll 1
     for (int j = 1; j < RJ; ++j) {
-        if (j * NT >= r) break;
+        if (j * NT + wave * kWave >= n_c) break;  // (wave-uniform)
         // (a select chain on the wave-uniform j: a register array cannot be indexed dynamically)
-        unsigned rc = rc_pre[RJ - 1];
-        bool on = con[RJ - 1];
-        int ap = pos[RJ - 1];
+        unsigned rc = crc[RJ - 1];
+        int kk = ck[RJ - 1];
 #pragma unroll
         for (int q = 1; q < RJ - 1; ++q)
-            if (j == q) { rc = rc_pre[q]; on = con[q]; ap = pos[q]; }
-        if (__ballot(on) == 0ull) continue;
+            if (j == q) { rc = crc[q]; kk = ck[q]; }
+        const int t = tid + j * NT;
         float l[MC][4];
-        gather_issue(rc, tid + j * NT, on, l);
-        gather_store(rc, tid + j * NT, on, ap, l);
+        gather_issue(rc, kk, t < n_c, l);
+        gather_store(rc, kk, t < n_c, t, l);
     }
     if ((flags & IPP_UPDATE_PREV) && tid == 0) {
         // (every thread took its copy of prev_action in batch 1, in front of the barrier above)
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                         for (int a = 0; a < NFC; ++a) {
                             const int yx = fb_yx[4 * b + a];
                             const float wa = fb_w[4 * b + a];
-                            const int fy = yx >> 16, fx = yx & 0xffff;
+                            const int fy = yx & 0xffff, fx = yx >> 16;
 #pragma unroll
                             for (int c = 0; c < VEC; ++c) {
                                 const int dr = abs(rrow - fy), dc = abs(rcol + c - fx);
