@@ -491,6 +491,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
 #pragma unroll
             for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
         {
+            typedef float __attribute__((address_space(3))) lds_float;
+            const unsigned lut_b = (unsigned)(size_t)(const lds_float*)lut, lw4 = 4u * (unsigned)lw, rcol4 = 4u * (unsigned)rcol;
             auto base_term = [&](auto nfc_tag) {
                 constexpr int NFC = decltype(nfc_tag)::value;
 #pragma unroll
@@ -503,11 +505,15 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                         for (int a = 0; a < NFC; ++a) {
                             const int yx = fb_yx[4 * b + a];
                             const float wa = fb_w[4 * b + a];
-                            const int fy = yx & 0xffff, fx = yx >> 16;
+                            // lut[|rrow - fy| * lw + |rcol + c - fx|] with the LDS byte address out of two v_sad_u32
+                            // (|a - b| + c) and one multiply-add (the abs / multiply / shift form was 17 instructions per cell
+                            // pair, a tenth of the kernel)
+                            const unsigned fy = (unsigned)(yx & 0xffff), fx4 = (unsigned)(yx >> 16) * 4u;
+                            const unsigned row_b = __umul24(__usad((unsigned)rrow, fy, 0u), lw4) + lut_b;
 #pragma unroll
                             for (int c = 0; c < VEC; ++c) {
-                                const int dr = abs(rrow - fy), dc = abs(rcol + c - fx);
-                                cb[c] = fmaf(wa, lut[__umul24(dr, lw) + dc], cb[c]);
+                                const unsigned addr = __usad(rcol4 + 4u * c, fx4, row_b);
+                                cb[c] = fmaf(wa, *reinterpret_cast<const lds_float*>((size_t)addr), cb[c]);
                             }
                         }
 #pragma unroll
@@ -642,14 +648,18 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         }
         // the m new rows: every lane of the patch's rows stores (the padding columns pcol >= wn get zeros that no reader looks
         // at): whole 512-byte runs instead of row segments with holes, i.e. no partially written sectors
-        if (commit && prow < hn && !((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) {
-            float outv[VEC];
+        // (buffer stores through the item's resource: the row as scalar offset, lanes outside the patch's rows out of range --
+        // no 64-bit address per lane and row)
+        if (commit && !((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) {
+            typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(row_rs, 0, 0, 0)) raw2;
+            const unsigned so = (prow < hn) ? (unsigned)flat * 4u : 0xffffffffu;
 #pragma unroll
             for (int j = 0; j < MC; ++j)
                 if (j < m) {
+                    rowv t;
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
-                    store_stream<VEC>(slot + (size_t)(r + j) * v.pstride + flat, outv);
+                    for (int c = 0; c < VEC; ++c) t[c] = acc[c][j];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, so, (r + j + 1) * v.pstride * 4, IPP_NT_STORES ? 2 : 0);
                 }
         }
         __builtin_amdgcn_wave_barrier();
