@@ -531,16 +531,19 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         // FAST: every record of the group is one of the first 128 and lies in one 64-record page: its patch offset and rectangle
         // come out of this wave's registers through v_readlane with the record index as the (scalar) lane select, -HT from the
         // LDS record.  Else (more than 128 contributing columns, or records in the global overflow block): generic pointers.
-        auto group = [&](int a0, auto fast_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value;
-            const int ev = ridx[a0 + min(lane, KP - 1)];  // (lane i < KP holds the i-th record of the group)
-            rowv uu[KP];
-            int es[KP];
+        // N rows per group: whole groups of KP without the "row exists" test, the remainder of a unit in a group of 2, 4 or KP
+        // rows (a fixed KP wasted 3.5 masked rows per unit on average, ~26 instructions each)
+        auto group = [&](int a0, auto fast_tag, auto n_tag, auto full_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value, FULL = decltype(full_tag)::value;
+            constexpr int N = decltype(n_tag)::value;
+            const int ev = ridx[a0 + min(lane, N - 1)];  // (lane i < N holds the i-th record of the group)
+            rowv uu[N];
+            int es[N];
             const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
             const int pc = page ? mcofs[1] : mcofs[0];
             const unsigned pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
+            for (int i = 0; i < N; ++i) {
                 const int e = __builtin_amdgcn_readlane(ev, i);
                 es[i] = e;
                 int cofs;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                 }
                 const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
                 // (bitwise: a short-circuit && on the lane's validity wrapped every row in an exec-mask region)
-                const bool ok = (int)(a0 + i < nact) &
+                const bool ok = (int)(FULL || a0 + i < nact) &
                                 (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
                 // one resource for the whole item, the patch offset as the request's scalar offset (a resource per row was four
                 // scalar instructions per row)
@@ -566,25 +569,36 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                 else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(row_rs, ok ? flat4 : 0xffffffffu, cofs, IPP_PATCH_AUX));  // (aux 2: nt)
             }
             // -HT of the group's rows, value l & 15 in lane l (read while the requests are in flight)
-            float qr[KP];
+            float qr[N];
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
+            for (int i = 0; i < N; ++i) {
                 const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
                 qr[i] = rp[lane & 15];
             }
-            __builtin_amdgcn_sched_barrier(0);  // all KP requests leave before the first wait
+            __builtin_amdgcn_sched_barrier(0);  // all N requests leave before the first wait
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
+            for (int i = 0; i < N; ++i) {
                 if (IPP_PATCH_ABLATE & 16) { acc[0][0] = fmaf(uu[i][0], qr[i], acc[0][0]); acc[1][0] = fmaf(uu[i][1], qr[i], acc[1][0]); continue; }
                 const float ur[VEC] = {uu[i][0], uu[i][1]};
                 fmac_row<VEC, MC>(acc, qr[i], ur);
             }
         };
-        for (int a0 = 0; a0 < nact; a0 += KP) {
-            const int last = min(a0 + KP, nact) - 1;  // (list positions < nact_fast hold records < n_fast, in increasing order)
-            const bool fast = last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6);
-            if (__builtin_amdgcn_readfirstlane((int)fast)) group(a0, std::true_type{});
-            else group(a0, std::false_type{});
+        // (list positions < nact_fast hold records < n_fast, in increasing order; a fast group lies in one 64-record page)
+        auto is_fast = [&](int a0, int last) {
+            return __builtin_amdgcn_readfirstlane((int)(last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6))) != 0;
+        };
+        typedef std::integral_constant<int, KP> n_kp;
+        int a0 = 0;
+        for (; a0 + KP <= nact; a0 += KP) {
+            if (is_fast(a0, a0 + KP - 1)) group(a0, std::true_type{}, n_kp{}, std::true_type{});
+            else group(a0, std::false_type{}, n_kp{}, std::false_type{});
+        }
+        const int rem = nact - a0;
+        if (rem > 0) {
+            if (!is_fast(a0, nact - 1)) group(a0, std::false_type{}, n_kp{}, std::false_type{});
+            else if (KP > 4 && rem > 4) group(a0, std::true_type{}, n_kp{}, std::false_type{});
+            else if (rem > 2) group(a0, std::true_type{}, std::integral_constant<int, 4>{}, std::false_type{});
+            else group(a0, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{});
         }
 
         IPP_WT(2);
@@ -618,11 +632,9 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
 #pragma unroll
             for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
             dm = dot_lanes<MC>(acc[c], yreg);
-            if (!lane_valid) {
-                w2 = 0.f; dm = 0.f;
-#pragma unroll
-                for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
-            }
+            // (lanes outside the rectangle: their new-row values land in the padding columns of the patch, which no reader
+            // looks at -- finite values of clamped cells, not worth 18 selects per unit)
+            if (!lane_valid) { w2 = 0.f; dm = 0.f; }
             dred[c] = w2;
             dmean[c] = dm;
             // rewards.py:11 mask from the pre-step mean and pre-step diag(P); rewards.py:23-30 trace reduction
@@ -646,7 +658,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                 store_vec<VEC>(mean_rw + cell0, outv);
             }
         }
-        // the m new rows: every lane of the patch's rows stores (the padding columns pcol >= wn get zeros that no reader looks
+        // the m new rows: every lane of the patch's rows stores (the padding columns pcol >= wn get values of clamped cells that no reader looks
         // at): whole 512-byte runs instead of row segments with holes, i.e. no partially written sectors
         // (buffer stores through the item's resource: the row as scalar offset, lanes outside the patch's rows out of range --
         // no 64-bit address per lane and row)

@@ -460,11 +460,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
             float w2 = 0.f;
 #pragma unroll
             for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
-            if (!lane_valid) {
-                w2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
-            }
+            if (!lane_valid) w2 = 0.f;  // (the new-row values of these lanes land in padding columns no reader looks at)
             dred[c] = w2;
             const bool in_mask = !adaptive || ((double)md_in[0][c] + v.kf * (double)md_in[1][c] >= v.thr);
             if (lane_valid && in_mask) part += (double)w2;
