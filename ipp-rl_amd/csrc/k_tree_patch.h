@@ -392,15 +392,17 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
             else base_term(std::integral_constant<int, 4>{});
         }
 
-        auto group = [&](int a0, auto fast_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value;
-            const int ev = ridx[a0 + min(lane, KP - 1)];
-            rowv uu[KP];
-            int es[KP];
+        // (whole groups of KP rows without the row-exists test, the remainder in a group of 2, 4 or KP rows: k_step_patch.h)
+        auto group = [&](int a0, auto fast_tag, auto n_tag, auto full_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value, FULL = decltype(full_tag)::value;
+            constexpr int N = decltype(n_tag)::value;
+            const int ev = ridx[a0 + min(lane, N - 1)];
+            rowv uu[N];
+            int es[N];
             const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
             const unsigned pc = page ? mcofs[1] : mcofs[0], pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
+            for (int i = 0; i < N; ++i) {
                 const int e = __builtin_amdgcn_readlane(ev, i);
                 es[i] = e;
                 unsigned cofs8, lo, ex;
@@ -416,29 +418,39 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
                     ex = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.z));
                 }
                 const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
-                const bool ok = (int)(a0 + i < nact) &
+                const bool ok = (int)(FULL || a0 + i < nact) &
                                 (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
                 const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0) + ((unsigned long long)cofs8 << 3), 0, 0x7ffffff0, 0x00020000);
                 uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, IPP_PATCH_AUX));
             }
-            float qr[KP];
+            float qr[N];
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
+            for (int i = 0; i < N; ++i) {
                 const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
                 qr[i] = rp[lane & 15];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
+            for (int i = 0; i < N; ++i) {
                 const float ur[VEC] = {uu[i][0], uu[i][1]};
                 fmac_row<VEC, MC>(acc, qr[i], ur);
             }
         };
-        for (int a0 = 0; a0 < nact; a0 += KP) {
-            const int last = min(a0 + KP, nact) - 1;
-            const bool fast = last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6);
-            if (__builtin_amdgcn_readfirstlane((int)fast)) group(a0, std::true_type{});
-            else group(a0, std::false_type{});
+        auto is_fast = [&](int a0, int last) {
+            return __builtin_amdgcn_readfirstlane((int)(last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6))) != 0;
+        };
+        typedef std::integral_constant<int, KP> n_kp;
+        int a0 = 0;
+        for (; a0 + KP <= nact; a0 += KP) {
+            if (is_fast(a0, a0 + KP - 1)) group(a0, std::true_type{}, n_kp{}, std::true_type{});
+            else group(a0, std::false_type{}, n_kp{}, std::false_type{});
+        }
+        const int rem = nact - a0;
+        if (rem > 0) {
+            if (!is_fast(a0, nact - 1)) group(a0, std::false_type{}, n_kp{}, std::false_type{});
+            else if (KP > 4 && rem > 4) group(a0, std::true_type{}, n_kp{}, std::false_type{});
+            else if (rem > 2) group(a0, std::true_type{}, std::integral_constant<int, 4>{}, std::false_type{});
+            else group(a0, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{});
         }
 
         if (!solved) {
