@@ -172,6 +172,28 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
         pos[j] = n_c + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
         n_c += all;
     }
+    // the contributing columns change hands (k_step_patch.h): thread t takes the t-th of them, so the gather runs over n_c columns
+    unsigned short* klist = lds.ridx;
+    unsigned* rclist = reinterpret_cast<unsigned*>(pl.S);  // (S, L, Li: 2160 bytes in front of zz / vv)
+    static_assert(4 * kPatchMaxRank <= 3 * MC * (MC + 1) * 8, "rectangle list does not fit the fp64 scratch");
+#pragma unroll
+    for (int j = 0; j < RJ; ++j)
+        if (con[j]) { klist[pos[j]] = (unsigned short)(tid + j * NT); rclist[pos[j]] = rcs[j]; }
+    __syncthreads();
+    unsigned crc[RJ];
+    long long coff[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int t = tid + j * NT;
+        const int k = (t < n_c) ? (int)klist[t] : 0;
+        crc[j] = (t < n_c) ? rclist[t] : 0u;
+        long long off = root_off + (long long)k * v.pstride * 4;
+#pragma unroll
+        for (int d = 0; d < kTreeDepth; ++d)
+            if (k >= poff[d]) off = node_off + ((long long)pid[d] * MC + (k - poff[d])) * (long long)v.pstride * 4;
+        coff[j] = off;
+    }
+    __syncthreads();
 
     // ------------------------------------------------------------------ gather HT for the contributing columns (owner lanes)
     auto gather_issue = [&](unsigned rc, long long off, bool on, float (&l)[MC][4]) {
@@ -231,7 +253,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     };
     {
         float l0[MC][4];
-        gather_issue(rcs[0], offs[0], con[0], l0);
+        const bool any0 = wave * kWave < n_c;  // (wave-uniform)
+        if (any0) gather_issue(crc[0], coff[0], tid < n_c, l0);
         {
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
             const int lw = v.plw;
@@ -242,22 +265,20 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
             if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
-        gather_store(rcs[0], offs[0], con[0], pos[0], l0);
+        if (any0) gather_store(crc[0], coff[0], tid < n_c, tid, l0);
     }
 #pragma unroll 1
     for (int j = 1; j < RJ; ++j) {
-        if (j * NT >= r) break;
-        unsigned rc = rcs[RJ - 1];
-        long long off = offs[RJ - 1];
-        bool on = con[RJ - 1];
-        int ap = pos[RJ - 1];
+        if (j * NT + wave * kWave >= n_c) break;  // (wave-uniform)
+        unsigned rc = crc[RJ - 1];
+        long long off = coff[RJ - 1];
 #pragma unroll
         for (int q = 1; q < RJ - 1; ++q)
-            if (j == q) { rc = rcs[q]; off = offs[q]; on = con[q]; ap = pos[q]; }
-        if (__ballot(on) == 0ull) continue;
+            if (j == q) { rc = crc[q]; off = coff[q]; }
+        const int t = tid + j * NT;
         float l[MC][4];
-        gather_issue(rc, off, on, l);
-        gather_store(rc, off, on, ap, l);
+        gather_issue(rc, off, t < n_c, l);
+        gather_store(rc, off, t < n_c, t, l);
     }
     const int n_lds = min(n_c, cap), n_ovf = n_c - n_lds;
     if (n_ovf > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
