@@ -451,9 +451,6 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         const bool lane_valid = prow < hn && pcol < wn;
         const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
         const int cell0 = rrow * v.W + rcol;  // (clamped for the masked lanes: any valid address)
-        float md_in[2][VEC];
-        if (IPP_PATCH_ABLATE & 128) { md_in[0][0] = md_in[0][1] = 0.5f; md_in[1][0] = md_in[1][1] = 1.f; }
-        else { load_vec<VEC>(mean_rw + cell0, md_in[0]); load_vec<VEC>(diag_rw + cell0, md_in[1]); }
         const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> kPatchDivShift);
         const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> kPatchDivShift));
         const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
@@ -604,6 +601,11 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
         IPP_WT(2);
         IPP_WT_COUNT(9, (nact + KP - 1) / KP);
         IPP_WT_COUNT(10, 1);
+        // pre-step mean and variance of the unit's cells (read behind the row stream: held across it, the four values were spilled
+        // to scratch, per unit and wave; the L^-1 FMAs below cover the round trip)
+        float md_in[2][VEC];
+        if (IPP_PATCH_ABLATE & 128) { md_in[0][0] = md_in[0][1] = 0.5f; md_in[1][0] = md_in[1][1] = 1.f; }
+        else { load_vec<VEC>(mean_rw + cell0, md_in[0]); load_vec<VEC>(diag_rw + cell0, md_in[1]); }
         // ---- wait (first unit only) for L^-1 and y, then Wc = (P[:,F] H_F^T) L^-1 in place (column j needs the entries b <= j)
         if (!solved) {
             while (__hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
