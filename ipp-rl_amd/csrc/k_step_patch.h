@@ -12,8 +12,10 @@
 // column slot was Npad floats (10 KB at 50x50, 160 KB at 200x200) instead of 2.6 KB.  The appended columns are written
 // the same way: m fully coalesced row writes per unit.
 //
-// Workgroup = NW waves, 8 / NW ... 16 / NW items resident per CU (the per-item work is a chain of dependent round trips:
-// throughput = resident items / item lifetime).  LDS diet against k_step_factor (36 KB -> ~15 KB):
+// Workgroup = NW waves (2), 5 waves per SIMD -> 10 items resident per CU at 96 VGPRs and 15 KB of LDS.  What bounds the kernel
+// is the number of instructions per item (launch time ~ the longest item alone + 10-12 ns per further item; at 32768 items it
+// sits on instructions x 4 cycles / SIMDs) -- not the HBM round trips: pipelined requests, more waves per item and priorities
+// all measured equal or worse (profiles/r03_experiments.txt 13-17).  LDS diet against k_step_factor (36 KB -> 15 KB):
 //   * HT = H_F U[F,:]^T is gathered and staged only for the columns whose rectangle reaches the footprint (the others have
 //     an exactly zero row): per such column one 64-byte RECORD  [-HT(0..11) | byte offset of its shifted patch | rectangle as
 //     two packed 16-bit pairs | k]  -- the stream reads the record (LDS broadcast) instead of a scalar load from a global
