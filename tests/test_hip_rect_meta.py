@@ -102,6 +102,26 @@ def test_rectangle_metadata_equals_stored_zeros_and_band_tiles(dim, B, T, steps)
         assert np.allclose(host(ca), host(cb), rtol=0, atol=3e-6)
 
 
+@pytest.mark.parametrize("waves", [1, 3, 4])
+def test_patch_kernel_with_other_waves_per_item_is_bit_identical(waves):
+    """k_step_patch is built for 1 .. 4 waves per item (IPP_PATCH_WAVES, A/B builds; 2 is the default): the unit -> wave
+    assignment is dynamic and the reward sums run in unit order, so every variant must give the default's bits -- through
+    staggered resets, predict-only calls and the remainder groups of the row stream."""
+    import torch
+
+    VARIANTS["waves"] = dict(IPP_PATCH_WAVES=waves)
+    VARIANTS["default"] = dict(IPP_PATCH_WAVES=None)
+    try:
+        a, b = run_episode(50, 48, 20, 45, "default"), run_episode(50, 48, 20, 45, "waves")
+    finally:
+        VARIANTS.pop("waves"); VARIANTS.pop("default")
+    assert torch.equal(a["ranks"], b["ranks"])
+    for key in ("rewards", "predicted", "mean", "diag"):
+        assert torch.equal(a[key], b[key]), key
+    for ca, cb in zip(a["cov"], b["cov"]):
+        assert torch.equal(ca, cb)
+
+
 def test_engine_reports_rectangle_metadata_only_where_it_applies():
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.engine import IPPEngine
