@@ -41,7 +41,7 @@ constexpr int kPatchRec = 16;  // floats per column record
 #define IPP_PATCH_KP 8  // (8 rows in flight per wave fit 96 VGPRs: 5 waves per SIMD; 12 rows at 4 waves per SIMD measured 3 % slower)
 #endif
 #ifndef IPP_PATCH_ABLATE
-#define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads
+#define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads, 256 no rectangle test per row
 #endif
 #ifndef IPP_PATCH_AUX
 #define IPP_PATCH_AUX 2  // cache policy bits of the row requests (2: nt)
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
                 }
                 const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
                 // (bitwise: a short-circuit && on the lane's validity wrapped every row in an exec-mask region)
-                const bool ok = (int)(FULL || a0 + i < nact) &
-                                (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
+                const bool ok = (IPP_PATCH_ABLATE & 256) ? (FULL || a0 + i < nact) : (bool)((int)(FULL || a0 + i < nact) &
+                                (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d)));
                 // one resource for the whole item, the patch offset as the request's scalar offset (a resource per row was four
                 // scalar instructions per row)
                 if (IPP_PATCH_ABLATE & 1) uu[i] = (rowv)(__int_as_float(cofs) * 1e-30f + (ok ? 1.f : 0.f));
