@@ -585,10 +585,11 @@ def main(argv=None):
                                                 "cells of the rectangle within window_rows of the footprint in BOTH directions (a stored column IS that "
                                                 "rectangle, as a compact patch; the padding columns a patch row may have are neither counted nor read)",
                 "note": "columns of U are stored as compact patches of their rectangles (k_step_patch.h): a wave's request for a stored row is 512 "
-                        "consecutive bytes, the new rows are written as whole runs; the kernel is bound by instruction issue (at 32768 envs it sits on instructions x 4 "
-                        "cycles / SIMDs) and, at 4096 envs, by its longest item (one item per CU: 0.063 ms), not by HBM: the same row stream "
-                        "without arithmetic runs at 5.1 TB/s (tools/probes/patch_probe.hip, profiles/r03_patch_probe.txt), software-pipelined "
-                        "requests change nothing (profiles/r03_experiments.txt 13-16)",
+                        "consecutive bytes, the new rows are written as whole runs; the kernel is bound by the per-item chain of short dependent phases at ten resident "
+                        "items per CU (launch time ~ the longest item alone, 0.063 ms, + 10-12 ns per further item), not by HBM or the FMA rate: "
+                        "the same row stream without arithmetic runs at 5.1 TB/s (tools/probes/patch_probe.hip, profiles/r03_patch_probe.txt), "
+                        "software-pipelined requests change nothing, the launch without the stream's FMAs is 6 % shorter "
+                        "(profiles/r03_experiments.txt 13-20)",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],

@@ -12,10 +12,10 @@
 // column slot was Npad floats (10 KB at 50x50, 160 KB at 200x200) instead of 2.6 KB.  The appended columns are written
 // the same way: m fully coalesced row writes per unit.
 //
-// Workgroup = NW waves (2), 5 waves per SIMD -> 10 items resident per CU at 96 VGPRs and 15 KB of LDS.  What bounds the kernel
-// is the number of instructions per item (launch time ~ the longest item alone + 10-12 ns per further item; at 32768 items it
-// sits on instructions x 4 cycles / SIMDs) -- not the HBM round trips: pipelined requests, more waves per item and priorities
-// all measured equal or worse (profiles/r03_experiments.txt 13-17).  LDS diet against k_step_factor (36 KB -> 15 KB):
+// Workgroup = NW waves (2), 5 waves per SIMD -> 10 items resident per CU at 95 VGPRs and 15 KB of LDS.  What bounds the kernel
+// is the chain of short dependent phases of an item (launch time ~ the longest item alone + 10-12 ns per further item) -- not
+// HBM and not the FMA rate: pipelined requests, more waves per item, priorities and even dropping the stream's FMAs change
+// little; removing phases and iterations did (profiles/r03_experiments.txt 13-20).  LDS diet against k_step_factor (36 -> 15 KB):
 //   * HT = H_F U[F,:]^T is gathered and staged only for the columns whose rectangle reaches the footprint (the others have
 //     an exactly zero row): per such column one 64-byte RECORD  [-HT(0..11) | byte offset of its shifted patch | rectangle as
 //     two packed 16-bit pairs | k]  -- the stream reads the record (LDS broadcast) instead of a scalar load from a global
