@@ -84,6 +84,8 @@ struct Engine {
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     bool patch = false;   // k_step_patch on compact column patches (View::patch)
     int patch_waves = 2;  // waves per item of k_step_patch
+    int pcap_big = 0, big_min_items = 0;  // large launches: k_step_patch<2, 4, 6> with LDS for 12 workgroups per CU (0: never)
+    size_t lds_big = 0;
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
     const double* reset_prior = nullptr;  // ipp_set_reset_prior: priors of the episodes started by ipp_step_autoreset
     bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
@@ -409,7 +411,11 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                 timed_launch(e, 0, k_step_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else if (e->patch_waves == 3)
                 timed_launch(e, 0, k_step_patch<3>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
-            else
+            else if (e->big_min_items > 0 && n >= e->big_min_items) {
+                View vb = v;  // (six waves per SIMD pay once a launch is many rounds of workgroups: k_step_patch.h)
+                vb.pcap = e->pcap_big;
+                timed_launch(e, 0, k_step_patch<2, 4, 6>, dim3(n), dim3(128), e->lds_big, s, vb, env_ids, n, action, prev, noise, flags, status, reward, ar);
+            } else
                 timed_launch(e, 0, k_step_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
         }
         if (prep_done) (void)hipEventRecord(prep_done, s);
@@ -798,6 +804,19 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                                               GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec))
                                    : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
         if (e->patch) e->gain_lds = PatchLds::bytes(v.pcap, v.plw * v.plw, e->patch_waves, v.punits, v.rank_cap);
+        if (e->patch && e->patch_waves == 2 && !getenv("IPP_PATCH_CAP") && !getenv("IPP_PATCH_WGS")) {
+            // second configuration for large launches: LDS share of 12 workgroups per CU (10 granules of 1280 bytes)
+            const size_t budget = (size_t)160 * 1024 / 12 / 1280 * 1280;
+            const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, 2, v.punits, v.rank_cap);
+            const int pc = fixed + 33 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 0;
+            int min_items = 16384;
+            if (const char* b = getenv("IPP_PATCH_BIG")) min_items = atoi(b);  // A/B: smallest launch that takes it (0: never)
+            if (pc >= 32 && min_items > 0) {
+                e->pcap_big = std::min(pc, (int)v.pcap);
+                e->lds_big = PatchLds::bytes(e->pcap_big, v.plw * v.plw, 2, v.punits, v.rank_cap);
+                e->big_min_items = min_items;
+            }
+        }
         if (e->fused && !e->patch) {
             e->pipe_lds = (v.meas_cap == 9) ? PipeLds<9>::bytes(v.rank_cap, lutf, v.win_tiles) : PipeLds<25>::bytes(v.rank_cap, lutf, v.win_tiles);
             e->pipe = e->pipe_lds <= 160 * 1024;

@@ -110,12 +110,16 @@ __device__ __forceinline__ void patch_sync() {
     if (ONE) wave_lds_sync(); else __syncthreads();
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_step_patch(
+// KPN rows per request group at MINW waves per SIMD: (8, 5) = 95 VGPRs is the default; (4, 6) = 80 VGPRs, 12 workgroups per CU, is
+// 5 % faster for launches of 32768 items and 27 % slower for 4096 (3072 slots: a short, late second round) -- the engine takes it
+// for large launches only.
+template <int NW, int KPN = kPatchKP, int MINW = IPP_PATCH_MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     View v, const int* __restrict__ env_ids, int n_items, const double* __restrict__ action,
     const double* __restrict__ prev_action, const float* __restrict__ meas_noise, unsigned flags,
     int* __restrict__ status_out, float* __restrict__ reward_out, AutoReset ar) {
-    constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
+    constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = KPN;
+    static_assert(KPN <= kPatchKP, "the row lists are padded for kPatchKP entries");
     constexpr int RJ = (kPatchMaxRank + NT - 1) / NT;      // rectangles per thread, loaded with the inputs
     constexpr int OW = (NW > 1) ? 1 : 0;                   // the wave that evaluates the observation
     constexpr bool ONE = (NW == 1);

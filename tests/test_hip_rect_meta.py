@@ -122,6 +122,26 @@ def test_patch_kernel_with_other_waves_per_item_is_bit_identical(waves):
         assert torch.equal(ca, cb)
 
 
+def test_large_launch_instantiation_is_bit_identical():
+    """Launches of >= 16384 items run k_step_patch<2, 4, 6> (4 rows per request group, six waves per SIMD, fewer LDS records);
+    IPP_PATCH_BIG=1 selects it for every launch: same bits as the default instantiation."""
+    import torch
+
+    VARIANTS["big"] = dict(IPP_PATCH_BIG=1)
+    VARIANTS["default"] = dict(IPP_PATCH_BIG=0)
+    try:
+        a, b = run_episode(50, 48, 20, 45, "default"), run_episode(50, 48, 20, 45, "big")
+        c, d = run_episode(100, 24, 16, 36, "default"), run_episode(100, 24, 16, 36, "big")
+    finally:
+        VARIANTS.pop("big"); VARIANTS.pop("default")
+    for x, y in ((a, b), (c, d)):
+        assert torch.equal(x["ranks"], y["ranks"])
+        for key in ("rewards", "predicted", "mean", "diag"):
+            assert torch.equal(x[key], y[key]), key
+        for ca, cb in zip(x["cov"], y["cov"]):
+            assert torch.equal(ca, cb)
+
+
 def test_engine_reports_rectangle_metadata_only_where_it_applies():
     from ipp_rl_amd import EngineConfig
     from ipp_rl_amd.engine import IPPEngine
