@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
 
         // ---- ordered compaction of the records whose rectangle meets the rows of this unit (lane a <-> record a; the
         // rectangles of the first 128 records sit in this lane's registers)
-        int nact = 0, nact_fast = 0;
+        int nact = 0, nact_fast = 0, first_a = 0;
         for (int a0 = 0; a0 < n_c; a0 += kWave) {
             const int a = a0 + lane;
             bool on = false;
@@ -478,12 +478,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
             }
             const unsigned long long mask = __ballot(on);
             if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)a;
+            if (nact == 0 && mask) first_a = a0 + (int)__builtin_ctzll(mask);  // (first list entry, for the padding below)
             nact += __popcll(mask);
             if (a0 < n_fast) nact_fast += __popcll(mask & ((a0 + kWave <= n_fast) ? ~0ull : ((1ull << (n_fast - a0)) - 1ull)));
         }
-        __builtin_amdgcn_wave_barrier();
         // group tail: entries past nact repeat the first active record with their requests masked off (0 * finite = 0)
-        if (nact > 0 && lane < KP) ridx[nact + lane] = ridx[0];
+        if (nact > 0 && lane < KP) ridx[nact + lane] = (unsigned short)first_a;
         __builtin_amdgcn_wave_barrier();
         IPP_WT(0);
 
