@@ -283,7 +283,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         ck[j] = (t < n_c) ? (int)klist[t] : 0;
         crc[j] = (t < n_c) ? rclist[t] : 0u;
     }
-    patch_sync<ONE>();
+    // (no barrier behind the reads: nothing below writes the two lists' areas before the barrier that ends the gather -- the
+    // records go to lds.rec, the prior tables to lds.lut and pl.ktab, which starts behind the rectangle list)
+    static_assert(4 * kPatchMaxRank <= (3 * MC * (MC + 1) + 3 * MC + 4 * MC) * 8, "rectangle list reaches pl.ktab");
 
     // ------------------------------------------------------------------ gather HT = H_F U[F,:]^T for the contributing columns
     // The OWNER of a column gathers it: lanes <-> columns, the footprint's blocks and cells are wave-uniform loop counters,

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
             if (k >= poff[d]) off = node_off + ((long long)pid[d] * MC + (k - poff[d])) * (long long)v.pstride * 4;
         coff[j] = off;
     }
-    __syncthreads();
+    // (no barrier behind the reads: nothing below writes the two lists' areas before the barrier that ends the gather)
 
     // ------------------------------------------------------------------ gather HT for the contributing columns (owner lanes)
     auto gather_issue = [&](unsigned rc, long long off, bool on, float (&l)[MC][4]) {
