@@ -70,6 +70,14 @@ def build_parser():
                     help="scheduled episode resets inside the step launch (ipp_step_autoreset; VecIPPEnv's default)")
     ap.add_argument("--no-fused-resets", dest="fused_resets", action="store_false",
                     help="A/B: the scheduled resets as their own launch after every step")
+    ap.add_argument("--parts", type=int, default=1,
+                    help="schedule of a step: the batch as this many fixed groups of envs, one launch and one stream per group "
+                         "(VecIPPEnv.step_async: a group's step t + 1 is ordered behind its own step t only, so the next launch of one "
+                         "group fills the slots the slowest items of the other still hold); 1 (default) = one launch per step on one stream. "
+                         "Measured on MI355X (profiles/r04_experiments.txt 1): the partitioned schedule LOSES -- 37.9 M against 40.0 M "
+                         "env-steps/s at 2 groups, 27.8 M at 4: dependent launches of a queue start ~9 us after their predecessor "
+                         "once two queues are active (0 us on one queue) and the groups lock in phase.  With parts > 1 the "
+                         "one-launch rate is measured as well (config.sync_schedule)")
     ap.add_argument("--regions", type=int, default=5,
                     help="timed regions of --steps steps each (barrier + sync around every one); `value` is the median region")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
@@ -196,7 +204,7 @@ def baseline_config_name(grid, envs, episode_steps, total=None):
 def workload_key(args):
     return {"envs": args.envs, "grid": args.grid, "state": args.state, "window_rows": args.window_rows,
             "tile_threads": args.tile_threads, "episode_steps": args.episode_steps, "predict_only": bool(args.predict_only),
-            "shuffle_prior": bool(args.shuffle_prior)}
+            "shuffle_prior": bool(args.shuffle_prior), "parts": args.parts}
 
 
 def cpu_baseline(cfg, args):
@@ -263,7 +271,7 @@ def pmc_traffic(kernel_name, key):
 # --------------------------------------------------------------------------------------------- the measurement
 def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_envs, episode_steps, state="factor",
                      window_rows=-1, shuffle_prior=False, tile_threads=0, predict_only=False, fused_resets=True,
-                     steps=80, warmup=8, timed=True, regions=1):
+                     steps=80, warmup=8, timed=True, regions=1, parts=1):
     """One workload: build the batched env, pre-roll to the stationary rank mix, W warm-up steps, the timed region
     (all ranks), then the roofline leg (same steps again with HIP events on the streaming kernel's dispatches).
     Returns a dict of plain numbers."""
@@ -274,9 +282,10 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     B, T = envs_local, episode_steps
     env = VecIPPEnv(cfg, B, state=state, episode_steps=T, device=device, seed=1234, env_id_offset=env_lo,
                     stagger=True, tile_threads=tile_threads, window_rows=window_rows, fused_reset=fused_resets,
-                    shuffle_prior_cov=shuffle_prior)
+                    shuffle_prior_cov=shuffle_prior, parts=1 if predict_only else parts)
     eng = env.engine
-    n_total = T + warmup + (regions + 1) * steps
+    use_parts = env.parts > 1 and bool(env._fused_reset)
+    n_total = T + warmup + (2 * regions + 2) * steps
     # synthetic inputs resident in HBM before the timed region
     actions = torch.stack([
         torch.as_tensor(cell_centre_actions(cfg, t, env_lo, env_lo + B, total_envs, ALTITUDES), dtype=torch.float64)
@@ -293,16 +302,32 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
             if predict_only:
                 eng.step(actions[t_idx], env.prev, predict_only=True, cov_only=True, reward_out=env.reward,
                          status_out=env.status)
+            elif use_parts:
+                # (the actions were written and synchronised before the timed region: nothing to order against)
+                env.step_async(actions[t_idx], inputs_ready=True)
             else:
                 env.step(actions[t_idx])
             t_idx += 1
+
+    def run_steps_sync(k):  # one launch per step on one stream (the schedule of rounds 1-3), same env, same kernels
+        nonlocal t_idx
+        for _ in range(k):
+            env.step(actions[t_idx], after_step_hook=_no_hook)
+            t_idx += 1
+
+    def median_region(regs):
+        order_r = sorted(range(len(regs)), key=lambda i: regs[i][1])
+        return regs[order_r[len(order_r) // 2]]
 
     run_steps(warmup)
     # `regions` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + device sync on both sides; the
     # reported region is the MEDIAN one (by the max-over-ranks time), the spread goes into the record
     timed_regions = [timed_region(run_steps, steps, torch.cuda.synchronize, ranks) for _ in range(max(1, regions))]
-    order_r = sorted(range(len(timed_regions)), key=lambda i: timed_regions[i][1])
-    per_rank, elapsed_max = timed_regions[order_r[len(order_r) // 2]]
+    per_rank, elapsed_max = median_region(timed_regions)
+    sync_regions = None
+    if use_parts:
+        env.wait()
+        sync_regions = [timed_region(run_steps_sync, steps, torch.cuda.synchronize, ranks) for _ in range(max(1, regions))]
     bad = int((env.status != 0).sum().item())
     bad_rewards = int((~torch.isfinite(env.reward)).sum().item())
 
@@ -327,6 +352,17 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     gain_ms, gain_n = eng.profile_read(0)
     down_ms, down_n = eng.profile_read(1)
     prep_ms, prep_n = eng.profile_read(2)
+    eng.profile_read_busy(0)
+    # ---- the same leg on the partitioned schedule: the launches of different streams overlap, so the kernel time of a step is
+    # the time during which at least one of them runs (union of the dispatches' HIP-event intervals), not the sum of the durations
+    busy_ms_per_step, part_launches, part_ms_avg = None, 0, None
+    if use_parts:
+        run_steps(steps)
+        torch.cuda.synchronize()
+        part_ms_avg, _ = eng.profile_read(0)
+        busy, part_launches = eng.profile_read_busy(0)
+        busy_ms_per_step = busy / steps
+        eng.streamed_bytes(reset=True)
     eng.profile(False)
     N = cfg.n_cells
     mean_rank_after = float(rank_sum.item()) / (steps * B)
@@ -347,8 +383,15 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     # factor state: the device counter holds what the launch really streamed (windowed columns, SURVEY 8(d): "N must be
     # replaced by the window size actually streamed"), r + m + 4 floats per touched cell; dense state: the formula is exact
     bytes_per_launch = counted if state == "factor" else formula_bytes
+    single_launch_ms = kernel_ms
+    if busy_ms_per_step:
+        kernel_ms = busy_ms_per_step  # per step: every part's launch, overlapped as scheduled
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     rec = {
+        "parts": env.parts if use_parts else 1, "single_launch_ms": single_launch_ms, "part_launches": part_launches,
+        "part_launch_ms_avg": part_ms_avg,
+        "sync_region_elapsed_max_s": [r[1] for r in sync_regions] if sync_regions else None,
+        "sync_elapsed_max_s": median_region(sync_regions)[1] if sync_regions else None,
         "grid": grid, "envs_local": B, "episode_steps": T, "state": state, "predict_only": bool(predict_only),
         "window_rows": int(eng.info.window_rows), "tile_threads": int(eng.info.tile_threads),
         "per_rank_s": per_rank, "elapsed_max_s": elapsed_max, "steps": steps, "warmup": warmup,
@@ -364,6 +407,10 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     del env, eng, actions
     torch.cuda.empty_cache()
     return rec, cfg
+
+
+def _no_hook():
+    pass
 
 
 def run_tree_wave(torch, device, *, grid=200, roots=1024, sims=256, depth=5, root_steps=5, reps=4, wave=4):
@@ -501,6 +548,30 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
             "launches": st["launches"], "nodes": st["nodes"], "inferences": st["inferences"], "all_policies_valid": ok}
 
 
+def schedule_text(rec):
+    if rec["parts"] > 1:
+        return (f"{rec['parts']} fixed groups of envs, one launch and one stream per group (VecIPPEnv.step_async -> ipp_step_parts): a group's "
+                "step t + 1 is ordered behind its OWN step t only (envs are independent), so consecutive steps of different groups overlap "
+                "on the device; every env still makes exactly `steps` steps inside the timed region")
+    return "one launch per step on one stream"
+
+
+def kernel_ms_text(rec):
+    if rec["parts"] > 1:
+        return ("per STEP: time during which at least one of the step's launches runs (union of the dispatches' HIP-event intervals over the "
+                "roofline leg / steps) -- the launches of the groups overlap, their individual durations (part_launch_ms_avg) add up to more "
+                "than the wall time; single_launch_ms_avg: the whole batch as ONE launch, alone on the device (the figure of rounds 1-3)")
+    return "average HIP-event duration of the step kernel's dispatches over the roofline leg"
+
+
+def sync_record(rec, total_envs, steps):
+    if not rec.get("sync_elapsed_max_s"):
+        return None
+    return {"schedule": "one launch per step on one stream (rounds 1-3)", "value": aggregate_rate(total_envs, steps, rec["sync_elapsed_max_s"]),
+            "ms_per_step": 1e3 * rec["sync_elapsed_max_s"] / steps,
+            "region_ms_per_step": [1e3 * t / steps for t in rec["sync_region_elapsed_max_s"]]}
+
+
 def extra_record(name, rec, total_envs):
     return {"name": name, "value": aggregate_rate(total_envs, rec["steps"], rec["elapsed_max_s"]), "unit": "env-steps/s",
             "ms_per_step": 1e3 * rec["elapsed_max_s"] / rec["steps"], "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"],
@@ -508,7 +579,8 @@ def extra_record(name, rec, total_envs):
             "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / rec["steps"]) / 1e9 / HBM_PEAK_GBS,
             "frac_definition": "frac: algorithmic bytes / the dominant kernel's average duration; step_frac: the same bytes / the whole step period "
                                "(every launch of the step, resets and ground-truth generation included)",
-            "window_rows": rec["window_rows"],
+            "window_rows": rec["window_rows"], "schedule_parts": rec["parts"], "single_launch_ms_avg": rec["single_launch_ms"],
+            "sync_schedule": sync_record(rec, total_envs, rec["steps"]),
             "mean_rank_after_step": rec["mean_rank_after_step"], "arena_gb": rec["arena_gb"],
             "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"]}
 
@@ -540,7 +612,7 @@ def main(argv=None):
                                 episode_steps=T, state=args.state, window_rows=args.window_rows,
                                 shuffle_prior=args.shuffle_prior, tile_threads=args.tile_threads,
                                 predict_only=args.predict_only, fused_resets=args.fused_resets, steps=args.steps,
-                                warmup=args.warmup, regions=args.regions)
+                                warmup=args.warmup, regions=args.regions, parts=args.parts)
     if rank == 0:
         traffic, traffic_source = pmc_traffic(rec["kernel"], workload_key(args))
         out = {
@@ -572,6 +644,8 @@ def main(argv=None):
                 "value_is": "median of the timed regions (each exactly `steps` steps, max over ranks)",
                 "per_rank_ms_per_step": [1e3 * t / args.steps for t in rec["per_rank_s"]],
                 "per_rank_env_steps_per_s": [B * args.steps / t for t in rec["per_rank_s"]],
+                "schedule": schedule_text(rec),
+                "sync_schedule": sync_record(rec, total_envs, args.steps),
             },
             "roofline": {
                 "bound": "hbm", "achieved": rec["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -579,6 +653,10 @@ def main(argv=None):
                 "traffic_over_algorithmic": (traffic / rec["bytes_per_launch"]) if traffic and rec["bytes_per_launch"] else None,
                 "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "launches": rec["launches"],
+                "kernel_ms_definition": kernel_ms_text(rec),
+                "single_launch_ms_avg": rec["single_launch_ms"],
+                "single_launch_frac": (rec["bytes_per_launch"] / (rec["single_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rec["single_launch_ms"] else None,
+                "part_launch_ms_avg": rec["part_launch_ms_avg"], "part_launches": rec["part_launches"],
                 "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
                 "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device: "
                                                 "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
@@ -618,7 +696,7 @@ def main(argv=None):
         ]
         for name, kw in todo:
             try:
-                r, _ = run_env_workload(torch, ranks, device, env_lo=0, total_envs=kw["envs_local"], steps=20, warmup=4, **kw)
+                r, _ = run_env_workload(torch, ranks, device, env_lo=0, total_envs=kw["envs_local"], steps=20, warmup=4, parts=args.parts, **kw)
                 extra.append(extra_record(name, r, kw["envs_local"]))
             except Exception as exc:
                 extra.append({"name": name, "error": repr(exc)})

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 10
+#define IPP_ABI_VERSION 11
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -187,6 +187,24 @@ int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const dou
 int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const double* action, double* prev_action,
                        const float* meas_noise, uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src,
                        const float* reset_gt, const double* init_action, void* stream);
+
+/*
+ * ipp_step_autoreset of the whole batch as n_parts launches, one per PART of the dispatch order, each on its own
+ * stream: part p runs the items at positions [part_begin[p], part_begin[p + 1]) of the order installed by
+ * ipp_set_item_order (n entries; the per-item arrays keep their batch indexing, env_ids == NULL: item == env).
+ * Envs are independent (no exchange between envs; an episode is a chain of update_grid_map calls on ONE
+ * map, mapping/mappings.py:114-153), so only an env's own step t + 1 has to follow its step t: with a FIXED partition of the
+ * envs into parts and one stream per part, the next launch of part A starts in the slots that the slowest items of part B
+ * still leave empty -- the double-buffered ("async") form of a vectorised env, where the policy of one half runs while
+ * the other half steps.  The caller orders the streams against everything else (inputs ready on streams[p], results
+ * consumed behind streams[p]); nothing in here joins them.  Fused engines only (ipp_info.fused_step == 1).
+ *   part_begin  [host] int32[n_parts + 1], increasing, part_begin[0] == 0, part_begin[n_parts] == n
+ *   streams     [host] hipStream_t[n_parts]
+ * Other arguments: ipp_step_autoreset.  Results are bit-identical to the single launch (same kernel, same items).
+ */
+int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_action, const float* meas_noise,
+                   uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src, const float* reset_gt,
+                   const double* init_action, int32_t n_parts, const int32_t* part_begin, void* const* streams);
 
 /*
  * Priors of the episodes that the following ipp_step_autoreset launches start: prior [dev] double[..][2] = (sigma^2, l)
@@ -434,6 +452,10 @@ int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out /*[host]*/
  * kind: 0 = gain kernel, 1 = dense downdate kernel, 2 = prologue kernel.  Synchronises. */
 int ipp_profile_enable(void* engine, int32_t enable);
 int ipp_profile_read(void* engine, int32_t kind, double* avg_ms /*[host]*/, int64_t* launches /*[host]*/, int32_t reset);
+/* Same events, other question: the time [ms] during which AT LEAST ONE kernel of that kind was running (union of the
+ * dispatches' [start, stop] intervals) since the last reset of this figure -- what the launches of ipp_step_parts cost when
+ * they overlap on the device (their individual durations then add up to more than the wall time).  Synchronises. */
+int ipp_profile_read_busy(void* engine, int32_t kind, double* busy_ms /*[host]*/, int64_t* launches /*[host]*/, int32_t reset);
 /* Bytes the gain kernel actually streamed / wrote since the last reset of the counter (rows x valid cells x 4 +
  * 4 floats of mean / diag traffic per touched cell), counted on the device per workgroup: the numerator of roofline.achieved when
  * window_rows > 0.  Synchronises. */

@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class IppConfig(C.Structure):
@@ -104,6 +104,7 @@ PROTOTYPES = {
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_step_autoreset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "ipp_step_parts": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     "ipp_observe": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "ipp_set_uav": (C.c_int, [_P, C.c_double, C.c_double]),
     "ipp_set_adaptive": (C.c_int, [_P, C.c_double, C.c_double]),
@@ -127,6 +128,7 @@ PROTOTYPES = {
     "ipp_streamed_bytes_detail": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, _P]),
     "ipp_profile_enable": (C.c_int, [_P, C.c_int32]),
     "ipp_profile_read": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+    "ipp_profile_read_busy": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }
 
 _lib = None

@@ -59,6 +59,8 @@ struct ProfSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0.0;
     int64_t launches = 0;
+    double busy_ms = 0.0;       // union of the dispatches' [start, stop] intervals (launches of different streams overlap)
+    int64_t busy_launches = 0;
 };
 
 struct Engine {
@@ -370,17 +372,28 @@ void timed_launch(Engine* e, int kind, void (*kernel)(P...), dim3 grid, dim3 blo
 }
 
 void prof_drain(ProfSlot& p) {
+    std::vector<std::pair<float, float>> iv;  // [start, stop] of every dispatch, ms behind the first start of this batch
+    for (auto& pr : p.pending) (void)hipEventSynchronize(pr.second);
     for (auto& pr : p.pending) {
-        (void)hipEventSynchronize(pr.second);
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
             p.total_ms += ms;
             p.launches += 1;
+            if (hipEventElapsedTime(&t0, p.pending.front().first, pr.first) == hipSuccess) iv.emplace_back(t0, t0 + ms);
         }
+    }
+    for (auto& pr : p.pending) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
     p.pending.clear();
+    std::sort(iv.begin(), iv.end());
+    float end = -1e30f;
+    for (auto& x : iv) {
+        if (x.first > end) { p.busy_ms += x.second - x.first; end = x.second; }
+        else if (x.second > end) { p.busy_ms += x.second - end; end = x.second; }
+    }
+    p.busy_launches += (int64_t)iv.size();
 }
 
 size_t gain_lds_bytes(const View& v, int q_chunk, int lut_cap) {
@@ -1066,6 +1079,38 @@ int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const do
     return step_impl(engine, env_ids, nullptr, n, action, prev_action, meas_noise, flags, reward, status, stream, ar);
 }
 
+int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_action, const float* meas_noise,
+                   uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src, const float* reset_gt,
+                   const double* init_action, int32_t n_parts, const int32_t* part_begin, void* const* streams) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    if (!action || !prev_action || !reward || !part_begin || !streams) return fail(-1, "null argument");
+    if (e->v.mode != IPP_FACTOR || !(e->fused || e->patch) || e->pipe || e->v.meas_cap != 9 || e->v.vec != 2)
+        return fail(-1, "ipp_step_parts: engines whose step is one fused kernel only (ipp_info.fused_step)");
+    if (flags & IPP_PREDICT_ONLY) return fail(-1, "ipp_step_parts: not with IPP_PREDICT_ONLY");
+    if (flags & ~(IPP_COV_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_GIVEN_OBSERVATION | IPP_UPDATE_PREV)) return fail(-1, "unknown flag bits 0x%x", flags);
+    if (n <= 0 || n > e->v.max_batch || n > e->v.cap) return fail(-1, "n = %d outside [1, min(max_batch, capacity)]", n);
+    if (!e->v.item_order || e->v.item_order_n != n) return fail(-1, "ipp_step_parts: needs the dispatch order of all n items (ipp_set_item_order)");
+    if (n_parts < 1 || n_parts > kMaxChunks) return fail(-1, "n_parts = %d outside [1, %d]", n_parts, kMaxChunks);
+    if (part_begin[0] != 0 || part_begin[n_parts] != n) return fail(-1, "part_begin has to run from 0 to n");
+    for (int p = 0; p < n_parts; ++p)
+        if (part_begin[p + 1] <= part_begin[p]) return fail(-1, "part %d is empty", p);
+    if (reset_src && (!reset_gt || !init_action)) return fail(-1, "reset_src needs reset_gt and init_action");
+    AutoReset ar = {reset_src, reset_gt, reset_src ? e->reset_prior : nullptr, reset_src ? prev_action : nullptr, {0.0, 0.0, 0.0}};
+    if (init_action) for (int k = 0; k < 3; ++k) ar.init[k] = init_action[k];
+    HIP_TRY(hipSetDevice(e->device));
+    e->last_n = n;
+    for (int p = 0; p < n_parts; ++p) {
+        View v = e->v;  // (the per-item arrays keep their batch indexing: a part is a range of positions of the order)
+        v.item_order = e->v.item_order + part_begin[p];
+        v.item_order_n = part_begin[p + 1] - part_begin[p];
+        launch_chunk<9, 2>(e, v, nullptr, nullptr, v.item_order_n, action, prev_action, meas_noise, flags, reward, status,
+                           reinterpret_cast<hipStream_t>(streams[p]), nullptr, ar);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ipp_generate_grf(void* engine, int32_t n, const float* white_noise, float* gt_out, void* stream) {
     Engine* e = as_engine(engine);
     if (!e || !white_noise || !gt_out) return fail(-1, "null argument");
@@ -1590,6 +1635,18 @@ int ipp_profile_read(void* engine, int32_t kind, double* avg_ms, int64_t* launch
     if (avg_ms) *avg_ms = p.launches ? p.total_ms / (double)p.launches : 0.0;
     if (launches) *launches = p.launches;
     if (reset) { p.total_ms = 0.0; p.launches = 0; }
+    return 0;
+}
+
+int ipp_profile_read_busy(void* engine, int32_t kind, double* busy_ms, int64_t* launches, int32_t reset) {
+    Engine* e = as_engine(engine);
+    if (!e || kind < 0 || kind > 2) return fail(-1, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    ProfSlot& p = e->prof[kind];
+    prof_drain(p);
+    if (busy_ms) *busy_ms = p.busy_ms;
+    if (launches) *launches = p.busy_launches;
+    if (reset) { p.busy_ms = 0.0; p.busy_launches = 0; }
     return 0;
 }
 

@@ -357,6 +357,21 @@ class IPPEngine:
         self._keep = (a, p, ids, dst, nz)
         return reward, status
 
+    def step_parts(self, actions, prev_actions, meas_noise, flags: int, reward, status, part_begin, streams, *,
+                   reset_src=None, reset_gt=None, init_action=None):
+        """ipp_step_parts: the whole batch as len(streams) launches, part p = positions [part_begin[p], part_begin[p + 1]) of
+        the dispatch order (set_item_order) on streams[p] (torch streams).  All tensor arguments are preallocated device
+        tensors (the batched driver's loop); nothing joins the streams here."""
+        n = int(actions.shape[0])
+        P = len(streams)
+        begins = (C.c_int32 * (P + 1))(*[int(b) for b in part_begin])
+        sts = (C.c_void_p * P)(*[C.c_void_p(st.cuda_stream) for st in streams])
+        init = (C.c_double * 3)(*[float(x) for x in init_action]) if init_action is not None else None
+        _ffi.check(self._lib.ipp_step_parts(self._h, n, self._ptr(actions), self._ptr(prev_actions), self._ptr(meas_noise), int(flags),
+                                            self._ptr(reward), self._ptr(status), self._ptr(reset_src), self._ptr(reset_gt), init,
+                                            P, begins, sts))
+        self._keep = (actions, prev_actions, meas_noise, reset_src, reset_gt)
+
     def step_raw(self, n, actions, prev_actions, meas_noise, flags, reward, status, env_ids=None):
         """Zero-overhead variant for the benchmark loop: all arguments are preallocated device tensors."""
         _ffi.check(self._lib.ipp_step(self._h, self._ptr(env_ids), C.c_void_p(0), n, self._ptr(actions), self._ptr(prev_actions),
@@ -523,6 +538,12 @@ class IPPEngine:
     def profile_read(self, kind: int, reset: bool = True):
         ms, cnt = C.c_double(0.0), C.c_int64(0)
         _ffi.check(self._lib.ipp_profile_read(self._h, int(kind), C.byref(ms), C.byref(cnt), 1 if reset else 0))
+        return float(ms.value), int(cnt.value)
+
+    def profile_read_busy(self, kind: int, reset: bool = True):
+        """(ms during which at least one kernel of that kind ran, launches) since the last reset of this figure."""
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        _ffi.check(self._lib.ipp_profile_read_busy(self._h, int(kind), C.byref(ms), C.byref(cnt), 1 if reset else 0))
         return float(ms.value), int(cnt.value)
 
     # ------------------------------------------------------------------ byte accounting (DESIGN.md, SURVEY 8(d))

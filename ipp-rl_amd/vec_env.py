@@ -23,6 +23,7 @@ import os
 
 import numpy as np
 
+from . import _ffi
 from .engine import EngineConfig, IPPEngine
 
 INIT_ACTION = (2.0, 2.0, 14.0)  # planning/missions.py:69
@@ -58,7 +59,8 @@ class VecIPPEnv:
     def __init__(self, cfg: EngineConfig, num_envs: int, state: str = "factor", episode_steps: int = 40,
                  device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
                  rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
-                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0, fused_reset: bool = True):
+                 adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0, fused_reset: bool = True,
+                 parts: int = 1):
         import torch
 
         self.torch = torch
@@ -90,6 +92,29 @@ class VecIPPEnv:
             ph = (np.arange(B, dtype=np.int64) + self.env_id_offset) % self.episode_steps
             self._orders = [torch.as_tensor(np.argsort(-((t + ph) % self.episode_steps), kind="stable").astype(np.int32), device=dev)
                             for t in range(self.episode_steps)]
+        # parts > 1: a FIXED partition of the envs into `parts` groups (every group holds every episode phase), each stepped by
+        # its own launch on its own stream (step_async / wait): only an env's OWN step t + 1 has to follow its step t, so the
+        # next launch of one group fills the slots that the slowest items of the other group still leave empty
+        # (IPPEngine.step_parts).  Their dispatch orders list group 0's items (heaviest first), then group 1's, ...
+        self.parts = 1
+        self._part_begin = None
+        self._part_streams = None
+        if parts > 1 and stagger and self._orders is not None and self.engine.info.fused_step == 1 and B >= 2 * parts:
+            self.parts = int(parts)
+            grp = ((np.arange(B, dtype=np.int64) + self.env_id_offset) // self.episode_steps) % self.parts
+            ph = (np.arange(B, dtype=np.int64) + self.env_id_offset) % self.episode_steps
+            self._orders_parts = []
+            for t in range(self.episode_steps):
+                w = (t + ph) % self.episode_steps
+                key = grp * (2 * self.episode_steps) + (self.episode_steps - 1 - w)  # group, then descending weight, then env id
+                self._orders_parts.append(torch.as_tensor(np.argsort(key, kind="stable").astype(np.int32), device=dev))
+            self._part_begin = [0] + [int(x) for x in np.cumsum(np.bincount(grp, minlength=self.parts))]
+            self._part_envs = [torch.as_tensor(np.nonzero(grp == g)[0].astype(np.int64), device=dev) for g in range(self.parts)]
+            self._part_streams = [torch.cuda.Stream(device=dev) for _ in range(self.parts)]
+            self._part_done = [torch.cuda.Event() for _ in range(self.parts)]
+            self._ev_inputs = torch.cuda.Event()
+            self._async_pending = False
+            self._main_dirty = True  # the caller's stream holds work on the env slots that the part streams have not waited for
         self._reset_ids_by_phase = None
         if stagger:
             ph = self.phase.cpu().numpy()
@@ -129,15 +154,23 @@ class VecIPPEnv:
             self._staged = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2 * K)]
             self._staged_white = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2 * K)]
             self._blk_ready = [torch.cuda.Event() for _ in range(2)]
-            self._blk_free = [torch.cuda.Event() for _ in range(2)]
-            for ev in self._blk_free:
-                ev.record(torch.cuda.current_stream(dev))
+            # (`free` of a buffer set: one event per stream that steps the batch -- the caller's, or one per part)
+            self._blk_free = [[torch.cuda.Event() for _ in range(self.parts)] for _ in range(2)]
+            for evs in self._blk_free:
+                for ev in evs:
+                    ev.record(torch.cuda.current_stream(dev))
             self._blk_tag = [-1, -1]   # block index staged in each buffer set
             self._blk_waited = -1      # block whose `ready` event the main stream has waited for
         # measurement noise for NOISE_RING steps per generator launch
         self._noise_ring = torch.empty((self.NOISE_RING, B, self.engine.meas_cap), dtype=torch.float32, device=dev)
         self._noise_pos = 0
         self._noise_fills = 0
+        if self.parts > 1:  # two rings: the next one is filled on the caller's stream while the part streams read this one
+            self._noise_rings = [self._noise_ring, torch.empty_like(self._noise_ring)]
+            self._ring_ready = [torch.cuda.Event() for _ in range(2)]
+            self._ring_free = [[torch.cuda.Event() for _ in range(self.parts)] for _ in range(2)]
+            self._ring_filled = [-1, -1]  # fill index held by each ring
+            self._ring_cur = 0
         self.reward = torch.empty(B, dtype=torch.float32, device=dev)
         self.status = torch.empty(B, dtype=torch.int32, device=dev)
         self._flags = (4 if adaptive else 0) | (8 if use_flight_time else 0)
@@ -185,6 +218,9 @@ class VecIPPEnv:
     def reset(self, env_ids=None, white_noise=None, gt=None, prior_scale=None, _phase=None):
         """Reset the given slots (all when None).  white_noise / gt: [n, H, W] NumPy or tensor (parity)."""
         torch = self.torch
+        if self.parts > 1:
+            self.wait()
+            self._main_dirty = True
         if _phase is not None:  # scheduled reset of step(): index tensors prepared at construction
             ids = self._reset_ids_by_phase[_phase]
         elif env_ids is None:
@@ -232,7 +268,8 @@ class VecIPPEnv:
         """Start, on the side stream, the ground truths of every reset of the steps [b K, (b + 1) K) into buffer set b % 2."""
         torch = self.torch
         K, set_ = self._blk_K, b % 2
-        self._side.wait_event(self._blk_free[set_])
+        for ev in self._blk_free[set_]:
+            self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
             for j in range(K):
                 p = self._phase_ending_at(b * K + j)
@@ -250,9 +287,12 @@ class VecIPPEnv:
         if self._side is None:
             return
         main = self.torch.cuda.current_stream(self.device)
+        if self.parts > 1:
+            self.wait()  # (the part streams' reads of the sets are in front of this point of the caller's stream)
         for set_ in range(2):
             self._blk_tag[set_] = -1
-            self._blk_free[set_].record(main)  # (everything that read the set is in front of this point of the stream)
+            for ev in self._blk_free[set_]:
+                ev.record(main)  # (everything that read the set is in front of this point of the stream)
         self._blk_waited = -1
 
     GT_STREAM, NOISE_STREAM = 1 << 40, 2 << 40  # subsequence = stream kind + episode index / step index
@@ -289,6 +329,16 @@ class VecIPPEnv:
         schedule known to the host (no device->host sync in the loop).
         """
         torch = self.torch
+        if self.parts > 1:
+            if env_ids is None and auto_reset and meas_noise is None and after_step_hook is None and \
+                    (self._fused_reset or self._reset_ids_by_phase is None):
+                # the synchronous call on a partitioned batch: the parts' launches run side by side, the caller's stream
+                # continues behind both (same results, one join per step)
+                self.step_async(actions)
+                self.wait()
+                return self.reward, self.status
+            self.wait()  # any other call form runs on the caller's stream, behind everything the part streams hold
+            self._main_dirty = True
         a = self.engine._dev(actions, torch.float64).reshape(-1, 3)
         main = torch.cuda.current_stream(self.device)
         scheduled = None
@@ -318,7 +368,9 @@ class VecIPPEnv:
             # behind an older event while resets of the main stream may still be reading it
             b_, j_ = divmod(self.t, self._blk_K)
             blk = (b_ % 2, j_ == self._blk_K - 1) if self._blk_tag[b_ % 2] == b_ else None
-        if meas_noise is None:
+        if meas_noise is None and self.parts > 1:
+            nz = self._noise_plane_parts(main, None)
+        elif meas_noise is None:
             if self._noise_pos == 0:
                 # plane p of the ring = step (fills * NOISE_RING + p); row = global env id
                 self.engine.normal_rows(self._noise_ring, self.engine.meas_cap, self.seed, self.NOISE_STREAM +
@@ -342,6 +394,8 @@ class VecIPPEnv:
         self.engine.step(a, self.prev, env_ids=env_ids, meas_noise=nz, adaptive=self.adaptive,
                          use_flight_time=self.use_flight_time, reward_out=self.reward, status_out=self.status,
                          update_prev=env_ids is None, **(fused or {}))
+        if meas_noise is None and self.parts > 1:
+            self._noise_done_parts(None)
         if fused is not None:
             self.episode[self._reset_ids_host[scheduled[0]]] += 1
             scheduled = None
@@ -354,21 +408,136 @@ class VecIPPEnv:
             p, k, n = scheduled
             self.reset(gt=self._staged[k][:n], _phase=p)
         if blk is not None and blk[1]:
-            self._blk_free[blk[0]].record(main)  # last step of the block: its buffer set may be refilled
+            for ev in self._blk_free[blk[0]]:
+                ev.record(main)  # last step of the block: its buffer set may be refilled
         return self.reward, self.status
+
+    # ------------------------------------------------------------------ partitioned batch: one launch and one stream per part
+    def part_stream(self, p: int):
+        """The stream that steps part p (run that part's policy on it and no event is needed around step_async)."""
+        return self._part_streams[p]
+
+    def part_envs(self, p: int):
+        """Env indices of part p (device int64 tensor; fixed for the lifetime of the env)."""
+        return self._part_envs[p]
+
+    def step_async(self, actions, inputs_ready: bool = False):
+        """
+        One env step of the whole batch as `parts` launches, part p on part_stream(p); returns at once, nothing joins the
+        streams: part p's results (reward / status entries of part_envs(p), its env slots) are complete behind
+        part_stream(p) -- wait(p) makes the caller's stream wait for them.  Same results as step(), bit for bit.
+        actions: [B, 3] float64 DEVICE tensor.  inputs_ready=False: the part streams first wait for the caller's stream at
+        this point (actions written on it are seen); True: the caller vouches that actions[part_envs(p)] are complete for
+        part_stream(p) (written on that stream, or synchronised earlier): no event at all.
+        """
+        torch = self.torch
+        if self.parts <= 1:
+            raise RuntimeError("step_async needs VecIPPEnv(parts > 1, stagger=True) on a fused-step engine")
+        if not (self._fused_reset or self._reset_ids_by_phase is None):
+            raise RuntimeError("step_async needs the scheduled resets inside the step launch (fused_reset)")
+        a = actions if (torch.is_tensor(actions) and actions.dtype == torch.float64 and actions.is_cuda and actions.is_contiguous()) \
+            else self.engine._dev(actions, torch.float64).reshape(-1, 3).contiguous()
+        main = torch.cuda.current_stream(self.device)
+        streams = self._part_streams
+        if not inputs_ready or self._main_dirty:
+            self._main_dirty = False
+            self._ev_inputs.record(main)
+            for st in streams:
+                st.wait_event(self._ev_inputs)
+        scheduled = None
+        blk = None
+        if self._reset_ids_by_phase is not None:
+            K = self._blk_K
+            b, j = divmod(self.t, K)
+            set_ = b % 2
+            if self._blk_tag[set_] != b:
+                self._stage_block(b)
+                self._blk_waited = -1
+            if self._blk_waited != b:
+                for st in streams:
+                    st.wait_event(self._blk_ready[set_])
+                self._blk_waited = b
+            if self._blk_tag[1 - set_] != b + 1 and 2 * K <= self.episode_steps:
+                self._stage_block(b + 1)
+            p = self._phase_ending_at(self.t)
+            n = int(self._reset_ids_by_phase[p].numel())
+            scheduled = (p, set_ * K + j, n) if n > 0 else None
+            blk = (set_, j == K - 1)
+        nz = self._noise_plane_parts(main, streams)
+        fused = {}
+        if scheduled is not None:
+            p, k, n = scheduled
+            fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
+            if self.shuffle_prior_cov:
+                self.engine.set_reset_prior(self._prior_scale_scheduled(p))
+        self.engine.set_item_order(self._orders_parts[self.t % self.episode_steps])
+        self.engine.step_parts(a, self.prev, nz, self._flags | _ffi.IPP_UPDATE_PREV, self.reward, self.status, self._part_begin, streams, **fused)
+        if scheduled is not None:
+            self.episode[self._reset_ids_host[scheduled[0]]] += 1
+        self._noise_done_parts(streams)
+        self.t += 1
+        if blk is not None and blk[1]:
+            for q, st in enumerate(streams):
+                self._blk_free[blk[0]][q].record(st)
+        self._async_pending = True
+
+    def _noise_plane_parts(self, main, streams):
+        """Measurement noise of this step on a partitioned batch: plane `pos` of ring (fill index % 2); the other ring is
+        refilled on the caller's stream one ring ahead.  streams: the part streams that will read it (None: the caller's).
+        Same planes as the single ring of parts == 1 (plane p of fill f = step f * NOISE_RING + p)."""
+        pos = self._noise_pos
+        if pos == 0:
+            f = self._ring_cur = self._noise_fills
+            self._noise_fills += 1
+            r = f % 2
+            for want, ring in ((f, r), (f + 1, 1 - r)):
+                if self._ring_filled[ring] != want:
+                    for ev in self._ring_free[ring]:  # (recorded behind the last step that read this ring)
+                        main.wait_event(ev)
+                    self.engine.normal_rows(self._noise_rings[ring], self.engine.meas_cap, self.seed,
+                                            self.NOISE_STREAM + want * self.NOISE_RING, row_offset=self.env_id_offset)
+                    self._ring_ready[ring].record(main)
+                    self._ring_filled[ring] = want
+            if streams is not None:
+                for st in streams:
+                    st.wait_event(self._ring_ready[r])
+        return self._noise_rings[self._ring_cur % 2][pos]
+
+    def _noise_done_parts(self, streams):
+        self._noise_pos = (self._noise_pos + 1) % self.NOISE_RING
+        if self._noise_pos == 0:
+            main = self.torch.cuda.current_stream(self.device)
+            for q in range(self.parts):
+                self._ring_free[self._ring_cur % 2][q].record(streams[q] if streams is not None else main)
+
+    def wait(self, part: Optional[int] = None):
+        """The caller's (current) stream waits for everything issued on part_stream(part) (all parts when None)."""
+        if self.parts <= 1 or not self._async_pending:
+            return
+        main = self.torch.cuda.current_stream(self.device)
+        for q in (range(self.parts) if part is None else [part]):
+            self._part_done[q].record(self._part_streams[q])
+            main.wait_event(self._part_done[q])
+        if part is None:
+            self._async_pending = False
 
     # ------------------------------------------------------------------ views
     def mean(self, env):
+        self.wait()
         return self.engine.read_mean(env)
 
     def diag(self, env):
+        self.wait()
         return self.engine.read_diag(env)
 
     def ground_truth(self, env):
+        self.wait()
         return self.engine.read_gt(env)
 
     def covariance(self, env):
+        self.wait()
         return self.engine.read_cov(env)
 
     def metrics(self, env_ids=None):
+        self.wait()
         return self.engine.metrics(env_ids=env_ids)
