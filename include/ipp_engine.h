@@ -444,7 +444,10 @@ int ipp_fill_normal(void* engine, float* out /*[dev]*/, uint64_t count, uint64_t
 int ipp_fill_normal_rows(void* engine, float* out /*[dev]*/, int32_t planes, int32_t rows, int32_t row_len,
                          const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence, void* stream);
 
-/* Copy the prologue record of item `idx` of the most recent ipp_step to the host (synchronises). */
+/* Copy the prologue record of item `idx` of the most recent ipp_step to the host (synchronises).  The fp64 copies of S, L^-1, z
+ * and y are written by the step only after ipp_debug_capture(engine, 1) (they cost 1.4 KB of stores per item); footprint, m, cost
+ * and status are always there. */
+int ipp_debug_capture(void* engine, int32_t enable);
 int ipp_debug_step_item(void* engine, int32_t idx, ipp_step_item* out /*[host]*/, void* stream);
 
 /* Average duration [ms] of the streaming kernels of ipp_step launched since the last call with
@@ -465,6 +468,10 @@ int ipp_streamed_bytes(void* engine, uint64_t* bytes /*[host]*/, int32_t reset, 
  * `bytes` follows.  mask_reread_bytes may be NULL.  Synchronises. */
 int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes /*[host]*/, uint64_t* mask_reread_bytes /*[host]*/, int32_t reset,
                               void* stream);
+/* Patch-layout engines, belonging to the last ipp_streamed_bytes(_detail) read: the same count with every stored row taken only on
+ * the cells INSIDE that column's own rectangle (the lanes outside are masked requests that fetch nothing) -- the bytes that have
+ * to move, a lower bound of `bytes` (which charges a stored row on every cell of the unit that meets it).  0 for other engines. */
+int ipp_streamed_bytes_needed(void* engine, uint64_t* bytes /*[host]*/);
 
 #ifdef __cplusplus
 }

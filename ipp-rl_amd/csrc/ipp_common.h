@@ -42,6 +42,7 @@ __device__ unsigned long long g_wphase[16];
 // perturbation small -- e.g. 0x1c6: stream = interval 2)
 #define IPP_WT(k) do { if ((IPP_WAVE_CLOCKS >> (k)) & 1) { const unsigned long long n_ = clock64(); wt_[k] += n_ - wt_last_; wt_last_ = n_; } } while (0)
 #define IPP_WT_COUNT(k, n) do { wt_[k] += (n); } while (0)
+#define IPP_WT_RESET do { wt_last_ = clock64(); } while (0)
 #define IPP_WT_FLUSH(lane) do { if ((lane) == 0) for (int q_ = 0; q_ < 12; ++q_) if (wt_[q_]) atomicAdd(&g_wphase[q_], wt_[q_]); } while (0)
 #else
 #if !IPP_TIMELINE
@@ -50,6 +51,7 @@ __device__ unsigned long long g_wphase[16];
 #define IPP_WT_DECL ((void)0)
 #define IPP_WT(k) ((void)0)
 #define IPP_WT_COUNT(k, n) ((void)0)
+#define IPP_WT_RESET ((void)0)
 #define IPP_WT_FLUSH(lane) ((void)0)
 #endif
 
@@ -193,6 +195,9 @@ struct View {
     // 5 % (one counter) / 19 % (two) of the fused step kernel: the waves' exits queued up behind same-address atomics.
     // (slot 0, words 1..7: debug phase timing)
     unsigned long long* counters;
+    // patch kernels: per ITEM [max_batch][2] = (streamed floats, floats on the lanes inside the stored columns' rectangles), plain
+    // read-add-write by the item's last wave (an item index belongs to one workgroup per launch: no atomics, no shared line)
+    unsigned long long* item_counts;
     int* tickets;    // [kTicketSlots] item ticket counters of the pipelined step kernel, one per launch in flight (k_step_pipe.h)
     float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]
     uint64_t cov_slot;  // floats per env slot
@@ -204,6 +209,7 @@ struct View {
     float* wc;       // dense: [max_batch][MC][Npad]
     double* partial; // [max_batch][n_tiles]
     double* dbg;     // [max_batch][2*MC*MC + 2*MC]   S, Linv, z, y in fp64 (tests)
+    int dbg_capture; // the wave-level m x m algebra (solve_wave_fast: fused / patch / tree kernels) fills dbg only when set (ipp_debug_capture)
     double* grf_h;   // [H][W] circular-convolution kernel of the GRF
     double2* grf_cs; // [W] (cos, sin)(2 pi j / W)          (k_grf_dft.h)
     double* grf_g;   // [H/2+1][W] column-convolution kernels  (k_grf_dft.h)

@@ -105,6 +105,7 @@ struct Engine {
     hipEvent_t ev_prep[8] = {};
     ProfSlot prof[3];
     int last_n = 0;
+    uint64_t last_needed_bytes = 0;  // of the last ipp_streamed_bytes(_detail) read
 };
 
 struct Layout {
@@ -112,7 +113,7 @@ struct Layout {
     bool patch;
     int patch_waves;
     PatchGeo pg;
-    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
+    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_icnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
         off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfhp, off_grfamp, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
 };
 
@@ -257,6 +258,7 @@ int plan(const ipp_config& c, Layout& L) {
     L.off_rank = o; o += up(cap * 4);
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(2 * cap * (uint64_t)c.rank_cap * 4) : 0;  // tile spans, then rectangles
     L.off_cnt = o; o += up((uint64_t)kCountSlots * 128);
+    L.off_icnt = o; o += up((uint64_t)c.max_batch * 16);
     L.off_tick = o; o += up((uint64_t)kTicketSlots * 4);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
@@ -712,7 +714,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.rank = reinterpret_cast<int*>(base + L.off_rank);
     v.colspan = reinterpret_cast<int*>(base + L.off_span);
     v.colrect = v.colspan + (size_t)cfg->capacity * cfg->rank_cap;
+    v.dbg_capture = 0;
     v.counters = reinterpret_cast<unsigned long long*>(base + L.off_cnt);
+    v.item_counts = reinterpret_cast<unsigned long long*>(base + L.off_icnt);
     v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
     v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
@@ -1586,6 +1590,14 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
     HIP_TRY(hipStreamSynchronize(s));
     uint64_t units = 0, extra = 0;
     for (int k = 0; k < kCountSlots; ++k) { units += cnt[16 * k]; extra += cnt[16 * k + 8]; }
+    {  // patch kernels: per-item totals
+        std::vector<unsigned long long> ic((size_t)2 * e->v.max_batch);
+        HIP_TRY(hipMemcpyAsync(ic.data(), e->v.item_counts, ic.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        uint64_t needed = 0;
+        for (size_t i = 0; i < ic.size(); i += 2) { units += ic[i]; needed += ic[i + 1]; }
+        e->last_needed_bytes = needed * 4;
+    }
     *bytes = units * 4;
     if (mask_reread_bytes) *mask_reread_bytes = extra * 4;
 #if IPP_PHASE_TIMING
@@ -1615,7 +1627,24 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_wphase), wp, sizeof wp));
     }
 #endif
-    if (reset) HIP_TRY(hipMemsetAsync(e->v.counters, 0, (size_t)kCountSlots * 128, s));
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(e->v.counters, 0, (size_t)kCountSlots * 128, s));
+        HIP_TRY(hipMemsetAsync(e->v.item_counts, 0, (size_t)e->v.max_batch * 16, s));
+    }
+    return 0;
+}
+
+int ipp_debug_capture(void* engine, int32_t enable) {
+    Engine* e = as_engine(engine);
+    if (!e) return fail(-1, "null engine");
+    e->v.dbg_capture = enable != 0;
+    return 0;
+}
+
+int ipp_streamed_bytes_needed(void* engine, uint64_t* bytes) {
+    Engine* e = as_engine(engine);
+    if (!e || !bytes) return fail(-1, "null argument");
+    *bytes = e->last_needed_bytes;
     return 0;
 }
 

@@ -988,7 +988,8 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
     double c[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) c[k] = (lane < m && k < m) ? S[min(lane, MC - 1) * LD + k] : ((k == lane) ? 1.0 : 0.0);
-    if (lane < MC) {  // debug copy of S (tests read it through ipp_debug_step_item)
+    const bool capture = v.dbg_capture != 0;  // (1.4 KB of fp64 stores per item: 6 MB per launch of the headline batch -- only on request)
+    if (capture && lane < MC) {  // debug copy of S (tests read it through ipp_debug_step_item)
 #pragma unroll
         for (int k = 0; k < MC; ++k) dbg[lane * MC + k] = (lane < m && k < m) ? c[k] : 0.0;
     }
@@ -1054,12 +1055,14 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         for (int i = 0; i < MC; ++i) {
             const double val = (!dead && i < m && lane < m) ? li[i] : 0.0;
             linv_f[i * MC + lane] = (float)val;
-            dbg[MC * MC + i * MC + lane] = val;
+            if (capture) dbg[MC * MC + i * MC + lane] = val;
         }
         const double yval = (!dead && !cov_only && lane < m) ? yv : 0.0;
         y_f[lane] = (float)yval;
-        dbg[2 * MC * MC + lane] = (lane < m) ? zz[lane] : 0.0;
-        dbg[2 * MC * MC + MC + lane] = yval;
+        if (capture) {
+            dbg[2 * MC * MC + lane] = (lane < m) ? zz[lane] : 0.0;
+            dbg[2 * MC * MC + MC + lane] = yval;
+        }
     }
     if (lane == 0) {
         ItemHdr ho = h;

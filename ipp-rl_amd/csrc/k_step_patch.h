@@ -105,6 +105,57 @@ struct PatchLds {
     }
 };
 
+}  // namespace ipp
+#include "k_patch_units.h"
+namespace ipp {
+
+// Io policy of the env step for patch_units: pre-step mean / variance from the env's planes, stored rows through the item's
+// single buffer resource (patch offset = scalar offset), results into the env's planes and the next m patches of its slot.
+struct StepIo {
+    static constexpr bool kMean = true;
+    typedef float rowv __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t row_rs;
+    float* mean_rw;
+    float* diag_rw;
+    bool cov_only;
+    int m, row0_bytes, pstride_bytes;
+    __device__ __forceinline__ rowv row_load(unsigned cofs, unsigned voff) const {
+        // one resource for the whole item, the patch offset as the request's scalar offset (a resource per row was four
+        // scalar instructions per row)
+        return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(row_rs, voff, (int)cofs, IPP_PATCH_AUX));  // (aux 2: nt)
+    }
+    __device__ __forceinline__ void load_pre(int cell0, int flat, int rrow, int rcol, float (&md)[2][2]) const {
+        if (IPP_PATCH_ABLATE & 128) { md[0][0] = md[0][1] = 0.5f; md[1][0] = md[1][1] = 1.f; }
+        else { load_vec<2>(mean_rw + cell0, md[0]); load_vec<2>(diag_rw + cell0, md[1]); }
+    }
+    __device__ __forceinline__ void store(bool commit, bool lane_valid, int cell0, int flat, unsigned flat4, const float (&acc)[2][9],
+                                          const float (&md)[2][2], const float (&dred)[2], const float (&dmean)[2]) const {
+        if (!commit || ((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) return;
+        if (lane_valid) {
+            float outv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) outv[c] = md[1][c] - dred[c];
+            store_vec<2>(diag_rw + cell0, outv);
+            if (!cov_only) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) outv[c] = md[0][c] + dmean[c];
+                store_vec<2>(mean_rw + cell0, outv);
+            }
+        }
+        // the m new rows (buffer stores through the item's resource: the row as scalar offset, lanes outside the rectangle out of
+        // range -- no 64-bit address per lane and row)
+        typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(row_rs, 0, 0, 0)) raw2;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j < m) {
+                rowv t;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) t[c] = acc[c][j];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, lane_valid ? flat4 : 0xffffffffu, row0_bytes + j * pstride_bytes, IPP_NT_STORES ? 2 : 0);
+            }
+    }
+};
+
 template <bool ONE>
 __device__ __forceinline__ void patch_sync() {
     if (ONE) wave_lds_sync(); else __syncthreads();
@@ -421,278 +472,44 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
     // v_readlane: no LDS round trip per stored row)
     const int n_fast = min(n_lds, 2 * kWave);
-    int mcofs[2];
-    unsigned mlo[2], mex[2];
+    unsigned mcofs[2], mlo[2], mex[2];
 #pragma unroll
     for (int p2 = 0; p2 < 2; ++p2) {
         const int a = p2 * kWave + lane;
-        mcofs[p2] = 0; mlo[p2] = 0x0000ffffu; mex[p2] = 0u;  // (empty rectangle)
+        mcofs[p2] = 0u; mlo[p2] = 0x0000ffffu; mex[p2] = 0u;  // (empty rectangle)
         if (a < n_fast) {
             const float4 mt = *reinterpret_cast<const float4*>(lds.rec + (size_t)a * kPatchRec + 12);
-            mcofs[p2] = __float_as_int(mt.x); mlo[p2] = __float_as_uint(mt.y); mex[p2] = __float_as_uint(mt.z);
+            mcofs[p2] = __float_as_uint(mt.x); mlo[p2] = __float_as_uint(mt.y); mex[p2] = __float_as_uint(mt.z);
         }
     }
 
-    // ------------------------------------------------------------------ units of the new patch: 64 lanes x 2 consecutive cells
-    const float* Ls = lds.Ls; const float* ys = lds.ys; const float* lut = lds.lut;
-    const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
-    unsigned short* ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
-    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
-    const int n_units = (hn * pw + 2 * kWave - 1) / (2 * kWave);
-    const int lw = v.plw;
-    unsigned long long units = 0;
-    bool solved = false, dead = false;
+    // ------------------------------------------------------------------ units of the new patch (k_patch_units.h)
+    const bool commit_u = h.commit != 0;
     const int env_u = h.env;
-    const bool rf1 = (h.rf == 1), commit_u = h.commit != 0;
-    float* mean_rw = v.mean + (size_t)env_u * v.Npad;
-    float* diag_rw = v.diag + (size_t)env_u * v.Npad;
-    typedef float rowv __attribute__((ext_vector_type(VEC)));
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-    for (;;) {
-        int u = 0;
-        if (lane == 0) u = atomicAdd(next_unit, 1);
-        u = __builtin_amdgcn_readfirstlane(u);
-        if (u >= n_units) break;
-        const int flat = 2 * (u * kWave + lane);
-        const int prow = (int)(((unsigned)flat * (unsigned)v.pdiv) >> kPatchDivShift), pcol = flat - prow * pw;
-        const bool lane_valid = prow < hn && pcol < wn;
-        const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
-        const int cell0 = rrow * v.W + rcol;  // (clamped for the masked lanes: any valid address)
-        const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> kPatchDivShift);
-        const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> kPatchDivShift));
-        const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
-        const unsigned flat4 = lane_valid ? (unsigned)flat * 4u : 0xffffffffu;  // byte offset of the lane's cells in a (shifted) patch; masked lanes out of range
-
-        // ---- ordered compaction of the records whose rectangle meets the rows of this unit (lane a <-> record a; the
-        // rectangles of the first 128 records sit in this lane's registers)
-        int nact = 0, nact_fast = 0, first_a = 0;
-        for (int a0 = 0; a0 < n_c; a0 += kWave) {
-            const int a = a0 + lane;
-            bool on = false;
-            if (a < n_c) {
-                unsigned lo, ex;
-                if (a < n_fast) { lo = (a0 == 0) ? mlo[0] : mlo[1]; ex = (a0 == 0) ? mex[0] : mex[1]; }
-                else if (a < cap) { lo = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 13]); ex = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 14]); }
-                else { lo = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 13]); ex = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 14]); }
-                const int r0k = lo & 0xffff, r1k = r0k + (int)(ex & 0xffff);
-                on = (IPP_PATCH_ABLATE & 64) ? true : (r1k >= urow0 && r0k <= urow1);
-            }
-            const unsigned long long mask = __ballot(on);
-            if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)a;
-            if (nact == 0 && mask) first_a = a0 + (int)__builtin_ctzll(mask);  // (first list entry, for the padding below)
-            nact += __popcll(mask);
-            if (a0 < n_fast) nact_fast += __popcll(mask & ((a0 + kWave <= n_fast) ? ~0ull : ((1ull << (n_fast - a0)) - 1ull)));
-        }
-        // group tail: entries past nact repeat the first active record with their requests masked off (0 * finite = 0)
-        if (nact > 0 && lane < KP) ridx[nact + lane] = (unsigned short)first_a;
-        __builtin_amdgcn_wave_barrier();
-        IPP_WT(0);
-
-        // ---- base term from the analytic prior: acc[.][b] = sum_{f in block b} w_f P0[cell, F_f]  (Wc L, L^-1 in the epilogue)
-        float acc[VEC][MC];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c)
-#pragma unroll
-            for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
-        {
-            typedef float __attribute__((address_space(3))) lds_float;
-            const unsigned lut_b = (unsigned)(size_t)(const lds_float*)lut, lw4 = 4u * (unsigned)lw, rcol4 = 4u * (unsigned)rcol;
-            auto base_term = [&](auto nfc_tag) {
-                constexpr int NFC = decltype(nfc_tag)::value;
-#pragma unroll
-                for (int b = 0; b < MC; ++b) {
-                    if (b < m) {
-                        float cb[VEC];
-#pragma unroll
-                        for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
-#pragma unroll
-                        for (int a = 0; a < NFC; ++a) {
-                            const int yx = fb_yx[4 * b + a];
-                            const float wa = fb_w[4 * b + a];
-                            // lut[|rrow - fy| * lw + |rcol + c - fx|] with the LDS byte address out of two v_sad_u32
-                            // (|a - b| + c) and one multiply-add (the abs / multiply / shift form was 17 instructions per cell
-                            // pair, a tenth of the kernel)
-                            const unsigned fy = (unsigned)(yx & 0xffff), fx4 = (unsigned)(yx >> 16) * 4u;
-                            const unsigned row_b = __umul24(__usad((unsigned)rrow, fy, 0u), lw4) + lut_b;
-#pragma unroll
-                            for (int c = 0; c < VEC; ++c) {
-                                const unsigned addr = __usad(rcol4 + 4u * c, fx4, row_b);
-                                cb[c] = fmaf(wa, *reinterpret_cast<const lds_float*>((size_t)addr), cb[c]);
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
-                    }
-                }
-            };
-            if (IPP_PATCH_ABLATE & 4) { acc[0][0] = (float)rrow; acc[1][0] = (float)rcol; }
-            else if (rf1) base_term(std::integral_constant<int, 1>{});
-            else base_term(std::integral_constant<int, 4>{});
-        }
-
-        IPP_WT(1);
-        // ---- stream the stored rows: acc += patch_k[flat + shift_k] * (-HT[k,:])
-        // FAST: every record of the group is one of the first 128 and lies in one 64-record page: its patch offset and rectangle
-        // come out of this wave's registers through v_readlane with the record index as the (scalar) lane select, -HT from the
-        // LDS record.  Else (more than 128 contributing columns, or records in the global overflow block): generic pointers.
-        // N rows per group: whole groups of KP without the "row exists" test, the remainder of a unit in a group of 2, 4 or KP
-        // rows (a fixed KP wasted 3.5 masked rows per unit on average, ~26 instructions each)
-        auto group = [&](int a0, auto fast_tag, auto n_tag, auto full_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value, FULL = decltype(full_tag)::value;
-            constexpr int N = decltype(n_tag)::value;
-            const int ev = ridx[a0 + min(lane, N - 1)];  // (lane i < N holds the i-th record of the group)
-            rowv uu[N];
-            int es[N];
-            const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
-            const int pc = page ? mcofs[1] : mcofs[0];
-            const unsigned pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int e = __builtin_amdgcn_readlane(ev, i);
-                es[i] = e;
-                int cofs;
-                unsigned lo, ex;
-                if (FAST) {
-                    cofs = __builtin_amdgcn_readlane(pc, e & 63);
-                    lo = (unsigned)__builtin_amdgcn_readlane((int)pl_, e & 63);
-                    ex = (unsigned)__builtin_amdgcn_readlane((int)pe, e & 63);
-                } else {
-                    const float* rp = (e < cap) ? (const float*)(lds.rec + (size_t)e * kPatchRec) : (const float*)(ovf + (size_t)(e - cap) * kPatchRec);
-                    const float4 mt = *reinterpret_cast<const float4*>(rp + 12);
-                    cofs = __builtin_amdgcn_readfirstlane(__float_as_int(mt.x));
-                    lo = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.y));
-                    ex = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.z));
-                }
-                const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
-                // (bitwise: a short-circuit && on the lane's validity wrapped every row in an exec-mask region)
-                const bool ok = (IPP_PATCH_ABLATE & 256) ? (FULL || a0 + i < nact) : (bool)((int)(FULL || a0 + i < nact) &
-                                (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d)));
-                // one resource for the whole item, the patch offset as the request's scalar offset (a resource per row was four
-                // scalar instructions per row)
-                if (IPP_PATCH_ABLATE & 1) uu[i] = (rowv)(__int_as_float(cofs) * 1e-30f + (ok ? 1.f : 0.f));
-                else uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(row_rs, ok ? flat4 : 0xffffffffu, cofs, IPP_PATCH_AUX));  // (aux 2: nt)
-            }
-            // -HT of the group's rows, value l & 15 in lane l (read while the requests are in flight)
-            float qr[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
-                qr[i] = rp[lane & 15];
-            }
-            __builtin_amdgcn_sched_barrier(0);  // all N requests leave before the first wait
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                if (IPP_PATCH_ABLATE & 16) { acc[0][0] = fmaf(uu[i][0], qr[i], acc[0][0]); acc[1][0] = fmaf(uu[i][1], qr[i], acc[1][0]); continue; }
-                const float ur[VEC] = {uu[i][0], uu[i][1]};
-                fmac_row<VEC, MC>(acc, qr[i], ur);
-            }
-        };
-        // (list positions < nact_fast hold records < n_fast, in increasing order; a fast group lies in one 64-record page)
-        auto is_fast = [&](int a0, int last) {
-            return __builtin_amdgcn_readfirstlane((int)(last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6))) != 0;
-        };
-        typedef std::integral_constant<int, KP> n_kp;
-        int a0 = 0;
-        for (; a0 + KP <= nact; a0 += KP) {
-            if (is_fast(a0, a0 + KP - 1)) group(a0, std::true_type{}, n_kp{}, std::true_type{});
-            else group(a0, std::false_type{}, n_kp{}, std::false_type{});
-        }
-        const int rem = nact - a0;
-        if (rem > 0) {
-            if (!is_fast(a0, nact - 1)) group(a0, std::false_type{}, n_kp{}, std::false_type{});
-            else if (KP > 4 && rem > 4) group(a0, std::true_type{}, n_kp{}, std::false_type{});
-            else if (rem > 2) group(a0, std::true_type{}, std::integral_constant<int, 4>{}, std::false_type{});
-            else group(a0, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{});
-        }
-
-        IPP_WT(2);
-        IPP_WT_COUNT(9, (nact + KP - 1) / KP);
-        IPP_WT_COUNT(10, 1);
-        // pre-step mean and variance of the unit's cells (read behind the row stream: held across it, the four values were spilled
-        // to scratch, per unit and wave; the L^-1 FMAs below cover the round trip)
-        float md_in[2][VEC];
-        if (IPP_PATCH_ABLATE & 128) { md_in[0][0] = md_in[0][1] = 0.5f; md_in[1][0] = md_in[1][1] = 1.f; }
-        else { load_vec<VEC>(mean_rw + cell0, md_in[0]); load_vec<VEC>(diag_rw + cell0, md_in[1]); }
-        // ---- wait (first unit only) for L^-1 and y, then Wc = (P[:,F] H_F^T) L^-1 in place (column j needs the entries b <= j)
-        if (!solved) {
-            while (__hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
-            solved = true;
-            dead = __hip_atomic_load(solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
-        }
-        IPP_WT(3);
-        // L^-1 row b in the lanes of lrow[b], y in the lanes of yreg: ten LDS reads in flight together, the 90 + 18 FMAs take their
-        // coefficients through the DPP row broadcast (45 + 9 dependent broadcast reads before)
-        float lrow[MC], yreg;
-#pragma unroll
-        for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
-        yreg = ys[min(lane & 15, MC - 1)];
-        if (!(IPP_PATCH_ABLATE & 8)) {
-            linv_col<8>(acc, lrow); linv_col<7>(acc, lrow); linv_col<6>(acc, lrow); linv_col<5>(acc, lrow); linv_col<4>(acc, lrow);
-            linv_col<3>(acc, lrow); linv_col<2>(acc, lrow); linv_col<1>(acc, lrow); linv_col<0>(acc, lrow);
-        }
-        const bool commit = commit_u && !dead;
-
-        // ---- epilogue: masked trace reduction, diag -= |Wc_i|^2, mean += Wc_i y, append the m new rows
-        float dred[VEC], dmean[VEC];
-        double part = 0.0;
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            float w2 = 0.f, dm = 0.f;
-#pragma unroll
-            for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
-            dm = dot_lanes<MC>(acc[c], yreg);
-            // (lanes outside the rectangle: their new-row values land in the padding columns of the patch, which no reader
-            // looks at -- finite values of clamped cells, not worth 18 selects per unit)
-            if (!lane_valid) { w2 = 0.f; dm = 0.f; }
-            dred[c] = w2;
-            dmean[c] = dm;
-            // rewards.py:11 mask from the pre-step mean and pre-step diag(P); rewards.py:23-30 trace reduction
-            const bool in_mask = !adaptive || ((double)md_in[0][c] + v.kf * (double)md_in[1][c] >= v.thr);
-            if (lane_valid && in_mask) part += (double)w2;
-        }
-        part = wave_sum_dpp(part);
-        if (lane == 0) lds.unit_red[u] = part;
-        const int in_cells = __popcll(__ballot(lane_valid)) * VEC;
-        // (stored rows + m new rows + mean and diag read and written) floats per touched cell
-        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells;
-        IPP_WT(4);
-        if (commit && lane_valid && !((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) {
-            float outv[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) outv[c] = md_in[1][c] - dred[c];
-            store_vec<VEC>(diag_rw + cell0, outv);
-            if (!cov_only) {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) outv[c] = md_in[0][c] + dmean[c];
-                store_vec<VEC>(mean_rw + cell0, outv);
-            }
-        }
-        // the m new rows: every lane of the patch's rows stores (the padding columns pcol >= wn get values of clamped cells that no reader looks
-        // at): whole 512-byte runs instead of row segments with holes, i.e. no partially written sectors
-        // (buffer stores through the item's resource: the row as scalar offset, lanes outside the patch's rows out of range --
-        // no 64-bit address per lane and row)
-        if (commit && !((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) {
-            typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(row_rs, 0, 0, 0)) raw2;
-            const unsigned so = (prow < hn) ? (unsigned)flat * 4u : 0xffffffffu;
-#pragma unroll
-            for (int j = 0; j < MC; ++j)
-                if (j < m) {
-                    rowv t;
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) t[c] = acc[c][j];
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, so, (r + j + 1) * v.pstride * 4, IPP_NT_STORES ? 2 : 0);
-                }
-        }
-        __builtin_amdgcn_wave_barrier();
-        IPP_WT(5);
-    }
-    IPP_WT(0);
+    const UnitGeo ug = unit_geometry(r0n, c0n, hn, wn, pw);
+    const int n_units = ug.n_units;
+    StepIo io;
+    io.row_rs = row_rs;
+    io.mean_rw = v.mean + (size_t)env_u * v.Npad;
+    io.diag_rw = v.diag + (size_t)env_u * v.Npad;
+    io.cov_only = cov_only;
+    io.m = m;
+    io.row0_bytes = (r + 1) * v.pstride * 4;  // first new row, from one patch in front of the slot (row_rs)
+    io.pstride_bytes = v.pstride * 4;
+    UnitArgs ua;
+    ua.m = m; ua.rf1 = (h.rf == 1); ua.adaptive = (flags & IPP_ADAPTIVE) != 0; ua.commit_u = commit_u;
+    ua.n_c = n_c; ua.n_fast = n_fast; ua.cap = cap; ua.ovf = ovf;
+    ua.next_unit = next_unit; ua.solve_flag = solve_flag;
+    ua.ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
+    unsigned long long units = 0, needed = 0;
+    bool dead = false;
+    patch_units<KP>(v, lds, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
+    IPP_WT_RESET;
     IPP_WT_COUNT(11, 1);
 
     // ------------------------------------------------------------------ per-item results (last wave to arrive)
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds.red);
-    if (lane == 0 && units) atomicAdd(cnt, units);
+    if (lane == 0 && units) { atomicAdd(cnt, units); atomicAdd(cnt + 1, needed); }
     int reset_k = -1;
     if (ar.src) reset_k = __builtin_amdgcn_readfirstlane(ar.src[item]);
     // this wave's stores have landed before the last wave rewrites the env's planes (explicit wait, not an agent-scope
@@ -715,8 +532,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         for (int t = 0; t < n_units; ++t) tot += lds.unit_red[t];  // unit order: bit-reproducible whatever wave took which unit
         reward_out[item] = dead ? NAN : (float)(tot / (cost_d + 1.0));  // rewards.py:31
         if (commit_item) v.rank[env_u] = r + m;
-        unsigned long long* slotc = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
-        if (cnt[0]) atomicAdd(slotc, cnt[0]);
+        if (cnt[0]) {  // (per-item totals, read-add-write: this workgroup is the only one of the launch that owns the item index)
+            unsigned long long* ic = v.item_counts + 2 * (size_t)item;
+            ic[0] += cnt[0];
+            ic[1] += cnt[1];
+        }
     }
     if (commit_item && lane < m) {
         v.colspan[(size_t)env_u * v.rank_cap + r + lane] = t_span;

@@ -508,6 +508,10 @@ class IPPEngine:
         self._keep_rows = ids
         return out
 
+    def debug_capture(self, enable: bool = True):
+        """The steps that follow keep fp64 copies of S, L^-1, z and y per item for debug_item (off by default: 1.4 KB of stores per item)."""
+        _ffi.check(self._lib.ipp_debug_capture(self._h, 1 if enable else 0))
+
     def debug_item(self, idx: int) -> Dict:
         it = _ffi.IppStepItem()
         _ffi.check(self._lib.ipp_debug_step_item(self._h, int(idx), C.byref(it), self.stream))
@@ -531,6 +535,12 @@ class IPPEngine:
         b, x = C.c_uint64(0), C.c_uint64(0)
         _ffi.check(self._lib.ipp_streamed_bytes_detail(self._h, C.byref(b), C.byref(x), 1 if reset else 0, self.stream))
         return int(b.value), int(x.value)
+
+    def streamed_bytes_needed(self) -> int:
+        """Of the last streamed_bytes(_detail) read: the bytes on the lanes inside the stored columns' own rectangles (patch engines)."""
+        b = C.c_uint64(0)
+        _ffi.check(self._lib.ipp_streamed_bytes_needed(self._h, C.byref(b)))
+        return int(b.value)
 
     def profile(self, enable: bool):
         _ffi.check(self._lib.ipp_profile_enable(self._h, 1 if enable else 0))

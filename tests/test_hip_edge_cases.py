@@ -23,6 +23,7 @@ def make(dim_x, dim_y=None, state="factor", capacity=2, res=4.0, **kw):
     dim_y = dim_y or dim_x
     cfg = EngineConfig(x_dim=dim_x, y_dim=dim_y, resolution=res, **kw.pop("cfg", {}))
     eng = IPPEngine(cfg, capacity=capacity, state=state, rank_cap=kw.pop("rank_cap", 512), **kw)
+    eng.debug_capture()  # (S / z of every step for debug_item)
     ocfg = orc.OracleConfig(x_dim=dim_x, y_dim=dim_y, resolution=res, coeff_a=cfg.coeff_a, coeff_b=cfg.coeff_b)
     return eng, ocfg
 

@@ -18,7 +18,9 @@ def engine_for(dim, state, capacity=2, **kw):
     from ipp_rl_amd import EngineConfig, IPPEngine
 
     cfg = EngineConfig(x_dim=dim, y_dim=dim)
-    return IPPEngine(cfg, capacity=capacity, state=state, rank_cap=kw.pop("rank_cap", 384), **kw)
+    eng = IPPEngine(cfg, capacity=capacity, state=state, rank_cap=kw.pop("rank_cap", 384), **kw)
+    eng.debug_capture()  # (S / z of every step for debug_item)
+    return eng
 
 
 def host(t):

@@ -41,6 +41,13 @@ def main():
             gaps.append(s0 - order_e[min(k, len(order_e) - 1)])
         print(f"k-th late start minus k-th end (slot refill delay): mean {np.mean(gaps):.1f} us   p10 {np.percentile(gaps, 10):.1f}  p90 {np.percentile(gaps, 90):.1f}")
     print(f"last workgroup start at {start[ok].max():.1f} us")
+    # the items that end last: where did their time go
+    last = np.argsort(-end)[:12]
+    print(" item   start  phaseA(header gather tables)  algebra_done  first_wave_out  end   [us]")
+    for i in last:
+        sub = [(t[i, k] - t0) / 100.0 for k in (3, 4, 5)] if t[i, 3] > 0 else [0, 0, 0]
+        print(f" {i:5d} {start[i]:7.1f} {mid[i] - start[i]:6.1f} ({sub[0] - start[i]:5.1f} {sub[2] - sub[0]:5.1f} {mid[i] - sub[2]:5.1f}) "
+              f"{(t[i, 7] - t0) / 100.0 - mid[i]:10.1f} {(t[i, 6] - t0) / 100.0:12.1f} {end[i]:7.1f}")
     edges = np.arange(0.0, end[ok].max() + bucket, bucket)
     print(" window[us]  resident  in phase A  streaming")
     for a, b in zip(edges[:-1], edges[1:]):
