@@ -19,6 +19,55 @@ namespace ipp {
 
 constexpr long long kTreePatchGuard = 65536;  // bytes in front of View::cov that the shifted patch offsets may reach into (address math only)
 
+// Io policy of the tree step for patch_units: the ROOT env's mean (rewards.py:11: the map's current mean), the PARENT state's variance
+// (the deepest path node whose rectangle holds the cells -- column bounds are even, a lane's two cells are inside or outside together --
+// else the root's), stored rows through a 64-bit offset from View::cov in 8-byte units (root slots and node blocks are different regions
+// of the arena), results into the NEW node's block: its variance on its rectangle and its m columns.  Covariance only: no mean update.
+struct TreeIo {
+    static constexpr bool kMean = false;
+    typedef float rowv __attribute__((ext_vector_type(2)));
+    const char* base0;
+    const float* mean_ro;
+    const float* diag_root;
+    const float* node_diag;
+    float* new_cols;
+    float* new_diag;
+    unsigned prc[kTreeDepth];
+    int pid[kTreeDepth];
+    int m, pw, pstride;
+    __device__ __forceinline__ rowv row_load(unsigned cofs8, unsigned voff) const {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0) + ((unsigned long long)cofs8 << 3), 0, 0x7ffffff0, 0x00020000);
+        return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, IPP_PATCH_AUX));
+    }
+    __device__ __forceinline__ void load_pre(int cell0, int flat, int rrow, int rcol, float (&md)[2][2]) const {
+        load_vec<2>(mean_ro + cell0, md[0]);
+        const float* src = diag_root + cell0;
+#pragma unroll
+        for (int d = 0; d < kTreeDepth; ++d) {
+            const unsigned rc = prc[d];
+            const int r0d = rc & 0xff, r1d = (rc >> 8) & 0xff, c0d = (rc >> 16) & 0xff, c1d = rc >> 24;
+            if (rrow >= r0d && rrow <= r1d && rcol >= c0d && rcol <= c1d)
+                src = node_diag + (size_t)pid[d] * pstride + (rrow - r0d) * pw + (rcol - c0d);
+        }
+        load_vec<2>(src, md[1]);
+    }
+    __device__ __forceinline__ void store(bool commit, bool lane_valid, int cell0, int flat, unsigned flat4, const float (&acc)[2][9],
+                                          const float (&md)[2][2], const float (&dred)[2], const float (&dmean)[2]) const {
+        if (!commit || !lane_valid) return;
+        float outv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) outv[c] = md[1][c] - dred[c];
+        store_vec<2>(new_diag + flat, outv);
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j < m) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) outv[c] = acc[c][j];
+                store_stream<2>(new_cols + (size_t)j * pstride + flat, outv);
+            }
+    }
+};
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
@@ -150,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, bb.count() - 1);
             const int ly = bb.y0 + blk_dy(aa, bb.bw), lx = bb.x0 + blk_dx(aa, bb.bw);
-            lds.fb_yx[4 * tid + a] = ((h.yu + ly) << 16) | (h.xl + lx);
+            lds.fb_yx[4 * tid + a] = (h.yu + ly) | ((h.xl + lx) << 16);  // grid row | grid column << 16 (k_step_patch.h)
             lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
             if (tid < m) pl.bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
         }
@@ -210,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
                 for (int a = 0; a < 4; ++a) {
                     if (a < cnt) {  // wave-uniform
                         const unsigned yx = (unsigned)uni(lds.fb_yx[4 * i + a]);
-                        const unsigned fy = yx >> 16, fx = yx & 0xffffu;
+                        const unsigned fy = yx & 0xffffu, fx = yx >> 16;
                         const bool in = on && fy >= r0k && fy <= r1k && fx >= c0k && fx <= c1k;
                         const float val = in ? patch[(int)(fy * (unsigned)pw + fx)] : patch[on ? (int)(r0k * (unsigned)pw + c0k) : 0];
                         l[i][a] = in ? val : 0.f;
@@ -305,222 +354,32 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
         }
     }
 
-    // ------------------------------------------------------------------ units of the new node's patch
-    const float* Ls = lds.Ls; const float* lut = lds.lut;
-    const int* fb_yx = lds.fb_yx; const float* fb_w = lds.fb_w;
-    unsigned short* ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
-    const bool adaptive = (flags & IPP_ADAPTIVE) != 0;
-    const int n_units = (hn * pw + 2 * kWave - 1) / (2 * kWave);
-    const int lw = v.plw;
-    unsigned long long units = 0;
-    bool solved = false, dead = false;
-    const bool rf1 = (h.rf == 1), commit_u = h.commit != 0 && expand;
-    const float* mean_ro = v.mean + (size_t)root * v.Npad;
-    const float* diag_root = v.diag + (size_t)root * v.Npad;
-    float* new_cols = tv.node_cov + (size_t)max(new_id, 0) * MC * v.pstride;
-    float* new_diag = tv.node_diag + (size_t)max(new_id, 0) * v.pstride;
-    typedef float rowv __attribute__((ext_vector_type(VEC)));
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-    for (;;) {
-        int u = 0;
-        if (lane == 0) u = atomicAdd(next_unit, 1);
-        u = __builtin_amdgcn_readfirstlane(u);
-        if (u >= n_units) break;
-        const int flat = 2 * (u * kWave + lane);
-        const int prow = (int)(((unsigned)flat * (unsigned)v.pdiv) >> kPatchDivShift), pcol = flat - prow * pw;
-        const bool lane_valid = prow < hn && pcol < wn;
-        const int rrow = r0n + min(prow, hn - 1), rcol = c0n + min(pcol, wn - VEC);
-        const int cell0 = rrow * v.W + rcol;
-        // mean of the ROOT env (rewards.py:11: the map's current mean) and the PARENT state's diagonal: the deepest path node
-        // whose rectangle holds the cells (column bounds are even: a lane's two cells are inside or outside together), else the root's
-        float md_in[2][VEC];
-        load_vec<VEC>(mean_ro + cell0, md_in[0]);
-        {
-            const float* src = diag_root + cell0;
+    // ------------------------------------------------------------------ units of the new node's patch (k_patch_units.h)
+    const bool commit_u = h.commit != 0 && expand;
+    const UnitGeo ug = unit_geometry(r0n, c0n, hn, wn, pw);
+    const int n_units = ug.n_units;
+    TreeIo io;
+    io.base0 = base0;
+    io.mean_ro = v.mean + (size_t)root * v.Npad;
+    io.diag_root = v.diag + (size_t)root * v.Npad;
+    io.node_diag = tv.node_diag;
+    io.new_cols = tv.node_cov + (size_t)max(new_id, 0) * MC * v.pstride;
+    io.new_diag = tv.node_diag + (size_t)max(new_id, 0) * v.pstride;
 #pragma unroll
-            for (int d = 0; d < kTreeDepth; ++d) {
-                const unsigned rc = prc[d];
-                const int r0d = rc & 0xff, r1d = (rc >> 8) & 0xff, c0d = (rc >> 16) & 0xff, c1d = rc >> 24;
-                if (rrow >= r0d && rrow <= r1d && rcol >= c0d && rcol <= c1d)
-                    src = tv.node_diag + (size_t)pid[d] * v.pstride + (rrow - r0d) * pw + (rcol - c0d);
-            }
-            load_vec<VEC>(src, md_in[1]);
-        }
-        const int urow0 = r0n + (int)(((unsigned)(u * 2 * kWave) * (unsigned)v.pdiv) >> kPatchDivShift);
-        const int urow1 = r0n + min(hn - 1, (int)(((unsigned)(u * 2 * kWave + 2 * kWave - 1) * (unsigned)v.pdiv) >> kPatchDivShift));
-        const unsigned lpos = (unsigned)rrow | ((unsigned)rcol << 16);
-        const unsigned flat4 = lane_valid ? (unsigned)flat * 4u : 0xffffffffu;
-
-        int nact = 0, nact_fast = 0;
-        for (int a0 = 0; a0 < n_c; a0 += kWave) {
-            const int a = a0 + lane;
-            bool on = false;
-            if (a < n_c) {
-                unsigned lo, ex;
-                if (a < n_fast) { lo = (a0 == 0) ? mlo[0] : mlo[1]; ex = (a0 == 0) ? mex[0] : mex[1]; }
-                else if (a < cap) { lo = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 13]); ex = __float_as_uint(lds.rec[(size_t)a * kPatchRec + 14]); }
-                else { lo = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 13]); ex = __float_as_uint(ovf[(size_t)(a - cap) * kPatchRec + 14]); }
-                const int r0k = lo & 0xffff, r1k = r0k + (int)(ex & 0xffff);
-                on = r1k >= urow0 && r0k <= urow1;
-            }
-            const unsigned long long mask = __ballot(on);
-            if (on) ridx[nact + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)a;
-            nact += __popcll(mask);
-            if (a0 < n_fast) nact_fast += __popcll(mask & ((a0 + kWave <= n_fast) ? ~0ull : ((1ull << (n_fast - a0)) - 1ull)));
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (nact > 0 && lane < KP) ridx[nact + lane] = ridx[0];
-        __builtin_amdgcn_wave_barrier();
-
-        float acc[VEC][MC];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c)
-#pragma unroll
-            for (int j = 0; j < MC; ++j) acc[c][j] = 0.f;
-        {
-            typedef float __attribute__((address_space(3))) lds_float;
-            const unsigned lut_b = (unsigned)(size_t)(const lds_float*)lut, lw4 = 4u * (unsigned)lw, rcol4 = 4u * (unsigned)rcol;
-            auto base_term = [&](auto nfc_tag) {
-                constexpr int NFC = decltype(nfc_tag)::value;
-#pragma unroll
-                for (int b = 0; b < MC; ++b) {
-                    if (b < m) {
-                        float cb[VEC];
-#pragma unroll
-                        for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
-#pragma unroll
-                        for (int a = 0; a < NFC; ++a) {
-                            const int yx = fb_yx[4 * b + a];
-                            const float wa = fb_w[4 * b + a];
-                            // lut[|rrow - fy| * lw + |rcol + c - fx|] with the LDS byte address out of two v_sad_u32
-                            // (|a - b| + c) and one multiply-add (the abs / multiply / shift form was 17 instructions per cell
-                            // pair, a tenth of the kernel)
-                            const unsigned fy = (unsigned)(yx >> 16), fx4 = (unsigned)(yx & 0xffff) * 4u;
-                            const unsigned row_b = __umul24(__usad((unsigned)rrow, fy, 0u), lw4) + lut_b;
-#pragma unroll
-                            for (int c = 0; c < VEC; ++c) {
-                                const unsigned addr = __usad(rcol4 + 4u * c, fx4, row_b);
-                                cb[c] = fmaf(wa, *reinterpret_cast<const lds_float*>((size_t)addr), cb[c]);
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < VEC; ++c) acc[c][b] = cb[c];
-                    }
-                }
-            };
-            if (rf1) base_term(std::integral_constant<int, 1>{});
-            else base_term(std::integral_constant<int, 4>{});
-        }
-
-        // (whole groups of KP rows without the row-exists test, the remainder in a group of 2, 4 or KP rows: k_step_patch.h)
-        auto group = [&](int a0, auto fast_tag, auto n_tag, auto full_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value, FULL = decltype(full_tag)::value;
-            constexpr int N = decltype(n_tag)::value;
-            const int ev = ridx[a0 + min(lane, N - 1)];
-            rowv uu[N];
-            int es[N];
-            const int page = FAST ? (__builtin_amdgcn_readfirstlane(ev) >> 6) : 0;
-            const unsigned pc = page ? mcofs[1] : mcofs[0], pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int e = __builtin_amdgcn_readlane(ev, i);
-                es[i] = e;
-                unsigned cofs8, lo, ex;
-                if (FAST) {
-                    cofs8 = (unsigned)__builtin_amdgcn_readlane((int)pc, e & 63);
-                    lo = (unsigned)__builtin_amdgcn_readlane((int)pl_, e & 63);
-                    ex = (unsigned)__builtin_amdgcn_readlane((int)pe, e & 63);
-                } else {
-                    const float* rp = (e < cap) ? (const float*)(lds.rec + (size_t)e * kPatchRec) : (const float*)(ovf + (size_t)(e - cap) * kPatchRec);
-                    const float4 mt = *reinterpret_cast<const float4*>(rp + 12);
-                    cofs8 = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.x));
-                    lo = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.y));
-                    ex = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(mt.z));
-                }
-                const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
-                const bool ok = (int)(FULL || a0 + i < nact) &
-                                (int)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d));
-                const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0) + ((unsigned long long)cofs8 << 3), 0, 0x7ffffff0, 0x00020000);
-                uu[i] = __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, ok ? flat4 : 0xffffffffu, 0, IPP_PATCH_AUX));
-            }
-            float qr[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float* rp = (FAST || es[i] < cap) ? (const float*)(lds.rec + (size_t)es[i] * kPatchRec) : (const float*)(ovf + (size_t)(es[i] - cap) * kPatchRec);
-                qr[i] = rp[lane & 15];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float ur[VEC] = {uu[i][0], uu[i][1]};
-                fmac_row<VEC, MC>(acc, qr[i], ur);
-            }
-        };
-        auto is_fast = [&](int a0, int last) {
-            return __builtin_amdgcn_readfirstlane((int)(last < nact_fast && ((int)ridx[a0] >> 6) == ((int)ridx[last] >> 6))) != 0;
-        };
-        typedef std::integral_constant<int, KP> n_kp;
-        int a0 = 0;
-        for (; a0 + KP <= nact; a0 += KP) {
-            if (is_fast(a0, a0 + KP - 1)) group(a0, std::true_type{}, n_kp{}, std::true_type{});
-            else group(a0, std::false_type{}, n_kp{}, std::false_type{});
-        }
-        const int rem = nact - a0;
-        if (rem > 0) {
-            if (!is_fast(a0, nact - 1)) group(a0, std::false_type{}, n_kp{}, std::false_type{});
-            else if (KP > 4 && rem > 4) group(a0, std::true_type{}, n_kp{}, std::false_type{});
-            else if (rem > 2) group(a0, std::true_type{}, std::integral_constant<int, 4>{}, std::false_type{});
-            else group(a0, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{});
-        }
-
-        if (!solved) {
-            while (__hip_atomic_load(solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
-            solved = true;
-            dead = __hip_atomic_load(solve_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2;
-        }
-        float lrow[MC];
-#pragma unroll
-        for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
-        linv_col<8>(acc, lrow); linv_col<7>(acc, lrow); linv_col<6>(acc, lrow); linv_col<5>(acc, lrow); linv_col<4>(acc, lrow);
-        linv_col<3>(acc, lrow); linv_col<2>(acc, lrow); linv_col<1>(acc, lrow); linv_col<0>(acc, lrow);
-        const bool commit = commit_u && !dead;
-
-        float dred[VEC];
-        double part = 0.0;
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            float w2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < MC; ++j) w2 = fmaf(acc[c][j], acc[c][j], w2);
-            if (!lane_valid) w2 = 0.f;  // (the new-row values of these lanes land in padding columns no reader looks at)
-            dred[c] = w2;
-            const bool in_mask = !adaptive || ((double)md_in[0][c] + v.kf * (double)md_in[1][c] >= v.thr);
-            if (lane_valid && in_mask) part += (double)w2;
-        }
-        part = wave_sum_dpp(part);
-        if (lane == 0) lds.unit_red[u] = part;
-        const int in_cells = __popcll(__ballot(lane_valid)) * VEC;
-        units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells;
-        if (commit && prow < hn) {  // the new node: its diagonal on its rectangle, its m columns (whole runs of the patch rows)
-            float outv[VEC];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) outv[c] = md_in[1][c] - dred[c];
-            store_vec<VEC>(new_diag + flat, outv);
-#pragma unroll
-            for (int j = 0; j < MC; ++j)
-                if (j < m) {
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
-                    store_stream<VEC>(new_cols + (size_t)j * v.pstride + flat, outv);
-                }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    for (int d = 0; d < kTreeDepth; ++d) { io.prc[d] = prc[d]; io.pid[d] = pid[d]; }
+    io.m = m; io.pw = pw; io.pstride = v.pstride;
+    UnitArgs ua;
+    ua.m = m; ua.rf1 = (h.rf == 1); ua.adaptive = (flags & IPP_ADAPTIVE) != 0; ua.commit_u = commit_u;
+    ua.n_c = n_c; ua.n_fast = n_fast; ua.cap = cap; ua.ovf = ovf;
+    ua.next_unit = next_unit; ua.solve_flag = solve_flag;
+    ua.ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
+    unsigned long long units = 0, needed = 0;
+    bool dead = false;
+    patch_units<KP>(v, lds, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
 
     // ------------------------------------------------------------------ per-item results (last wave to arrive)
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds.red);
-    if (lane == 0 && units) atomicAdd(cnt, units);
+    if (lane == 0 && units) { atomicAdd(cnt, units); atomicAdd(cnt + 1, needed); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int arrived = 0;
     if (lane == 0) arrived = atomicAdd(done_waves, 1);
@@ -542,8 +401,11 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
             meta[3] = root;
             meta[4] = (int)rect_pack(r0n, r1n, c0n, c1n);
         }
-        unsigned long long* slotc = v.counters + (size_t)(item & (kCountSlots - 1)) * 16;
-        if (cnt[0]) atomicAdd(slotc, cnt[0]);
+        if (cnt[0]) {  // (per-item totals: k_step_patch.h)
+            unsigned long long* ic = v.item_counts + 2 * (size_t)item;
+            ic[0] += cnt[0];
+            ic[1] += cnt[1];
+        }
     }
 }
 
