@@ -78,6 +78,9 @@ def build_parser():
                          "env-steps/s at 2 groups, 27.8 M at 4: dependent launches of a queue start ~9 us after their predecessor "
                          "once two queues are active (0 us on one queue) and the groups lock in phase.  With parts > 1 the "
                          "one-launch rate is measured as well (config.sync_schedule)")
+    ap.add_argument("--step-priority", type=int, default=0,
+                    help="A/B: run the steps on a stream of this priority (-1: above the side stream that generates the next episodes' "
+                         "ground truths, whose workgroups then only take the slots the step launches leave free)")
     ap.add_argument("--regions", type=int, default=5,
                     help="timed regions of --steps steps each (barrier + sync around every one); `value` is the median region")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
@@ -347,6 +350,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
             t_idx += 1
     torch.cuda.synchronize()
     counted, mask_reread = eng.streamed_bytes_detail(reset=True)  # device counters: floats actually streamed x 4
+    needed = eng.streamed_bytes_needed() / steps  # ... with every stored row taken on the cells inside its own rectangle only
     counted /= steps
     mask_reread /= steps
     gain_ms, gain_n = eng.profile_read(0)
@@ -399,6 +403,8 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "mean_rank_after_step": mean_rank_after, "bad_status": bad, "bad_rewards": bad_rewards,
         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
         "bytes_per_launch": bytes_per_launch, "mask_reread_bytes_per_launch": mask_reread if state == "factor" else 0.0,
+        "necessary_bytes_per_launch": needed if (state == "factor" and needed > 0) else None,
+        "workgroup_threads": 64 * int(os.environ.get("IPP_PATCH_WAVES", "2")) if (state == "factor" and int(eng.info.patch_layout)) else int(eng.info.tile_threads),
         "formula_bytes_per_launch": formula_bytes, "achieved_gbs": achieved,
         "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
         "arena_gb": float(eng.info.arena_bytes) / 1e9,
@@ -579,6 +585,8 @@ def extra_record(name, rec, total_envs):
             "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / rec["steps"]) / 1e9 / HBM_PEAK_GBS,
             "frac_definition": "frac: algorithmic bytes / the dominant kernel's average duration; step_frac: the same bytes / the whole step period "
                                "(every launch of the step, resets and ground-truth generation included)",
+            "necessary_bytes_per_launch": rec["necessary_bytes_per_launch"],
+            "frac_necessary": (rec["necessary_bytes_per_launch"] / (rec["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rec["necessary_bytes_per_launch"] and rec["kernel_ms"] else None,
             "window_rows": rec["window_rows"], "schedule_parts": rec["parts"], "single_launch_ms_avg": rec["single_launch_ms"],
             "sync_schedule": sync_record(rec, total_envs, rec["steps"]),
             "mean_rank_after_step": rec["mean_rank_after_step"], "arena_gb": rec["arena_gb"],
@@ -608,7 +616,10 @@ def main(argv=None):
     lo, hi, total_envs, scaling = shard_plan(args, rank, world)
     B, T = hi - lo, args.episode_steps
 
-    rec, cfg = run_env_workload(torch, ranks, device, grid=args.grid, envs_local=B, env_lo=lo, total_envs=total_envs,
+    import contextlib
+    prio_ctx = torch.cuda.stream(torch.cuda.Stream(device=device, priority=args.step_priority)) if args.step_priority else contextlib.nullcontext()
+    with prio_ctx:
+      rec, cfg = run_env_workload(torch, ranks, device, grid=args.grid, envs_local=B, env_lo=lo, total_envs=total_envs,
                                 episode_steps=T, state=args.state, window_rows=args.window_rows,
                                 shuffle_prior=args.shuffle_prior, tile_threads=args.tile_threads,
                                 predict_only=args.predict_only, fused_resets=args.fused_resets, steps=args.steps,
@@ -634,7 +645,7 @@ def main(argv=None):
                             f"flight-time cost; {'predict-only (reward) calls' if args.predict_only else 'full fused env step (predict + observe + update)'}",
                 "envs_per_gpu": B, "envs_total": total_envs, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,
                 "episode_steps": T, "episode_phase": "staggered (stationary rank mix)",
-                "mean_rank_after_step": rec["mean_rank_after_step"], "tile_threads": rec["tile_threads"], "window_rows": rec["window_rows"],
+                "mean_rank_after_step": rec["mean_rank_after_step"], "tile_threads": rec["workgroup_threads"], "window_rows": rec["window_rows"],
                 "prior": "shuffled per episode (window sized for 1.2 l)" if args.shuffle_prior else "fixed (example.yaml)",
                 "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"],
                 "rng": "device Philox4x32-10 keyed on the global env id",
@@ -658,16 +669,23 @@ def main(argv=None):
                 "single_launch_frac": (rec["bytes_per_launch"] / (rec["single_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rec["single_launch_ms"] else None,
                 "part_launch_ms_avg": rec["part_launch_ms_avg"], "part_launches": rec["part_launches"],
                 "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
+                "necessary_bytes_per_launch": rec["necessary_bytes_per_launch"],
+                "frac_necessary": (rec["necessary_bytes_per_launch"] / (rec["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                  if rec["necessary_bytes_per_launch"] and rec["kernel_ms"] else None,
+                "traffic_over_necessary": (traffic / rec["necessary_bytes_per_launch"]) if traffic and rec["necessary_bytes_per_launch"] else None,
+                "necessary_bytes_definition": "the same count with every stored row charged only on the cells INSIDE that column's own rectangle "
+                                              "(the lanes outside are masked requests that fetch nothing): sum over rows of popcount(lanes in the rectangle) x 8 "
+                                              "+ (m + 4) x 4 bytes per cell of the new rectangle, counted on the device next to algorithmic_bytes",
                 "algorithmic_bytes_definition": "SURVEY 8(d): 4 x (stored rows + m new rows + 4) bytes per touched cell, counted on the device: "
                                                 "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
                                                 "cells of the rectangle within window_rows of the footprint in BOTH directions (a stored column IS that "
                                                 "rectangle, as a compact patch; the padding columns a patch row may have are neither counted nor read)",
-                "note": "columns of U are stored as compact patches of their rectangles (k_step_patch.h): a wave's request for a stored row is 512 "
-                        "consecutive bytes, the new rows are written as whole runs; the kernel is bound by the per-item chain of short dependent phases at ten resident "
-                        "items per CU (launch time ~ the longest item alone, 0.063 ms, + 10-12 ns per further item), not by HBM or the FMA rate: "
-                        "the same row stream without arithmetic runs at 5.1 TB/s (tools/probes/patch_probe.hip, profiles/r03_patch_probe.txt), "
-                        "software-pipelined requests change nothing, the launch without the stream's FMAs is 6 % shorter "
-                        "(profiles/r03_experiments.txt 13-20)",
+                "note": "columns of U are stored as compact patches of their rectangles (k_step_patch.h + k_patch_units.h): one 2-wave workgroup per item, "
+                        "units of 128 valid cells, active columns as bit masks walked with scalar instructions.  What bounds the launch at 4096 items "
+                        "(profiles/r04_experiments.txt): the per-item chain -- prologue (dependent loads + fp64 header) 11.6 us, m x m algebra 7.7 us, "
+                        "then rows at 0.16 us per 512-byte request for a lone wave / 0.3 us under load (8 requests per round trip); the heaviest item takes "
+                        "0.10 ms under load (0.063 ms alone) and the second round of items starts at 0.04-0.05 ms; overlapping consecutive launches on two "
+                        "queues loses to the queue gap (item 1 of that log)",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],

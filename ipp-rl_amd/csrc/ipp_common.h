@@ -32,6 +32,11 @@ __device__ unsigned long long g_timeline[8 * kTimelineItems];  // per item: star
 // serialise the wave and make the kernel several times slower -- proportions only): a wave sums the time between its ticks per
 // phase in scalar registers and adds the sums to g_wphase when it exits; ipp_streamed_bytes prints and clears them
 __device__ unsigned long long g_wphase[16];
+// per-unit trace of the patch kernels: [item][wave 0..1][slot 0..7][unit index << 32 | rows, start, stream done, end] (wall clock, 10 ns)
+constexpr int kUnitTraceItems = 4096;
+__device__ unsigned long long g_unit_trace[kUnitTraceItems * 2 * 8 * 4];
+#define IPP_UNIT_TRACE(item, wave, slot, k, val) do { if ((item) < kUnitTraceItems && (wave) < 2 && (slot) < 8 && (threadIdx.x & 63) == 0) \
+    g_unit_trace[((((size_t)(item) * 2 + (wave)) * 8 + (slot)) * 4) + (k)] = (val); } while (0)
 #ifndef IPP_WAVE_CLOCKS
 #define IPP_WAVE_CLOCKS 0
 #endif
@@ -47,6 +52,7 @@ __device__ unsigned long long g_wphase[16];
 #else
 #if !IPP_TIMELINE
 #define IPP_MARK(item, k) ((void)0)
+#define IPP_UNIT_TRACE(item, wave, slot, k, val) ((void)0)
 #endif
 #define IPP_WT_DECL ((void)0)
 #define IPP_WT(k) ((void)0)

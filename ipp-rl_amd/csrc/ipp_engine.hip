@@ -55,6 +55,10 @@ constexpr uint64_t kAlign = 256;
 constexpr int kMaxChunks = 8;
 inline uint64_t up(uint64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
+#ifndef IPP_PATCH_BIGKP
+#define IPP_PATCH_BIGKP 4  // rows per request group of the six-waves-per-SIMD instantiation of k_step_patch
+#endif
+
 struct ProfSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0.0;
@@ -133,9 +137,7 @@ bool patch_layout(const ipp_config& c, int MC) {
     if (c.node_capacity > 0) {
         // tree nodes on patches (k_tree_patch.h): the records address column patches by 32-bit offsets in 8-byte units from
         // View::cov: root slots + node blocks must lie within 32 GB of it
-        const PatchGeo g = patch_geometry(c.x_dim, c.y_dim, c.window_rows);
-        const double reach = 4.0 * g.pstride * ((double)c.capacity * c.rank_cap + (double)c.node_capacity * 10.0) + 4.0 * c.max_batch * (c.rank_cap * 16.0 + 4096.0) * 4;
-        if (reach > 30e9) return false;
+        // (plan() checks the reach of the 32-bit record offsets on the finished layout)
         if (const char* tp = getenv("IPP_TREE_PATCH")) { if (atoi(tp) == 0) return false; }  // A/B: band-tile tree kernels
     }
     if (c.x_dim % 2 != 0 || c.x_dim > 256 || c.y_dim > 256) return false;
@@ -167,7 +169,7 @@ int min_window_rows(const ipp_config& c) {
     return r;
 }
 
-int plan(const ipp_config& c, Layout& L) {
+int plan(const ipp_config& c, Layout& L, bool allow_patch = true) {
     if (c.x_dim <= 0 || c.y_dim <= 0) return fail(-1, "x_dim/y_dim must be positive");
     if (!(c.resolution > 0)) return fail(-1, "resolution must be positive");
     if (c.state_repr != IPP_DENSE && c.state_repr != IPP_FACTOR) return fail(-1, "state_repr must be IPP_DENSE or IPP_FACTOR");
@@ -189,7 +191,7 @@ int plan(const ipp_config& c, Layout& L) {
     const long window_cells = std::min<long>(c.y_dim, 2L * c.window_rows + 5) * c.x_dim;
     L.VEC = (L.MC == 9 && !(windowed && window_cells < 16 * 256)) ? 4 : 2;
     if (const char* ve = getenv("IPP_VEC")) { if (L.MC == 9 && (atoi(ve) == 2 || atoi(ve) == 4)) L.VEC = atoi(ve); }  // A/B experiments
-    L.patch = patch_layout(c, L.MC);
+    L.patch = allow_patch && patch_layout(c, L.MC);
     L.patch_waves = patch_waves_wanted();
     if (L.patch) {
         L.VEC = 2;
@@ -299,6 +301,14 @@ int plan(const ipp_config& c, Layout& L) {
         L.off_tr_diag = o; o += up(nc * wc * 4 + 4096);
         L.off_tr_meta = o; o += up(nc * kNodeMeta * 4);
         L.off_sc_ndiag = o; o += c.score_scratch ? up(np * 4) : 0;
+        // tree nodes on patches (k_tree_patch.h): a record addresses its column patch by a 32-bit offset in 8-byte units from
+        // View::cov - kTreePatchGuard, so root slots AND node blocks have to lie within 2^35 bytes of it -- decided on the finished
+        // layout (the score scratch sits between the two regions: 6.5 GB at 200x200, 17 GB at 256x256); beyond that the band-tile
+        // tree kernels take over
+        if (L.patch && allow_patch) {
+            const uint64_t reach = (L.off_tr_diag - L.off_cov) + (uint64_t)kTreePatchGuard + (1ull << 20);  // (+ the largest shift of a patch)
+            if (reach >= (1ull << 35)) return plan(c, L, false);
+        }
     }
     L.total = o;
     return 0;
@@ -429,7 +439,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
             else if (e->big_min_items > 0 && n >= e->big_min_items) {
                 View vb = v;  // (six waves per SIMD pay once a launch is many rounds of workgroups: k_step_patch.h)
                 vb.pcap = e->pcap_big;
-                timed_launch(e, 0, k_step_patch<2, 4, 6>, dim3(n), dim3(128), e->lds_big, s, vb, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                timed_launch(e, 0, k_step_patch<2, IPP_PATCH_BIGKP, 6>, dim3(n), dim3(128), e->lds_big, s, vb, env_ids, n, action, prev, noise, flags, status, reward, ar);
             } else
                 timed_launch(e, 0, k_step_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
         }
@@ -863,6 +873,16 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<9, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    {  // patch kernels: IPP_PATCH_WGS <= 2 asks for more than the default 64 KB of dynamic LDS
+        const int pl = 160 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2, IPP_PATCH_BIGKP, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     const int glds = (int)e->gain_lds;
@@ -991,6 +1011,8 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     out->step_lds_bytes = e->gain_lds;
     out->fused_step = e->fused ? 1 : 0;
     out->patch_layout = e->patch ? 1 : 0;
+    out->patch_waves = e->patch ? e->patch_waves : 0;
+    out->patch_big_min_items = e->patch ? e->big_min_items : 0;
     return 0;
 }
 
@@ -1231,10 +1253,13 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
     e->last_n = n;
     const View& v = e->v;
     if (e->patch) {  // tree nodes as patches: one fused kernel for every launch size (k_tree_patch.h)
-        if (e->patch_waves == 4)
-            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
+        // (LDS sized for the waves this kernel really has: the step kernel may run 1 or 3 waves per item -- IPP_PATCH_WAVES --, the tree kernel 2 or 4)
+        const int nw = e->patch_waves == 4 ? 4 : 2;
+        const size_t tlds = PatchLds::bytes(v.pcap, v.plw * v.plw, nw, v.punits, v.rank_cap);
+        if (nw == 4)
+            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
         else
-            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
+            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1613,6 +1638,12 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
         std::vector<unsigned long long> tl(n);
         HIP_TRY(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_timeline), n * 8));
         if (FILE* f = fopen(path, "wb")) { fwrite(tl.data(), 8, n, f); fclose(f); }
+        std::vector<unsigned long long> ut((size_t)kUnitTraceItems * 2 * 8 * 4);
+        HIP_TRY(hipMemcpyFromSymbol(ut.data(), HIP_SYMBOL(g_unit_trace), ut.size() * 8));
+        const std::string upath = std::string(path) + ".units";
+        if (FILE* f = fopen(upath.c_str(), "wb")) { fwrite(ut.data(), 8, ut.size(), f); fclose(f); }
+        std::fill(ut.begin(), ut.end(), 0ull);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_unit_trace), ut.data(), ut.size() * 8));
     }
     {
         unsigned long long wp[16];

@@ -78,6 +78,7 @@ struct UnitArgs {
     int* next_unit;     // LDS ticket counter
     int* solve_flag;    // LDS: 0 pending, 1 L^-1 / y ready, 2 S not positive definite
     unsigned short* ridx;  // this wave's list area (records beyond the register pages)
+    int item;           // (timing builds: the per-unit trace)
 };
 
 // The loop.  mcofs / mlo / mex: offset word, (first row | first column << 16) and (rows - 1 | columns - 1 << 16) of record a in lane
@@ -98,6 +99,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
     unsigned short* ridx = ua.ridx;
     bool solved = false;
     units = 0; needed = 0; dead = false;
+    int tslot = 0;
     IPP_WT_DECL;  // (phase clocks of the timing build: 0 setup + masks, 1 prior term, 2 stream, 3 mean / diag + solve wait, 4 L^-1 + epilogue, 5 stores)
 
     for (;;) {
@@ -105,6 +107,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         if (lane == 0) u = atomicAdd(ua.next_unit, 1);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= g.n_units) break;
+        IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 1, wall_clock64());
         const int idx = 2 * (u * kWave + lane);
         const int prow = (int)(((unsigned)idx * g.wdiv) >> kUnitDivShift), pcol = idx - prow * g.wn;
 #if IPP_UNIT_PWSTRIDE
@@ -290,6 +293,8 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
             fma_rows(std::integral_constant<int, KP>{}, uu, qr);
         }
 
+        IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 0, ((unsigned long long)u << 32) | (unsigned)nact);
+        IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 2, wall_clock64());
         IPP_WT(2);
         IPP_WT_COUNT(9, (nact + KP - 1) / KP);
         IPP_WT_COUNT(10, 1);
@@ -344,6 +349,8 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         io.store(commit, lane_valid, cell0, flat, flat4, acc, md_in, dred, dmean);
         __builtin_amdgcn_wave_barrier();
         IPP_WT(5);
+        IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 3, wall_clock64());
+        ++tslot;
     }
     IPP_WT_FLUSH(lane);
 }

@@ -355,7 +355,9 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
         gather_sum(l, sacc);
     };
     float sacc0[UN];
-    const bool gather_on = (MODE == IPP_FACTOR) && gi < m && r > 0;
+    // (ipp_observe stops behind the observation: it must not touch the covariance state -- on a patch-layout engine the column
+    // addresses of this band-tile gather do not even exist, a slot holds rank_cap * pstride floats)
+    const bool gather_on = (MODE == IPP_FACTOR) && gi < m && r > 0 && !obs_out;
     // rows past the rank clamp to r - 1: their span was read for an unused column, the value is discarded below.
     // The pass stays in flight across mid_work (block tables and prior table: arithmetic on the header): its 1.5 us run
     // under the 4 us round trip.  (While mid_work also loaded the mean / diag of the window for the mask this cost 48 live

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     UnitArgs ua;
     ua.m = m; ua.rf1 = (h.rf == 1); ua.adaptive = (flags & IPP_ADAPTIVE) != 0; ua.commit_u = commit_u;
     ua.n_c = n_c; ua.n_fast = n_fast; ua.cap = cap; ua.ovf = ovf;
-    ua.next_unit = next_unit; ua.solve_flag = solve_flag;
+    ua.next_unit = next_unit; ua.solve_flag = solve_flag; ua.item = item;
     ua.ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
     unsigned long long units = 0, needed = 0;
     bool dead = false;

@@ -253,9 +253,11 @@ class ClassicMCTS:
     @staticmethod
     def merge_roots(root_a: Node, root_b: Node) -> Node:
         """:320-339"""
+        # both sides keyed by action: children are not de-duplicated on expansion, so of several children with one action the LAST
+        # one stands for the action, and every action of root_b is merged or appended once
         by_action = {str(list(ch.action)): ch for ch in root_a.children}
-        for ch_b in list(root_b.children):
-            key = str(list(ch_b.action))
+        by_action_b = {str(list(ch.action)): ch for ch in root_b.children}
+        for key, ch_b in by_action_b.items():
             if key in by_action:
                 by_action[key].visits += ch_b.visits
                 by_action[key].value_sum += ch_b.value_sum

@@ -87,6 +87,33 @@ def test_arena_sizing_and_validation_without_gpu():
     assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(nbytes)) < 0
 
 
+def test_tree_patches_stay_within_reach_of_their_32_bit_record_offsets():
+    """k_tree_patch addresses a column patch by a 32-bit offset in 8-byte units from View::cov: root slots and node blocks have to lie
+    within 2^35 bytes of it.  The decision is taken on the finished arena layout (the score scratch -- one dense P, 17 GB at
+    256x256 -- sits between the two regions: ADVICE r03); beyond the reach the engine plans the band-tile tree kernels, whose nodes
+    are an order of magnitude larger."""
+    from ipp_rl_amd import _ffi
+
+    lib = _ffi.load()
+
+    def arena(nodes, score):
+        c = _ffi.IppConfig(x_dim=256, y_dim=256, resolution=4.0, tan_half_fov_x=0.57735, tan_half_fov_y=0.57735,
+                           rf_altitude=10.0, coeff_a=0.05, coeff_b=0.2, signal_variance=1.82, length_scale=3.67, max_v=2,
+                           max_a=2, value_threshold=0.4, interval_factor=0, cluster_radius=5, state_repr=_ffi.IPP_FACTOR,
+                           capacity=4, rank_cap=90, max_batch=64, max_measurements=9, tile_threads=0, window_rows=10,
+                           score_scratch=score, node_capacity=nodes, fixed_prior=1)
+        n = ctypes.c_uint64(0)
+        assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(n)) == 0, lib.ipp_last_error()
+        return n.value
+
+    per_node_patch = (arena(200_000, 0) - arena(100_000, 0)) / 100_000
+    assert 20e3 < per_node_patch < 40e3                      # a node = 10 patches of ~2.6 KB
+    # without the scratch 700 000 nodes are 19 GB: in reach; with the 17 GB scratch in front of them they are not
+    assert arena(700_000, 0) < 22e9
+    assert arena(700_000, 1) - arena(700_000, 0) > 100e9     # band-tile nodes (>= 25 grid rows of 256 cells x 10 per node)
+    assert arena(100_000, 1) - arena(100_000, 0) < 20e9      # 2.7 GB of nodes behind the scratch: still patches
+
+
 def test_engine_fails_loudly_without_gpu():
     import torch
 

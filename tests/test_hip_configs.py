@@ -54,9 +54,12 @@ def test_fullsize_batch_invariants_subset_parity_and_reproducibility(grid, B, T,
     N, S = cfg.n_cells, 192  # S: envs also run through the exact factor mode
     full = IPPEngine(cfg, capacity=B, state="factor", rank_cap=9 * T, window_rows=-1, fixed_prior=True)
     exact = IPPEngine(cfg, capacity=S, state="factor", rank_cap=9 * T, window_rows=0)
-    # the bench's path: window from the fixed prior; k_prepare + 128-thread k_gain_factor for large batches (>= 8192 envs on grids of >= 6000 cells, >= 24576 envs below)
-    # (csrc/ipp_engine.hip plan(); the fused k_step_factor of smaller batches is covered by the configs[1] tests)
-    assert full.info.window_rows == 10 and full.info.tile_threads == 128
+    # the bench's path: window from the fixed prior, factor columns as compact patches, k_step_patch -- and for launches of this size
+    # its six-waves-per-SIMD instantiation (csrc/ipp_engine.hip patch_layout() / launch_chunk()); a regression in the selection rules
+    # would put these configs back on the band-tile kernels with every numeric check below still green
+    assert full.info.window_rows == 10
+    assert full.info.patch_layout == 1 and full.info.fused_step == 1 and full.info.patch_waves == 2
+    assert 0 < full.info.patch_big_min_items <= B
     print(f"[{name}] arena {full.info.arena_bytes / 1e9:.1f} GB, {full.info.cov_slot_bytes / 1e6:.2f} MB of columns per env")
     white = torch.empty((B, N), dtype=torch.float32, device="cuda")
     full.normal_rows(white, N, 11, 1 << 40)
@@ -377,3 +380,23 @@ def test_fullsize_device_search_1024_roots_256_sims_200x200():
     nsa1 = mcts.t_Nsa.copy()
     out2 = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
     assert np.array_equal(nsa1, mcts.t_Nsa) and all(out[j][0] == out2[j][0] for j in range(roots))
+
+
+@pytest.mark.parametrize("grid,capacity,T,node_capacity,big", [
+    (50, 64, 40, 0, False),        # configs[0] / [1]: 50x50 (the headline batch is 4096 envs: below the six-wave threshold)
+    (50, 4096, 40, 0, False),      # configs[1]
+    (100, 256, 16, 0, False),      # configs[2] geometry (the full batch: test above)
+    (50, 16384, 40, 0, True),      # configs[3] per-GPU share launches >= 16384 items
+    (200, 64, 11, 256, False),     # configs[4]: 200x200 roots + tree nodes
+])
+def test_baseline_configs_take_the_patch_kernels(grid, capacity, T, node_capacity, big):
+    """Kernel selection per BASELINE config: the window of the fixed example prior puts every one of them on the patch layout."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    fresh_gpu()
+    eng = IPPEngine(EngineConfig(x_dim=grid, y_dim=grid), capacity=capacity, state="factor", rank_cap=9 * T, window_rows=-1,
+                    fixed_prior=True, node_capacity=node_capacity)
+    assert eng.info.window_rows == 10
+    assert eng.info.patch_layout == 1 and eng.info.fused_step == 1 and eng.info.patch_waves == 2
+    assert (0 < eng.info.patch_big_min_items <= capacity) == big
+    eng.close()

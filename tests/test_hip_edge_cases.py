@@ -399,3 +399,43 @@ def test_fullsize_windowed_fused_path_tracks_the_exact_mode():
         assert float((fast.mean(e).double() - exact.mean(e).double()).abs().max()) < 1e-5
         assert float((fast.diag(e).double() - exact.diag(e).double()).abs().max()) < 1e-5
         assert torch.equal(fast.ground_truth(e), exact.ground_truth(e))
+
+
+def test_observe_on_a_patch_engine_after_committed_steps_leaves_the_state_alone():
+    """ipp_observe (Sensor.take_measurement, sensors/cameras.py:108-116) on a patch-layout engine whose slots hold columns: the
+    observation-only prologue must not gather from the covariance slots (their band-tile addresses do not exist on this layout --
+    ADVICE r03: reads past the slot / the arena); same z as a band-tile engine in the same state, state untouched, last env slot
+    of a tight arena included."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B = 8
+    rs = np.random.RandomState(21)
+    gt = torch.as_tensor(rs.uniform(size=(B, cfg.n_cells)), dtype=torch.float32, device="cuda")
+    patch = IPPEngine(cfg, capacity=B, state="factor", rank_cap=64, window_rows=-1, fixed_prior=True, max_batch=B)
+    band = IPPEngine(cfg, capacity=B, state="factor", rank_cap=64, window_rows=10, tile_threads=256, fixed_prior=True, max_batch=B)
+    assert patch.info.patch_layout == 1 and band.info.patch_layout == 0
+    prev = np.tile([2.0, 2.0, 14.0], (B, 1))
+    for eng in (patch, band):
+        eng.reset(gt=gt)
+    for t in range(6):
+        a = np.stack([4.0 * rs.randint(20, 30, B) + 2.0, 4.0 * rs.randint(20, 30, B) + 2.0, rs.randint(5, 15, B).astype(float)], axis=1)
+        eps = rs.normal(size=(B, 9))
+        for eng in (patch, band):
+            eng.step(a, prev, meas_noise=eps)
+        prev = a
+    ranks = patch.ranks().clone()
+    assert int(ranks.min()) > 0
+    before = [(patch.read_mean(e).clone(), patch.read_diag(e).clone()) for e in range(B)]
+    cov7 = patch.read_cov(B - 1).clone()
+    a = np.stack([4.0 * rs.randint(20, 30, B) + 2.0, 4.0 * rs.randint(20, 30, B) + 2.0, rs.randint(5, 15, B).astype(float)], axis=1)
+    eps = rs.normal(size=(B, 9))
+    zp, mp, sp = patch.observe(a, meas_noise=eps)
+    zb, mb, sb = band.observe(a, meas_noise=eps)
+    torch.cuda.synchronize()
+    assert torch.equal(zp, zb) and torch.equal(mp, mb) and torch.equal(sp, sb)
+    assert torch.equal(patch.ranks(), ranks)
+    for e in range(B):
+        assert torch.equal(patch.read_mean(e), before[e][0]) and torch.equal(patch.read_diag(e), before[e][1])
+    assert torch.equal(patch.read_cov(B - 1), cov7)

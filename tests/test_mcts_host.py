@@ -130,3 +130,27 @@ def test_parallel_simulations_keep_the_accounting_consistent():
     assert np.all(m.t_Nsa[: m.n_count].sum(axis=1) == m.n_Ns[: m.n_count])          # virtual visits all undone
     assert not np.any(np.isinf(m.t_num[: m.n_count]))                                # every requested edge got its device result
     assert eng.steps == m.stats["device_steps"] and m.stats["launches"] <= 16 * 6    # <= one launch per level and wave
+
+
+def test_merge_roots_counts_an_action_once_like_the_reference():
+    """planning/mcts_mission.py:320-339: both roots' children are put into dicts keyed by the action first -- of several children
+    with the same action (expansion does not de-duplicate) the LAST one stands for the action, and every action of root_b is merged
+    or appended once."""
+    from ipp_rl_amd.planning.mcts_mission import ClassicMCTS, Node
+
+    def node(action, visits, value_sum):
+        n = Node(0, -1, [], action=action)
+        n.visits, n.value_sum = visits, value_sum
+        return n
+
+    root_a, root_b = node([0, 0, 0], 10, 5.0), node([0, 0, 0], 7, 3.0)
+    a1, a2 = node([1, 1, 8], 4, 2.0), node([2, 2, 8], 6, 3.0)
+    root_a.children = [a1, a2]
+    b1, b1_dup, b3, b3_dup = node([1, 1, 8], 1, 0.5), node([1, 1, 8], 2, 1.5), node([3, 3, 8], 3, 0.75), node([3, 3, 8], 1, 0.25)
+    root_b.children = [b1, b1_dup, b3, b3_dup]
+    out = ClassicMCTS.merge_roots(root_a, root_b)
+    assert out is root_a
+    assert (a1.visits, a1.value_sum) == (4 + 2, 2.0 + 1.5)          # the last duplicate of root_b, once
+    assert (a2.visits, a2.value_sum) == (6, 3.0)
+    assert len(root_a.children) == 3 and root_a.children[2] is b3_dup  # appended once
+    assert (root_a.visits, root_a.value_sum) == (10 + 2 + 1, 5.0 + 1.5 + 0.25)

@@ -40,6 +40,18 @@ def main():
         for k, s0 in enumerate(late):  # k-th late start reuses (at best) the slot of the k-th end
             gaps.append(s0 - order_e[min(k, len(order_e) - 1)])
         print(f"k-th late start minus k-th end (slot refill delay): mean {np.mean(gaps):.1f} us   p10 {np.percentile(gaps, 10):.1f}  p90 {np.percentile(gaps, 90):.1f}")
+    import os
+    if os.path.exists(path + ".units"):
+        ut = np.fromfile(path + ".units", dtype=np.uint64).reshape(-1, 2, 8, 4)
+        for i in np.argsort(-end)[:3]:
+            print(f" units of item {i} (start {start[i]:.1f}, end {end[i]:.1f} us):")
+            for w in range(2):
+                for k in range(8):
+                    a = ut[i, w, k]
+                    if a[1] == 0:
+                        continue
+                    ts = [(float(x) - t0) / 100.0 for x in a[1:]]
+                    print(f"   wave {w} unit {int(a[0] >> np.uint64(32))} rows {int(a[0] & np.uint64(0xffffffff)):4d}  start {ts[0]:6.1f}  stream done {ts[1]:6.1f} (+{ts[1] - ts[0]:5.1f})  end {ts[2]:6.1f} (+{ts[2] - ts[1]:4.1f})")
     print(f"last workgroup start at {start[ok].max():.1f} us")
     # the items that end last: where did their time go
     last = np.argsort(-end)[:12]
