@@ -201,8 +201,8 @@ struct View {
     // 5 % (one counter) / 19 % (two) of the fused step kernel: the waves' exits queued up behind same-address atomics.
     // (slot 0, words 1..7: debug phase timing)
     unsigned long long* counters;
-    // patch kernels: per ITEM [max_batch][2] = (streamed floats, floats on the lanes inside the stored columns' rectangles), plain
-    // read-add-write by the item's last wave (an item index belongs to one workgroup per launch: no atomics, no shared line)
+    // patch kernels: per ITEM [max_batch][2] = (streamed floats, floats on the lanes inside the stored columns' rectangles), added by
+    // the item's last wave with return-less atomics (an item index belongs to one workgroup per launch: no shared line, no wait)
     unsigned long long* item_counts;
     int* tickets;    // [kTicketSlots] item ticket counters of the pipelined step kernel, one per launch in flight (k_step_pipe.h)
     float* cov;      // factor: [cap][rank_cap][Npad]   dense: [cap][N][Npad]

@@ -23,6 +23,7 @@
 #include "k_misc.h"
 #include "k_grf_dft.h"
 #include "k_grf_hartley.h"
+#include "k_grf_fft.h"
 #include "k_score.h"
 #include "k_plane.h"
 #include "k_tree.h"
@@ -82,6 +83,7 @@ struct Engine {
     ScoreView sv = {};
     bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
     int grf_tt = 0;        // > 0: even square grids up to 128: k_grf_hartley<grf_tt> (fp64 MFMA GEMMs)
+    bool grf_fft = false;  // ... and n = 50 / 100: k_grf_fft (fast Hartley transforms) on the same amplitude table
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
     int lut_rows = 0;  // workgroup-per-item factor kernels: rows |drow| of the prior table kept in LDS
@@ -616,6 +618,15 @@ void launch_grf_hartley(const View& v, int n, const float* white, const int32_t*
 int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
     const View& v = e->v;
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
+    if (e->grf_tt > 0 && e->grf_fft) {  // n = 50 / 100: fast Hartley transforms in LDS (k_grf_fft.h), same amplitude table
+        const int np = 16 * e->grf_tt;
+        if (v.W == 100)
+            hipLaunchKernelGGL((k_grf_fft<10>), dim3(n), dim3(512), grf_fft_lds_bytes(100), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out);
+        else
+            hipLaunchKernelGGL((k_grf_fft<5>), dim3(n), dim3(256), grf_fft_lds_bytes(50), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (e->grf_tt > 0) {  // even n <= 128: four fp64 GEMMs on the matrix cores, normalisation fused (k_grf_hartley.h)
         switch (e->grf_tt) {
             case 1: launch_grf_hartley<1>(v, n, white, env_ids, gt_out, s); break;
@@ -955,6 +966,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                 (void)hipFuncSetAttribute(fn[tt - 1], hipFuncAttributeMaxDynamicSharedMemorySize, hl);
                 if (n == 50) (void)hipFuncSetAttribute((const void*)&k_grf_hartley<4, 4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
                 if (n == 100) (void)hipFuncSetAttribute((const void*)&k_grf_hartley<7, 8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
+                e->grf_fft = (n == 50 || n == 100);
+                if (const char* gf = getenv("IPP_GRF_FFT")) e->grf_fft = e->grf_fft && atoi(gf) != 0;  // A/B: the GEMM form
+                (void)hipFuncSetAttribute((const void*)&k_grf_fft<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(100));
+                (void)hipFuncSetAttribute((const void*)&k_grf_fft<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(50));
             }
         }
         if (e->grf_dft) {

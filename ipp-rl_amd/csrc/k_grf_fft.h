@@ -1,0 +1,181 @@
+// Gaussian random field through FAST Hartley transforms (simulations/ground_truths.py:14-33: field = Re ifft2(fft2(white) * amp),
+// min-max normalised) for n = 50 and n = 100 -- the grids of BASELINE configs[1] .. [3].
+//
+// Same identity as k_grf_hartley.h: the white noise is real and the amplitude is real and even in each spectral index, so with the
+// separable Hartley transform T = H (x) H (H[j][k] = cos + sin of 2 pi j k / n, H H = n I)
+//      field = H (amp .* (H w H)) H          (constants dropped: the field is min-max normalised right after)
+// -- but the four multiplications by H are not GEMMs (8 n^3 flops per field: 2048 fields of 100x100 per step of configs[2] took
+// 0.47 ms, as long as the step kernel, on 101 KB of LDS and 168 VGPRs that evicted the step's workgroups).  Here every multiplication
+// is n one-dimensional Hartley transforms computed as n / 2 COMPLEX FFTs of two real vectors packed as real and imaginary part
+//      z = x + i y,  Z = FFT(z):   DHT_x[j] = a + c - b + d,   DHT_y[j] = b + d + a - c      (Z[j] = a + i b, Z[n - j] = c + i d)
+// and a length-n FFT is two steps of small FFTs held in registers (n = N1 x 10, N1 = 5 or 10: the four-step scheme):
+//   A  thread (pair f, column c < 10):  FFT-N1 over the elements c + 10 r, times the twiddles w_n^(c k), written back in place
+//   B  thread (pair f, row k < N1):     FFT-10 over the elements 10 k + c, output q is X[k + N1 q]
+//   C  thread (pair f, ...):            the Hartley combination of the elements j and n - j above (and the amplitude, once)
+// ~0.7 MFLOP per field instead of 10, all in place on ONE n x (n + 1) fp64 array in LDS (81 KB at n = 100, 20 KB at n = 50), ~90 VGPRs.
+// Checked against numpy.fft in fp64 to 7e-16 (tools/probes/grf_fft_model.py is this kernel line by line in NumPy).
+#pragma once
+#include "ipp_common.h"
+
+namespace ipp {
+
+__host__ __device__ inline size_t grf_fft_lds_bytes(int n) { return ((size_t)n * (n + 1) + 2 * (size_t)n + 2 * 16) * 8 + 64; }
+
+// forward DFT of 5 complex numbers (re / im arrays, in place)
+__device__ __forceinline__ void fft5(double (&re)[5], double (&im)[5]) {
+    constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos 72, cos 144 degrees
+    constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin 72, sin 144 degrees
+    const double t1r = re[1] + re[4], t1i = im[1] + im[4], t2r = re[2] + re[3], t2i = im[2] + im[3];
+    const double t3r = re[1] - re[4], t3i = im[1] - im[4], t4r = re[2] - re[3], t4i = im[2] - im[3];
+    const double m1r = re[0] + c1 * t1r + c2 * t2r, m1i = im[0] + c1 * t1i + c2 * t2i;
+    const double m2r = re[0] + c2 * t1r + c1 * t2r, m2i = im[0] + c2 * t1i + c1 * t2i;
+    const double u1r = s1 * t3r + s2 * t4r, u1i = s1 * t3i + s2 * t4i;
+    const double u2r = s2 * t3r - s1 * t4r, u2i = s2 * t3i - s1 * t4i;
+    re[0] += t1r + t2r; im[0] += t1i + t2i;
+    // X1 = m1 - i u1, X4 = m1 + i u1, X2 = m2 - i u2, X3 = m2 + i u2     (-i (ur + i ui) = ui - i ur)
+    re[1] = m1r + u1i; im[1] = m1i - u1r;
+    re[4] = m1r - u1i; im[4] = m1i + u1r;
+    re[2] = m2r + u2i; im[2] = m2i - u2r;
+    re[3] = m2r - u2i; im[3] = m2i + u2r;
+}
+// forward DFT of 10 complex numbers: two FFT-5 on the even / odd elements + the radix-2 butterflies
+__device__ __forceinline__ void fft10(double (&re)[10], double (&im)[10]) {
+    double er[5] = {re[0], re[2], re[4], re[6], re[8]}, ei[5] = {im[0], im[2], im[4], im[6], im[8]};
+    double qr[5] = {re[1], re[3], re[5], re[7], re[9]}, qi[5] = {im[1], im[3], im[5], im[7], im[9]};
+    fft5(er, ei);
+    fft5(qr, qi);
+    // w_10^k = exp(-2 pi i k / 10), k = 0 .. 4
+    constexpr double wr[5] = {1.0, 0.80901699437494742410, 0.30901699437494742410, -0.30901699437494742410, -0.80901699437494742410};
+    constexpr double wi[5] = {0.0, -0.58778525229247312917, -0.95105651629515357212, -0.95105651629515357212, -0.58778525229247312917};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double tr = wr[k] * qr[k] - wi[k] * qi[k], ti = wr[k] * qi[k] + wi[k] * qr[k];
+        re[k] = er[k] + tr; im[k] = ei[k] + ti;
+        re[k + 5] = er[k] - tr; im[k + 5] = ei[k] - ti;
+    }
+}
+template <int N>
+__device__ __forceinline__ void fft_small(double (&re)[N], double (&im)[N]) {
+    if constexpr (N == 5) fft5(re, im); else fft10(re, im);
+}
+
+// One Hartley pass: X <- DHT along `axis` of every vector (axis 1: the rows of X, axis 0: its columns), times amp on the way out when
+// amp != nullptr.  element j of vector v sits at X[v * sv + j * sj].
+template <int N1, int NT>
+__device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const double* tw, const double* __restrict__ amp, int amp_ld, int tid) {
+    constexpr int N2 = 10, n = N1 * N2;
+    const int f = tid / 10, c = tid - 10 * f;  // pair of vectors, position inside the group of ten threads
+    const bool on = f < n / 2;
+    double* x0 = X + (size_t)(2 * f) * sv;  // real part: vector 2 f, imaginary part: vector 2 f + 1
+    double* x1 = x0 + sv;
+    // ---- A: FFT-N1 over the elements c + 10 r, twiddles w_n^(c k)
+    if (on) {
+        double re[N1], im[N1];
+#pragma unroll
+        for (int r = 0; r < N1; ++r) { re[r] = x0[(c + N2 * r) * sj]; im[r] = x1[(c + N2 * r) * sj]; }
+        fft_small<N1>(re, im);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+            const double wr = tw[2 * (c * k)], wi = tw[2 * (c * k) + 1];  // (c k < n)
+            x0[(c + N2 * k) * sj] = re[k] * wr - im[k] * wi;
+            x1[(c + N2 * k) * sj] = re[k] * wi + im[k] * wr;
+        }
+    }
+    __syncthreads();
+    // ---- B: FFT-10 over the elements 10 k + c (threads k < N1), output q is X[k + N1 q]
+    {
+        double re[N2], im[N2];
+        const bool onb = on && c < N1;
+        if (onb) {
+#pragma unroll
+            for (int q = 0; q < N2; ++q) { re[q] = x0[(N2 * c + q) * sj]; im[q] = x1[(N2 * c + q) * sj]; }
+            fft10(re, im);
+        }
+        __syncthreads();  // (every row is in registers before the first scattered store)
+        if (onb) {
+#pragma unroll
+            for (int q = 0; q < N2; ++q) { x0[(c + N1 * q) * sj] = re[q]; x1[(c + N1 * q) * sj] = im[q]; }
+        }
+    }
+    __syncthreads();
+    // ---- C: the two Hartley transforms out of the packed spectrum, pairs (j, n - j), j = 0 .. n / 2
+    if (on) {
+        for (int j = c; j <= n / 2; j += 10) {
+            const int jj = (j == 0) ? 0 : n - j;
+            const double a = x0[j * sj], b = x1[j * sj], cc = x0[jj * sj], d = x1[jj * sj];
+            double xj = a + cc - b + d, yj = b + d + a - cc, xjj = cc + a - d + b, yjj = d + b + cc - a;
+            if (amp) {  // amp is even in both indices and symmetric: amp[v][j] whichever the axis
+                const double a0j = amp[(size_t)(2 * f) * amp_ld + j], a1j = amp[(size_t)(2 * f + 1) * amp_ld + j];
+                const double a0jj = amp[(size_t)(2 * f) * amp_ld + jj], a1jj = amp[(size_t)(2 * f + 1) * amp_ld + jj];
+                xj *= a0j; yj *= a1j; xjj *= a0jj; yjj *= a1jj;
+            }
+            x0[j * sj] = xj; x1[j * sj] = yj;
+            x0[jj * sj] = xjj; x1[jj * sj] = yjj;
+        }
+    }
+    __syncthreads();
+}
+
+// One workgroup per field.  white [n_items][N] float standard normals; amp [n][amp_ld] doubles (the table of k_grf_hartley.h: zero padded,
+// leading dimension amp_ld); result into the env slots (gt_out == nullptr) or gt_out [n_items][N].
+template <int N1>
+__global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const int* __restrict__ env_ids, int n_items, const float* __restrict__ white,
+                                                                  const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out) {
+    constexpr int n = N1 * 10, LD = n + 1, NT = (N1 == 10) ? 512 : 256, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
+    const int item = blockIdx.x;
+    if (item >= n_items) return;
+    const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
+    if (env < 0 || env >= v.cap) return;
+    double* X = reinterpret_cast<double*>(smem_gf);
+    double* tw = X + (size_t)n * LD;  // [n] (cos, -sin)(2 pi j / n)
+    double* red = tw + 2 * n;         // [2][16] min / max per wave
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = n * n;
+    {
+        const float2* __restrict__ w2 = reinterpret_cast<const float2*>(white + (size_t)item * N);
+        for (int i = tid; i < N / 2; i += NT) {
+            const float2 wv = w2[i];
+            const int y = i / (n / 2), x = 2 * (i - y * (n / 2));
+            X[y * LD + x] = (double)wv.x;
+            X[y * LD + x + 1] = (double)wv.y;
+        }
+        for (int j = tid; j < n; j += NT) {
+            double sn, cs;
+            sincos(-6.283185307179586476925 * (double)j / (double)n, &sn, &cs);
+            tw[2 * j] = cs; tw[2 * j + 1] = sn;
+        }
+    }
+    __syncthreads();
+    grf_fft_pass<N1, NT>(X, LD, 1, tw, nullptr, 0, tid);      // rows:    w H
+    grf_fft_pass<N1, NT>(X, 1, LD, tw, amp, amp_ld, tid);     // columns: amp .* (H w H)
+    grf_fft_pass<N1, NT>(X, LD, 1, tw, nullptr, 0, tid);
+    grf_fft_pass<N1, NT>(X, 1, LD, tw, nullptr, 0, tid);      // field (x constants)
+    // ---- min-max normalisation to [0, 1] (ground_truths.py:31), fp64 like the reference
+    double lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < N; i += NT) {
+        const int y = i / n, x = i - y * n;
+        const double f = X[y * LD + x];
+        lo = fmin(lo, f); hi = fmax(hi, f);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, off));
+        hi = fmax(hi, __shfl_xor(hi, off));
+    }
+    if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
+    __syncthreads();
+    double dlo = red[0], dhi = red[16];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[16 + w]); }
+    const double span = dhi - dlo;
+    float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
+    for (int i = tid; i < N; i += NT) {
+        const int y = i / n, x = i - y * n;
+        gt[i] = (float)((X[y * LD + x] - dlo) / span);
+    }
+    if (!gt_out)
+        for (int i = N + tid; i < v.Npad; i += NT) gt[i] = 0.f;
+}
+
+}  // namespace ipp

@@ -234,7 +234,10 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
             for (int i = 0; i < N; ++i) {
                 const bool real = FULL || i < nreal;  // (wave-uniform)
                 int e = e0;
-                if (real) { e = (int)__builtin_ctzll(mk); mk &= mk - 1ull; }
+                if (real) {
+                    e = (int)__builtin_ctzll(mk);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(mk) : "s"(e));  // (mk &= mk - 1 is three scalar instructions)
+                }
                 if (i == 0) e0 = e;
                 const unsigned cofs = (unsigned)__builtin_amdgcn_readlane((int)pc, e);
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)pl_, e);

@@ -532,10 +532,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         for (int t = 0; t < n_units; ++t) tot += lds.unit_red[t];  // unit order: bit-reproducible whatever wave took which unit
         reward_out[item] = dead ? NAN : (float)(tot / (cost_d + 1.0));  // rewards.py:31
         if (commit_item) v.rank[env_u] = r + m;
-        if (cnt[0]) {  // (per-item totals, read-add-write: this workgroup is the only one of the launch that owns the item index)
+        if (cnt[0]) {  // (per-item totals: this workgroup is the only one of the launch that owns the item index -- no contention)
             unsigned long long* ic = v.item_counts + 2 * (size_t)item;
-            ic[0] += cnt[0];
-            ic[1] += cnt[1];
+            atomicAdd(ic, cnt[0]);      // (no return value: the wave does not wait for the round trip; nobody else adds to this line)
+            atomicAdd(ic + 1, cnt[1]);
         }
     }
     if (commit_item && lane < m) {

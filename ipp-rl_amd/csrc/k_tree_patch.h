@@ -403,8 +403,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
         }
         if (cnt[0]) {  // (per-item totals: k_step_patch.h)
             unsigned long long* ic = v.item_counts + 2 * (size_t)item;
-            ic[0] += cnt[0];
-            ic[1] += cnt[1];
+            atomicAdd(ic, cnt[0]);      // (no return value: the wave does not wait for the round trip; nobody else adds to this line)
+            atomicAdd(ic + 1, cnt[1]);
         }
     }
 }

@@ -539,7 +539,10 @@ class IPPEngine:
     def streamed_bytes_needed(self) -> int:
         """Of the last streamed_bytes(_detail) read: the bytes on the lanes inside the stored columns' own rectangles (patch engines)."""
         b = C.c_uint64(0)
-        _ffi.check(self._lib.ipp_streamed_bytes_needed(self._h, C.byref(b)))
+        fn = getattr(self._lib, "ipp_streamed_bytes_needed", None) if os.environ.get("IPP_AB_OLD_LIB") else self._lib.ipp_streamed_bytes_needed
+        if fn is None or fn.argtypes is None:  # (tools/ab_libs.sh timing an older build of the engine)
+            return 0
+        _ffi.check(fn(self._h, C.byref(b)))
         return int(b.value)
 
     def profile(self, enable: bool):

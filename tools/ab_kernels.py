@@ -36,11 +36,13 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=60)
     ap.add_argument("--window-rows", type=int, default=12)
+    ap.add_argument("--grid", type=int, default=50)
+    ap.add_argument("--episode-steps", type=int, default=40)
     ap.add_argument("--order", default="natural", help="comma list per variant: natural | desc | asc (items sorted by rank)")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
-    cfg = EngineConfig(x_dim=50, y_dim=50)
-    B, T = args.envs, 40
+    cfg = EngineConfig(x_dim=args.grid, y_dim=args.grid)
+    B, T = args.envs, args.episode_steps
     alts = [float(a) for a in range(5, 15)]
     n_steps = T + args.rounds
     acts = torch.stack([torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, alts)) for t in range(n_steps)]).cuda()
