@@ -351,6 +351,15 @@ int ipp_state_plane(void* engine, int32_t env_id, const float* mean_for_mask, ui
  * overlap ipp_step / ipp_reset of the same engine issued on another stream.
  */
 int ipp_generate_grf(void* engine, int32_t n, const float* white_noise /*[dev]*/, float* gt_out /*[dev]*/, void* stream);
+/*
+ * The same with the white noise drawn inside the generator: field i gets exactly the numbers
+ * ipp_fill_normal_rows(out, 1, n, H * W, row_ids, row_offset, seed, subsequence) would have put into row i (so a ground truth does
+ * not depend on which of the two routes made it), without the H * W floats per field written and read back.  Only where
+ * the engine has such a generator (50x50 and 100x100 grids: k_grf_fft.h); returns -3 elsewhere (use the two calls).
+ *   row_ids [dev] int32[n] or NULL (row i)
+ */
+int ipp_generate_grf_rows(void* engine, int32_t n, const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence,
+                          float* gt_out /*[dev]*/, void* stream);
 
 /*
  * One fused environment step for `n` items.  Replaces, per item:

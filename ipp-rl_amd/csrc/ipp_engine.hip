@@ -615,15 +615,18 @@ void launch_grf_hartley(const View& v, int n, const float* white, const int32_t*
                            (const double*)v.grf_hp, (const double*)v.grf_amp, gt_out);
 }
 
-int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s) {
+int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* env_ids, float* gt_out, hipStream_t s,
+               const GrfNoise* noise = nullptr) {
     const View& v = e->v;
+    if (!white && !(noise && e->grf_tt > 0 && e->grf_fft)) return fail(-1, "in-kernel ground-truth noise needs the fast Hartley path (50x50 / 100x100 grids)");
+    const GrfNoise gn = noise ? *noise : GrfNoise{nullptr, 0, 0, 0};
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
     if (e->grf_tt > 0 && e->grf_fft) {  // n = 50 / 100: fast Hartley transforms in LDS (k_grf_fft.h), same amplitude table
         const int np = 16 * e->grf_tt;
         if (v.W == 100)
-            hipLaunchKernelGGL((k_grf_fft<10>), dim3(n), dim3(512), grf_fft_lds_bytes(100), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out);
+            hipLaunchKernelGGL((k_grf_fft<10>), dim3(n), dim3(512), grf_fft_lds_bytes(100), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn);
         else
-            hipLaunchKernelGGL((k_grf_fft<5>), dim3(n), dim3(256), grf_fft_lds_bytes(50), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out);
+            hipLaunchKernelGGL((k_grf_fft<5>), dim3(n), dim3(256), grf_fft_lds_bytes(50), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1159,6 +1162,18 @@ int ipp_generate_grf(void* engine, int32_t n, const float* white_noise, float* g
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(e->device));
     return launch_grf(e, n, white_noise, e->v.grf_raw2, nullptr, gt_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ipp_generate_grf_rows(void* engine, int32_t n, const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence,
+                          float* gt_out, void* stream) {
+    Engine* e = as_engine(engine);
+    if (!e || !gt_out) return fail(-1, "null argument");
+    if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
+    if (n == 0) return 0;
+    if (!(e->grf_tt > 0 && e->grf_fft)) return fail(-3, "ipp_generate_grf_rows: this grid has no generator that draws its own noise (ipp_fill_normal_rows + ipp_generate_grf)");
+    HIP_TRY(hipSetDevice(e->device));
+    const GrfNoise gn = {row_ids, (long long)row_offset, seed, subsequence};
+    return launch_grf(e, n, nullptr, e->v.grf_raw2, nullptr, gt_out, reinterpret_cast<hipStream_t>(stream), &gn);
 }
 
 int ipp_observe(void* engine, const int32_t* env_ids, int32_t n, const double* action, const float* meas_noise,

@@ -16,6 +16,7 @@
 // Checked against numpy.fft in fp64 to 7e-16 (tools/probes/grf_fft_model.py is this kernel line by line in NumPy).
 #pragma once
 #include "ipp_common.h"
+#include "k_misc.h"
 
 namespace ipp {
 
@@ -116,11 +117,20 @@ __device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const do
     __syncthreads();
 }
 
-// One workgroup per field.  white [n_items][N] float standard normals; amp [n][amp_ld] doubles (the table of k_grf_hartley.h: zero padded,
-// leading dimension amp_ld); result into the env slots (gt_out == nullptr) or gt_out [n_items][N].
+// Where the white noise of a field comes from when it is drawn in the kernel (white == nullptr): the numbers ipp_fill_normal_rows would
+// have written for row id (row_ids ? row_ids[item] : item) + row_offset of a row_len = N fill -- the fill kernel's 4 N bytes per field
+// written and read back (160 MB per step of configs[2], 13 % of its GPU time) do not exist then.
+struct GrfNoise {
+    const int* row_ids;
+    long long row_offset;
+    uint64_t seed, subseq;
+};
+
+// One workgroup per field.  white [n_items][N] float standard normals (or nullptr: GrfNoise); amp [n][amp_ld] doubles (the table of
+// k_grf_hartley.h: zero padded, leading dimension amp_ld); result into the env slots (gt_out == nullptr) or gt_out [n_items][N].
 template <int N1>
 __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const int* __restrict__ env_ids, int n_items, const float* __restrict__ white,
-                                                                  const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out) {
+                                                                  const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out, GrfNoise gn) {
     constexpr int n = N1 * 10, LD = n + 1, NT = (N1 == 10) ? 512 : 256, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
     const int item = blockIdx.x;
@@ -133,12 +143,26 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = n * n;
     {
-        const float2* __restrict__ w2 = reinterpret_cast<const float2*>(white + (size_t)item * N);
-        for (int i = tid; i < N / 2; i += NT) {
-            const float2 wv = w2[i];
-            const int y = i / (n / 2), x = 2 * (i - y * (n / 2));
-            X[y * LD + x] = (double)wv.x;
-            X[y * LD + x + 1] = (double)wv.y;
+        if (white) {
+            const float2* __restrict__ w2 = reinterpret_cast<const float2*>(white + (size_t)item * N);
+            for (int i = tid; i < N / 2; i += NT) {
+                const float2 wv = w2[i];
+                const int y = i / (n / 2), x = 2 * (i - y * (n / 2));
+                X[y * LD + x] = (double)wv.x;
+                X[y * LD + x + 1] = (double)wv.y;
+            }
+        } else {
+            const uint64_t rid = (uint64_t)((gn.row_ids ? (long long)gn.row_ids[item] : (long long)item) + gn.row_offset);
+            constexpr int qpr = (N + 3) / 4;  // counters per row: element e of the row is normal e & 3 of counter rid * qpr + (e >> 2)
+            for (int qc = tid; qc < qpr; qc += NT) {
+                float nrm[4];
+                philox_normal4(rid * (uint64_t)qpr + (uint64_t)qc, gn.subseq, gn.seed, nrm);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int e = 4 * qc + h;
+                    if (e < N) { const int y = e / n; X[y * LD + (e - y * n)] = (double)nrm[h]; }
+                }
+            }
         }
         for (int j = tid; j < n; j += NT) {
             double sn, cs;

@@ -348,6 +348,25 @@ __global__ void k_fill_normal(float* __restrict__ out, uint64_t count, uint64_t 
         if (q * 4 + e < count) out[q * 4 + e] = nrm[e];
 }
 
+// The four normals of counter q: Philox4x32-10 of (q, subsequence) under the key `seed`, two Box-Muller pairs (ONE definition for the
+// fill kernels and for the generators that draw their noise in place, so that a number does not depend on who draws it).
+__device__ __forceinline__ void philox_normal4(uint64_t q, uint64_t subseq, uint64_t seed, float (&nrm)[4]) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)subseq, (uint32_t)(subseq >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u0 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+        const float u1 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.0f * logf(fmaxf(u0, 1e-30f)));
+        float sn, cs;
+        sincosf(6.283185307179586f * u1, &sn, &cs);
+        nrm[2 * h] = rad * cs;
+        nrm[2 * h + 1] = rad * sn;
+    }
+}
+
 // Row-keyed variant: out[p][j][c] (planes x rows x row_len) = normal(seed, subsequence subseq0 + p, counter =
 // (row id of j) * ceil(row_len / 4) + c / 4, element c % 4), row id = (row_ids ? row_ids[j] : j) + row_offset.
 // A row is an env (its ground-truth white noise, its measurement noise of one step): keyed on the GLOBAL env id the
@@ -362,21 +381,12 @@ __global__ void k_fill_normal_rows(float* __restrict__ out, int planes, int rows
     const uint64_t rid = (uint64_t)((row_ids ? (long long)row_ids[j] : (long long)j) + row_offset);
     const uint64_t q = rid * (uint64_t)qpr + (uint64_t)qc;
     const uint64_t subseq = subseq0 + (uint64_t)p;
-    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)subseq, (uint32_t)(subseq >> 32)};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    float nrm[4];
+    philox_normal4(q, subseq, seed, nrm);
     float* o = out + ((size_t)p * rows + j) * row_len + 4 * qc;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float u0 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
-        const float u1 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
-        const float rad = sqrtf(-2.0f * logf(fmaxf(u0, 1e-30f)));
-        float sn, cs;
-        sincosf(6.283185307179586f * u1, &sn, &cs);
-        if (4 * qc + 2 * h < row_len) o[2 * h] = rad * cs;
-        if (4 * qc + 2 * h + 1 < row_len) o[2 * h + 1] = rad * sn;
-    }
+    for (int h = 0; h < 4; ++h)
+        if (4 * qc + h < row_len) o[h] = nrm[h];
 }
 
 }  // namespace ipp

@@ -309,6 +309,20 @@ class IPPEngine:
         self._keep_grf = w
         return out
 
+    def generate_grf_rows(self, n: int, seed: int, subsequence: int, out, row_ids=None, row_offset: int = 0, stream=None) -> bool:
+        """generate_grf with the white noise drawn inside the generator (the numbers normal_rows(.., n_cells, seed, subsequence, row_ids,
+        row_offset) would have written).  Returns False when this grid has no such generator (caller: normal_rows + generate_grf)."""
+        torch = _torch()
+        ids = self._dev(row_ids, torch.int32)
+        st = self.stream if stream is None else C.c_void_p(stream.cuda_stream)
+        rc = self._lib.ipp_generate_grf_rows(self._h, int(n), self._ptr(ids), int(row_offset), int(seed) & (2 ** 64 - 1),
+                                             int(subsequence) & (2 ** 64 - 1), self._ptr(out), st)
+        if rc == -3:
+            return False
+        _ffi.check(rc)
+        self._keep_grf = ids
+        return True
+
     def step(self, actions, prev_actions, env_ids=None, dst_ids=None, meas_noise=None, *, cov_only=False,
              predict_only=False, adaptive=True, use_flight_time=True, given_observation=False, reward_out=None,
              status_out=None, update_prev=False, reset_src=None, reset_gt=None, init_action=None):

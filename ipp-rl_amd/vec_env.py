@@ -141,6 +141,7 @@ class VecIPPEnv:
         # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
         # for the resets after step t+1 is started at the beginning of step t, so it has two steps to finish
         self._side = torch.cuda.Stream(device=dev) if stagger else None
+        self._grf_rows = None if os.environ.get("IPP_GRF_ROWS", "1") != "0" else False  # (False: the engine has no in-generator noise / A/B)
         # Staging in BLOCKS of K steps: the fields of all resets of block b + 1 are generated while block b runs, into one of
         # two buffer sets, and the streams meet ONCE per block (main waits for the block's `ready` event before its first step
         # and records `free` behind its last; the side stream waits for `free` before it refills the set).  With an event
@@ -277,6 +278,15 @@ class VecIPPEnv:
                 if n == 0:
                     continue
                 buf = set_ * K + j
+                # the envs of a scheduled reset share their episode index: the generator draws the white noise itself where it can
+                # (50x50 / 100x100: no [n, N] noise array written and read back), else fill + generate
+                epi = self.episode[self._reset_ids_host[p]]
+                if self._grf_rows is not False and len(epi) and np.all(epi == epi[0]):
+                    self._grf_rows = self.engine.generate_grf_rows(n, self.seed, self.GT_STREAM + int(epi[0]), self._staged[buf][:n],
+                                                                   row_ids=self._reset_ids_by_phase[p], row_offset=self.env_id_offset,
+                                                                   stream=self._side)
+                    if self._grf_rows:
+                        continue
                 white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white[buf][:n])
                 self.engine.generate_grf(white, out=self._staged[buf][:n], stream=self._side)
             self._blk_ready[set_].record(self._side)

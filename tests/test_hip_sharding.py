@@ -316,3 +316,30 @@ def test_pipelined_step_kernel_matches_default_and_oracle(monkeypatch):
         prev = a
     assert np.max(np.abs(host(pipe.engine.read_mean(7)) - st.mean)) < TOL
     assert np.max(np.abs(host(pipe.engine.read_diag(7)) - np.diag(st.P))) < TOL
+
+
+@pytest.mark.parametrize("n", [50, 100, 64])
+def test_generator_drawn_noise_equals_fill_then_generate(n):
+    """ipp_generate_grf_rows (white noise drawn inside the fast Hartley generator: 50x50 / 100x100) against ipp_fill_normal_rows +
+    ipp_generate_grf: the same fields bit for bit (one Philox definition, keyed on the global row id), with and without row ids and an
+    offset; grids without such a generator report it (-3 -> False) and the batched driver falls back to the two calls."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    eng = IPPEngine(EngineConfig(x_dim=n, y_dim=n), capacity=8, state="factor", rank_cap=16)
+    N = n * n
+    ids = torch.tensor([5, 0, 7, 3, 3], dtype=torch.int32, device="cuda")
+    for row_ids, off in ((None, 0), (ids, 0), (ids, 123456789)):
+        k = 5
+        white = torch.empty((k, N), dtype=torch.float32, device="cuda")
+        eng.normal_rows(white, N, 77, (1 << 40) + 9, row_ids=row_ids, row_offset=off)
+        ref = eng.generate_grf(white)
+        out = torch.empty((k, N), dtype=torch.float32, device="cuda")
+        ok = eng.generate_grf_rows(k, 77, (1 << 40) + 9, out, row_ids=row_ids, row_offset=off)
+        torch.cuda.synchronize()
+        if n == 64:
+            assert ok is False
+            return
+        assert ok is True
+        assert torch.equal(out, ref)
+    assert torch.equal(out[3], out[4]) and not torch.equal(out[0], out[1])  # (rows 3 and 4 share an id)
