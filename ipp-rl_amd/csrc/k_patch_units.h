@@ -27,6 +27,12 @@
 #ifndef IPP_UNIT_PWSTRIDE
 #define IPP_UNIT_PWSTRIDE 0  // A/B: enumerate the units over the patch stride pw instead of the rectangle's own width
 #endif
+#ifndef IPP_UNIT_PIPE
+#define IPP_UNIT_PIPE 0      // 1: whole request groups software-pipelined (2 KP rows in flight per wave)
+#endif
+#ifndef IPP_UNIT_STAGED
+#define IPP_UNIT_STAGED 0    // 1: the bookkeeping of a request group stage by stage over its rows (independent instructions per stage)
+#endif
 #ifndef IPP_UNIT_NOCOUNT
 #define IPP_UNIT_NOCOUNT 0   // A/B: no in-rectangle count (roofline.necessary_bytes reads 0)
 #endif
@@ -230,6 +236,50 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
             rowv uu[N];
             float qr[N];
             int e0 = 0;
+#if IPP_UNIT_STAGED
+            // stage by stage over the N rows of the group instead of row by row: every stage is N independent instructions, so a wave
+            // that has the SIMD to itself (the tail of a launch: the heaviest items) does not wait on the chain
+            // s_ff1 -> v_readlane -> v_pk_sub -> v_pk_min -> v_cmp -> v_cndmask -> buffer_load of ONE row at a time
+            int es[N];
+            unsigned cofs_[N], lo_[N], ex_[N];
+            bool okb[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool real = FULL || i < nreal;
+                int e = e0;
+                if (real) { e = (int)__builtin_ctzll(mk); asm("s_bitset0_b64 %0, %1" : "+s"(mk) : "s"(e)); }
+                if (i == 0) e0 = e;
+                es[i] = e;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                cofs_[i] = (unsigned)__builtin_amdgcn_readlane((int)pc, es[i]);
+                lo_[i] = (unsigned)__builtin_amdgcn_readlane((int)pl_, es[i]);
+                ex_[i] = (unsigned)__builtin_amdgcn_readlane((int)pe, es[i]);
+            }
+            us2 dd[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) dd[i] = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo_[i]);
+            us2 mm[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) mm[i] = __builtin_elementwise_min(dd[i], __builtin_bit_cast(us2, ex_[i]));
+#pragma unroll
+            for (int i = 0; i < N; ++i) okb[i] = __builtin_bit_cast(unsigned, mm[i]) == __builtin_bit_cast(unsigned, dd[i]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool real = FULL || i < nreal;
+                const unsigned f4 = real ? flat4 : 0xffffffffu;
+#if !IPP_UNIT_NOCOUNT
+                if (real) in_rect += __popcll(__ballot(okb[i]));
+#endif
+                uu[i] = io.row_load(cofs_[i], okb[i] ? f4 : 0xffffffffu);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) qr[i] = lds.rec[(size_t)(page * kWave + es[i]) * kPatchRec + (lane & 15)];
+            __builtin_amdgcn_sched_barrier(0);
+            fma_rows(n_tag, uu, qr);
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const bool real = FULL || i < nreal;  // (wave-uniform)
@@ -259,12 +309,49 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
             __builtin_amdgcn_sched_barrier(0);  // all N requests leave before the first wait
             fma_rows(n_tag, uu, qr);
         };
+        // (IPP_UNIT_PIPE) whole groups software-pipelined: the requests of group g + 1 leave before the FMAs of group g, so a wave keeps
+        // 2 KP rows in flight and the round trip of a group hides behind the arithmetic of its predecessor
+        auto issue_full = [&](unsigned long long& mk, int page, rowv (&uu)[KP], float (&qr)[KP]) {
+            const unsigned pc = page ? mcofs[1] : mcofs[0], pl_ = page ? mlo[1] : mlo[0], pe = page ? mex[1] : mex[0];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const int e = (int)__builtin_ctzll(mk);
+                asm("s_bitset0_b64 %0, %1" : "+s"(mk) : "s"(e));
+                const unsigned cofs = (unsigned)__builtin_amdgcn_readlane((int)pc, e);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)pl_, e);
+                const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)pe, e);
+                const us2 d = __builtin_bit_cast(us2, lpos) - __builtin_bit_cast(us2, lo);
+                const bool ok = __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2, ex))) == __builtin_bit_cast(unsigned, d);
+#if !IPP_UNIT_NOCOUNT
+                in_rect += __popcll(__ballot(ok));
+#endif
+                uu[i] = io.row_load(cofs, ok ? flat4 : 0xffffffffu);
+                qr[i] = lds.rec[(size_t)(page * kWave + e) * kPatchRec + (lane & 15)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
 #pragma unroll 1
         for (int page = 0; page < 2; ++page) {
             unsigned long long mk = page ? pmask[1] : pmask[0];
             int left = __popcll(mk);
             typedef std::integral_constant<int, KP> n_kp;
+#if IPP_UNIT_PIPE
+            if (left >= KP) {
+                rowv ua[KP], ub[KP];
+                float qa[KP], qb[KP];
+                issue_full(mk, page, ua, qa); left -= KP;
+                for (;;) {
+                    if (left < KP) { fma_rows(n_kp{}, ua, qa); break; }
+                    issue_full(mk, page, ub, qb); left -= KP;
+                    fma_rows(n_kp{}, ua, qa);
+                    if (left < KP) { fma_rows(n_kp{}, ub, qb); break; }
+                    issue_full(mk, page, ua, qa); left -= KP;
+                    fma_rows(n_kp{}, ub, qb);
+                }
+            }
+#else
             for (; left >= KP; left -= KP) fast_group(mk, page, KP, n_kp{}, std::true_type{});
+#endif
             if (left > 0) {
                 if (KP > 8 && left > 8) fast_group(mk, page, left, n_kp{}, std::false_type{});
                 else if (KP > 4 && left > 4) fast_group(mk, page, left, std::integral_constant<int, (KP < 8 ? KP : 8)>{}, std::false_type{});

@@ -113,7 +113,11 @@ __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int
     h.ny = (h.h - 1) / h.rf + 1;
     h.m = h.nx * h.ny;                                                            // mappings.py:125-126
     h.f = h.w * h.h;
+#ifdef IPP_HDR_ABLATE
+    h.nv_d = v.coeff_a * 0.8; with_cost = false;  // (timing experiment: no exp, no flight time)
+#else
     h.nv_d = v.coeff_a * (1.0 - exp(-v.coeff_b * az));                            // sensor_models.py:30
+#endif
     h.nv = (float)h.nv_d;
     double cost = 0.0;
     if (with_cost) {
@@ -872,7 +876,11 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
     if (lane < f) sub[lane] = (double)gt_f;
     double* wyt = L;           // [orows][h.h]   (the L / Li scratch is not used by solve_wave_fast)
     double* wxt = L + 2 * MC;  // [ocols][h.w]
+#ifdef IPP_OBS_ABLATE
+    if (false) {
+#else
     if (h.rf > 1) {
+#endif
         const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
         for (int idx = lane; idx < orows * h.h; idx += kWave) wyt[idx] = area_weight(h.h, orows, idx / h.h, idx % h.h);
         for (int idx = lane; idx < ocols * h.w; idx += kWave) wxt[idx] = area_weight(h.w, ocols, idx / h.w, idx % h.w);
@@ -881,7 +889,11 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
     if (lane < m) {
         const Block myb = block_of(lane, h.nx, h.rf, h.w, h.h);
         double val;
+#ifdef IPP_OBS_ABLATE
+        if (true) {
+#else
         if (h.rf == 1) {
+#endif
             val = sub[lane];
         } else {
             const int ocols = (h.h + h.rf - 1) / h.rf;
