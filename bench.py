@@ -617,13 +617,14 @@ def main(argv=None):
     B, T = hi - lo, args.episode_steps
 
     import contextlib
+
     prio_ctx = torch.cuda.stream(torch.cuda.Stream(device=device, priority=args.step_priority)) if args.step_priority else contextlib.nullcontext()
     with prio_ctx:
-      rec, cfg = run_env_workload(torch, ranks, device, grid=args.grid, envs_local=B, env_lo=lo, total_envs=total_envs,
-                                episode_steps=T, state=args.state, window_rows=args.window_rows,
-                                shuffle_prior=args.shuffle_prior, tile_threads=args.tile_threads,
-                                predict_only=args.predict_only, fused_resets=args.fused_resets, steps=args.steps,
-                                warmup=args.warmup, regions=args.regions, parts=args.parts)
+        rec, cfg = run_env_workload(torch, ranks, device, grid=args.grid, envs_local=B, env_lo=lo, total_envs=total_envs,
+                                    episode_steps=T, state=args.state, window_rows=args.window_rows,
+                                    shuffle_prior=args.shuffle_prior, tile_threads=args.tile_threads,
+                                    predict_only=args.predict_only, fused_resets=args.fused_resets, steps=args.steps,
+                                    warmup=args.warmup, regions=args.regions, parts=args.parts)
     if rank == 0:
         traffic, traffic_source = pmc_traffic(rec["kernel"], workload_key(args))
         out = {
