@@ -624,9 +624,9 @@ int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* 
     if (e->grf_tt > 0 && e->grf_fft) {  // n = 50 / 100: fast Hartley transforms in LDS (k_grf_fft.h), same amplitude table
         const int np = 16 * e->grf_tt;
         if (v.W == 100)
-            hipLaunchKernelGGL((k_grf_fft<10>), dim3(n), dim3(512), grf_fft_lds_bytes(100), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn);
+            hipLaunchKernelGGL((k_grf_fft<10>), dim3(n), dim3(512), grf_fft_lds_bytes(100), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn, (const double2*)v.grf_cs);
         else
-            hipLaunchKernelGGL((k_grf_fft<5>), dim3(n), dim3(256), grf_fft_lds_bytes(50), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn);
+            hipLaunchKernelGGL((k_grf_fft<5>), dim3(n), dim3(256), grf_fft_lds_bytes(50), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn, (const double2*)v.grf_cs);
         HIP_TRY(hipGetLastError());
         return 0;
     }

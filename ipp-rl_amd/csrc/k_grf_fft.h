@@ -12,7 +12,8 @@
 //   A  thread (pair f, column c < 10):  FFT-N1 over the elements c + 10 r, times the twiddles w_n^(c k), written back in place
 //   B  thread (pair f, row k < N1):     FFT-10 over the elements 10 k + c, output q is X[k + N1 q]
 //   C  thread (pair f, ...):            the Hartley combination of the elements j and n - j above (and the amplitude, once)
-// ~0.7 MFLOP per field instead of 10, all in place on ONE n x (n + 1) fp64 array in LDS (81 KB at n = 100, 20 KB at n = 50), ~90 VGPRs.
+// ~0.7 MFLOP per field instead of 10, all in place on ONE fp64 array in LDS (n = 100: 100 x 100, exactly 80 KB: two fields per CU; n = 50:
+// 50 x 51, 20 KB), twiddles from the (cos, sin) table of k_grf_dft.h, ~90 VGPRs.
 // Checked against numpy.fft in fp64 to 7e-16 (tools/probes/grf_fft_model.py is this kernel line by line in NumPy).
 #pragma once
 #include "ipp_common.h"
@@ -20,7 +21,10 @@
 
 namespace ipp {
 
-__host__ __device__ inline size_t grf_fft_lds_bytes(int n) { return ((size_t)n * (n + 1) + 2 * (size_t)n + 2 * 16) * 8 + 64; }
+// n x LD fp64 array + min / max scratch.  n = 100: LD = n, exactly 80 KB = half of a CU's LDS, so that TWO fields are resident per CU (the
+// kernel is bound by LDS round trips between its sixteen barriers: a second workgroup fills them); n = 50: LD = n + 1 (seven per CU either way).
+__host__ __device__ inline int grf_fft_ld(int n) { return n == 100 ? n : n + 1; }
+__host__ __device__ inline size_t grf_fft_lds_bytes(int n) { return n == 100 ? (size_t)80 * 1024 : ((size_t)n * (n + 1) + 2 * 16) * 8 + 64; }
 
 // forward DFT of 5 complex numbers (re / im arrays, in place)
 __device__ __forceinline__ void fft5(double (&re)[5], double (&im)[5]) {
@@ -63,7 +67,7 @@ __device__ __forceinline__ void fft_small(double (&re)[N], double (&im)[N]) {
 // One Hartley pass: X <- DHT along `axis` of every vector (axis 1: the rows of X, axis 0: its columns), times amp on the way out when
 // amp != nullptr.  element j of vector v sits at X[v * sv + j * sj].
 template <int N1, int NT>
-__device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const double* tw, const double* __restrict__ amp, int amp_ld, int tid) {
+__device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const double2* __restrict__ tw, const double* __restrict__ amp, int amp_ld, int tid) {
     constexpr int N2 = 10, n = N1 * N2;
     const int f = tid / 10, c = tid - 10 * f;  // pair of vectors, position inside the group of ten threads
     const bool on = f < n / 2;
@@ -77,7 +81,8 @@ __device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const do
         fft_small<N1>(re, im);
 #pragma unroll
         for (int k = 0; k < N1; ++k) {
-            const double wr = tw[2 * (c * k)], wi = tw[2 * (c * k) + 1];  // (c k < n)
+            const double2 t = tw[c * k];  // (cos, sin)(2 pi c k / n), c k < n: w_n^(c k) = cos - i sin
+            const double wr = t.x, wi = -t.y;
             x0[(c + N2 * k) * sj] = re[k] * wr - im[k] * wi;
             x1[(c + N2 * k) * sj] = re[k] * wi + im[k] * wr;
         }
@@ -130,16 +135,18 @@ struct GrfNoise {
 // k_grf_hartley.h: zero padded, leading dimension amp_ld); result into the env slots (gt_out == nullptr) or gt_out [n_items][N].
 template <int N1>
 __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const int* __restrict__ env_ids, int n_items, const float* __restrict__ white,
-                                                                  const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out, GrfNoise gn) {
-    constexpr int n = N1 * 10, LD = n + 1, NT = (N1 == 10) ? 512 : 256, NW = NT / 64;
+                                                                  const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out, GrfNoise gn,
+                                                                  const double2* __restrict__ tw) {
+    constexpr int n = N1 * 10, LD = (N1 == 10) ? n : n + 1, NT = (N1 == 10) ? 512 : 256, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
     if (env < 0 || env >= v.cap) return;
     double* X = reinterpret_cast<double*>(smem_gf);
-    double* tw = X + (size_t)n * LD;  // [n] (cos, -sin)(2 pi j / n)
-    double* red = tw + 2 * n;         // [2][16] min / max per wave
+    // min / max per wave: behind the array (n = 50) or, at n = 100 where the array fills the workgroup's 80 KB, in its first row once the
+    // field has been reduced into registers (see below)
+    double* red = (N1 == 10) ? X : X + (size_t)n * LD;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = n * n;
     {
@@ -164,29 +171,30 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
                 }
             }
         }
-        for (int j = tid; j < n; j += NT) {
-            double sn, cs;
-            sincos(-6.283185307179586476925 * (double)j / (double)n, &sn, &cs);
-            tw[2 * j] = cs; tw[2 * j + 1] = sn;
-        }
     }
     __syncthreads();
     grf_fft_pass<N1, NT>(X, LD, 1, tw, nullptr, 0, tid);      // rows:    w H
     grf_fft_pass<N1, NT>(X, 1, LD, tw, amp, amp_ld, tid);     // columns: amp .* (H w H)
     grf_fft_pass<N1, NT>(X, LD, 1, tw, nullptr, 0, tid);
     grf_fft_pass<N1, NT>(X, 1, LD, tw, nullptr, 0, tid);      // field (x constants)
-    // ---- min-max normalisation to [0, 1] (ground_truths.py:31), fp64 like the reference
+    // ---- min-max normalisation to [0, 1] (ground_truths.py:31), fp64 like the reference; the field moves into registers first (the
+    // cross-wave exchange of the extrema reuses the array's first row)
+    constexpr int PER = (n * n + NT - 1) / NT;
+    double val[PER];
     double lo = INFINITY, hi = -INFINITY;
-    for (int i = tid; i < N; i += NT) {
-        const int y = i / n, x = i - y * n;
-        const double f = X[y * LD + x];
-        lo = fmin(lo, f); hi = fmax(hi, f);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = tid + q * NT;
+        const int y = min(i, N - 1) / n, x = min(i, N - 1) - y * n;
+        val[q] = X[y * LD + x];
+        if (i < N) { lo = fmin(lo, val[q]); hi = fmax(hi, val[q]); }
     }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
         lo = fmin(lo, __shfl_xor(lo, off));
         hi = fmax(hi, __shfl_xor(hi, off));
     }
+    __syncthreads();  // (every thread holds its cells)
     if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
     __syncthreads();
     double dlo = red[0], dhi = red[16];
@@ -194,9 +202,10 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
     for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[16 + w]); }
     const double span = dhi - dlo;
     float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
-    for (int i = tid; i < N; i += NT) {
-        const int y = i / n, x = i - y * n;
-        gt[i] = (float)((X[y * LD + x] - dlo) / span);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = tid + q * NT;
+        if (i < N) gt[i] = (float)((val[q] - dlo) / span);
     }
     if (!gt_out)
         for (int i = N + tid; i < v.Npad; i += NT) gt[i] = 0.f;
