@@ -44,7 +44,7 @@ ALTITUDES = [float(a) for a in range(5, 15)]  # 10 levels, min 5, max 14, spacin
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--steps", type=int, default=200)  # (a region of 200 steps is 20 ms: past the clock ramp that spread 80-step regions by 17 %)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
     ap.add_argument("--envs-total", type=int, default=0,

@@ -84,6 +84,7 @@ struct Engine {
     bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
     int grf_tt = 0;        // > 0: even square grids up to 128: k_grf_hartley<grf_tt> (fp64 MFMA GEMMs)
     bool grf_fft = false;  // ... and n = 50 / 100: k_grf_fft (fast Hartley transforms) on the same amplitude table
+    bool grf_fp64 = false; // ... in fp64 (IPP_GRF_FP64=1) instead of fp32
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
     int lut_rows = 0;  // workgroup-per-item factor kernels: rows |drow| of the prior table kept in LDS
@@ -623,10 +624,15 @@ int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* 
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
     if (e->grf_tt > 0 && e->grf_fft) {  // n = 50 / 100: fast Hartley transforms in LDS (k_grf_fft.h), same amplitude table
         const int np = 16 * e->grf_tt;
-        if (v.W == 100)
-            hipLaunchKernelGGL((k_grf_fft<10>), dim3(n), dim3(512), grf_fft_lds_bytes(100), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn, (const double2*)v.grf_cs);
-        else
-            hipLaunchKernelGGL((k_grf_fft<5>), dim3(n), dim3(256), grf_fft_lds_bytes(50), s, v, env_ids, n, white, (const double*)v.grf_amp, np, gt_out, gn, (const double2*)v.grf_cs);
+        const double* ampt = (const double*)v.grf_amp;
+        const double2* twt = (const double2*)v.grf_cs;
+        if (e->grf_fp64) {
+            if (v.W == 100) hipLaunchKernelGGL((k_grf_fft<10, double>), dim3(n), dim3(512), grf_fft_lds_bytes(100, 8), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
+            else hipLaunchKernelGGL((k_grf_fft<5, double>), dim3(n), dim3(256), grf_fft_lds_bytes(50, 8), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
+        } else {
+            if (v.W == 100) hipLaunchKernelGGL((k_grf_fft<10, float>), dim3(n), dim3(512), grf_fft_lds_bytes(100, 4), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
+            else hipLaunchKernelGGL((k_grf_fft<5, float>), dim3(n), dim3(256), grf_fft_lds_bytes(50, 4), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -971,8 +977,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                 if (n == 100) (void)hipFuncSetAttribute((const void*)&k_grf_hartley<7, 8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
                 e->grf_fft = (n == 50 || n == 100);
                 if (const char* gf = getenv("IPP_GRF_FFT")) e->grf_fft = e->grf_fft && atoi(gf) != 0;  // A/B: the GEMM form
-                (void)hipFuncSetAttribute((const void*)&k_grf_fft<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(100));
-                (void)hipFuncSetAttribute((const void*)&k_grf_fft<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(50));
+                if (const char* g64 = getenv("IPP_GRF_FP64")) e->grf_fp64 = atoi(g64) != 0;
+                (void)hipFuncSetAttribute((const void*)&k_grf_fft<10, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(100, 8));
+                (void)hipFuncSetAttribute((const void*)&k_grf_fft<5, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(50, 8));
             }
         }
         if (e->grf_dft) {

@@ -24,18 +24,21 @@ namespace ipp {
 // n x LD fp64 array + min / max scratch.  n = 100: LD = n, exactly 80 KB = half of a CU's LDS, so that TWO fields are resident per CU (the
 // kernel is bound by LDS round trips between its sixteen barriers: a second workgroup fills them); n = 50: LD = n + 1 (seven per CU either way).
 __host__ __device__ inline int grf_fft_ld(int n) { return n == 100 ? n : n + 1; }
-__host__ __device__ inline size_t grf_fft_lds_bytes(int n) { return n == 100 ? (size_t)80 * 1024 : ((size_t)n * (n + 1) + 2 * 16) * 8 + 64; }
+__host__ __device__ inline size_t grf_fft_lds_bytes(int n, int real_bytes = 8) {
+    return n == 100 ? (size_t)10 * 1024 * real_bytes : ((size_t)n * (n + 1) + 2 * 16) * real_bytes + 64;
+}
 
-// forward DFT of 5 complex numbers (re / im arrays, in place)
-__device__ __forceinline__ void fft5(double (&re)[5], double (&im)[5]) {
-    constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos 72, cos 144 degrees
-    constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin 72, sin 144 degrees
-    const double t1r = re[1] + re[4], t1i = im[1] + im[4], t2r = re[2] + re[3], t2i = im[2] + im[3];
-    const double t3r = re[1] - re[4], t3i = im[1] - im[4], t4r = re[2] - re[3], t4i = im[2] - im[3];
-    const double m1r = re[0] + c1 * t1r + c2 * t2r, m1i = im[0] + c1 * t1i + c2 * t2i;
-    const double m2r = re[0] + c2 * t1r + c1 * t2r, m2i = im[0] + c2 * t1i + c1 * t2i;
-    const double u1r = s1 * t3r + s2 * t4r, u1i = s1 * t3i + s2 * t4i;
-    const double u2r = s2 * t3r - s1 * t4r, u2i = s2 * t3i - s1 * t4i;
+// forward DFT of 5 complex numbers (re / im arrays, in place); T = double, or float (IPP_GRF_FP32: see k_grf_fft)
+template <typename T>
+__device__ __forceinline__ void fft5(T (&re)[5], T (&im)[5]) {
+    constexpr T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos 72, cos 144 degrees
+    constexpr T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin 72, sin 144 degrees
+    const T t1r = re[1] + re[4], t1i = im[1] + im[4], t2r = re[2] + re[3], t2i = im[2] + im[3];
+    const T t3r = re[1] - re[4], t3i = im[1] - im[4], t4r = re[2] - re[3], t4i = im[2] - im[3];
+    const T m1r = re[0] + c1 * t1r + c2 * t2r, m1i = im[0] + c1 * t1i + c2 * t2i;
+    const T m2r = re[0] + c2 * t1r + c1 * t2r, m2i = im[0] + c2 * t1i + c1 * t2i;
+    const T u1r = s1 * t3r + s2 * t4r, u1i = s1 * t3i + s2 * t4i;
+    const T u2r = s2 * t3r - s1 * t4r, u2i = s2 * t3i - s1 * t4i;
     re[0] += t1r + t2r; im[0] += t1i + t2i;
     // X1 = m1 - i u1, X4 = m1 + i u1, X2 = m2 - i u2, X3 = m2 + i u2     (-i (ur + i ui) = ui - i ur)
     re[1] = m1r + u1i; im[1] = m1i - u1r;
@@ -44,45 +47,46 @@ __device__ __forceinline__ void fft5(double (&re)[5], double (&im)[5]) {
     re[3] = m2r - u2i; im[3] = m2i + u2r;
 }
 // forward DFT of 10 complex numbers: two FFT-5 on the even / odd elements + the radix-2 butterflies
-__device__ __forceinline__ void fft10(double (&re)[10], double (&im)[10]) {
-    double er[5] = {re[0], re[2], re[4], re[6], re[8]}, ei[5] = {im[0], im[2], im[4], im[6], im[8]};
-    double qr[5] = {re[1], re[3], re[5], re[7], re[9]}, qi[5] = {im[1], im[3], im[5], im[7], im[9]};
+template <typename T>
+__device__ __forceinline__ void fft10(T (&re)[10], T (&im)[10]) {
+    T er[5] = {re[0], re[2], re[4], re[6], re[8]}, ei[5] = {im[0], im[2], im[4], im[6], im[8]};
+    T qr[5] = {re[1], re[3], re[5], re[7], re[9]}, qi[5] = {im[1], im[3], im[5], im[7], im[9]};
     fft5(er, ei);
     fft5(qr, qi);
     // w_10^k = exp(-2 pi i k / 10), k = 0 .. 4
-    constexpr double wr[5] = {1.0, 0.80901699437494742410, 0.30901699437494742410, -0.30901699437494742410, -0.80901699437494742410};
-    constexpr double wi[5] = {0.0, -0.58778525229247312917, -0.95105651629515357212, -0.95105651629515357212, -0.58778525229247312917};
+    constexpr T wr[5] = {(T)1.0, (T)0.80901699437494742410, (T)0.30901699437494742410, (T)-0.30901699437494742410, (T)-0.80901699437494742410};
+    constexpr T wi[5] = {(T)0.0, (T)-0.58778525229247312917, (T)-0.95105651629515357212, (T)-0.95105651629515357212, (T)-0.58778525229247312917};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const double tr = wr[k] * qr[k] - wi[k] * qi[k], ti = wr[k] * qi[k] + wi[k] * qr[k];
+        const T tr = wr[k] * qr[k] - wi[k] * qi[k], ti = wr[k] * qi[k] + wi[k] * qr[k];
         re[k] = er[k] + tr; im[k] = ei[k] + ti;
         re[k + 5] = er[k] - tr; im[k + 5] = ei[k] - ti;
     }
 }
-template <int N>
-__device__ __forceinline__ void fft_small(double (&re)[N], double (&im)[N]) {
+template <int N, typename T>
+__device__ __forceinline__ void fft_small(T (&re)[N], T (&im)[N]) {
     if constexpr (N == 5) fft5(re, im); else fft10(re, im);
 }
 
 // One Hartley pass: X <- DHT along `axis` of every vector (axis 1: the rows of X, axis 0: its columns), times amp on the way out when
 // amp != nullptr.  element j of vector v sits at X[v * sv + j * sj].
-template <int N1, int NT>
-__device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const double2* __restrict__ tw, const double* __restrict__ amp, int amp_ld, int tid) {
+template <int N1, int NT, typename T>
+__device__ __forceinline__ void grf_fft_pass(T* X, int sv, int sj, const double2* __restrict__ tw, const double* __restrict__ amp, int amp_ld, int tid) {
     constexpr int N2 = 10, n = N1 * N2;
     const int f = tid / 10, c = tid - 10 * f;  // pair of vectors, position inside the group of ten threads
     const bool on = f < n / 2;
-    double* x0 = X + (size_t)(2 * f) * sv;  // real part: vector 2 f, imaginary part: vector 2 f + 1
-    double* x1 = x0 + sv;
+    T* x0 = X + (size_t)(2 * f) * sv;  // real part: vector 2 f, imaginary part: vector 2 f + 1
+    T* x1 = x0 + sv;
     // ---- A: FFT-N1 over the elements c + 10 r, twiddles w_n^(c k)
     if (on) {
-        double re[N1], im[N1];
+        T re[N1], im[N1];
 #pragma unroll
         for (int r = 0; r < N1; ++r) { re[r] = x0[(c + N2 * r) * sj]; im[r] = x1[(c + N2 * r) * sj]; }
-        fft_small<N1>(re, im);
+        fft_small<N1, T>(re, im);
 #pragma unroll
         for (int k = 0; k < N1; ++k) {
             const double2 t = tw[c * k];  // (cos, sin)(2 pi c k / n), c k < n: w_n^(c k) = cos - i sin
-            const double wr = t.x, wi = -t.y;
+            const T wr = (T)t.x, wi = (T)-t.y;
             x0[(c + N2 * k) * sj] = re[k] * wr - im[k] * wi;
             x1[(c + N2 * k) * sj] = re[k] * wi + im[k] * wr;
         }
@@ -90,7 +94,7 @@ __device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const do
     __syncthreads();
     // ---- B: FFT-10 over the elements 10 k + c (threads k < N1), output q is X[k + N1 q]
     {
-        double re[N2], im[N2];
+        T re[N2], im[N2];
         const bool onb = on && c < N1;
         if (onb) {
 #pragma unroll
@@ -108,11 +112,11 @@ __device__ __forceinline__ void grf_fft_pass(double* X, int sv, int sj, const do
     if (on) {
         for (int j = c; j <= n / 2; j += 10) {
             const int jj = (j == 0) ? 0 : n - j;
-            const double a = x0[j * sj], b = x1[j * sj], cc = x0[jj * sj], d = x1[jj * sj];
-            double xj = a + cc - b + d, yj = b + d + a - cc, xjj = cc + a - d + b, yjj = d + b + cc - a;
+            const T a = x0[j * sj], b = x1[j * sj], cc = x0[jj * sj], d = x1[jj * sj];
+            T xj = a + cc - b + d, yj = b + d + a - cc, xjj = cc + a - d + b, yjj = d + b + cc - a;
             if (amp) {  // amp is even in both indices and symmetric: amp[v][j] whichever the axis
-                const double a0j = amp[(size_t)(2 * f) * amp_ld + j], a1j = amp[(size_t)(2 * f + 1) * amp_ld + j];
-                const double a0jj = amp[(size_t)(2 * f) * amp_ld + jj], a1jj = amp[(size_t)(2 * f + 1) * amp_ld + jj];
+                const T a0j = (T)amp[(size_t)(2 * f) * amp_ld + j], a1j = (T)amp[(size_t)(2 * f + 1) * amp_ld + j];
+                const T a0jj = (T)amp[(size_t)(2 * f) * amp_ld + jj], a1jj = (T)amp[(size_t)(2 * f + 1) * amp_ld + jj];
                 xj *= a0j; yj *= a1j; xjj *= a0jj; yjj *= a1jj;
             }
             x0[j * sj] = xj; x1[j * sj] = yj;
@@ -133,7 +137,10 @@ struct GrfNoise {
 
 // One workgroup per field.  white [n_items][N] float standard normals (or nullptr: GrfNoise); amp [n][amp_ld] doubles (the table of
 // k_grf_hartley.h: zero padded, leading dimension amp_ld); result into the env slots (gt_out == nullptr) or gt_out [n_items][N].
-template <int N1>
+// T = float (default): the transforms in fp32 -- inputs and output are fp32 anyway and the field is min-max normalised: 6e-7 of the
+// normalised field against numpy's fp64 path (bar 1e-5, tests/test_hip_big_grids.py), half the LDS (four 100x100 fields per CU) and
+// plain-rate arithmetic; T = double (IPP_GRF_FP64=1) keeps the reference's precision end to end.
+template <int N1, typename T>
 __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const int* __restrict__ env_ids, int n_items, const float* __restrict__ white,
                                                                   const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out, GrfNoise gn,
                                                                   const double2* __restrict__ tw) {
@@ -143,10 +150,10 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
     if (item >= n_items) return;
     const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
     if (env < 0 || env >= v.cap) return;
-    double* X = reinterpret_cast<double*>(smem_gf);
+    T* X = reinterpret_cast<T*>(smem_gf);
     // min / max per wave: behind the array (n = 50) or, at n = 100 where the array fills the workgroup's 80 KB, in its first row once the
     // field has been reduced into registers (see below)
-    double* red = (N1 == 10) ? X : X + (size_t)n * LD;
+    T* red = (N1 == 10) ? X : X + (size_t)n * LD;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = n * n;
     {
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
             for (int i = tid; i < N / 2; i += NT) {
                 const float2 wv = w2[i];
                 const int y = i / (n / 2), x = 2 * (i - y * (n / 2));
-                X[y * LD + x] = (double)wv.x;
-                X[y * LD + x + 1] = (double)wv.y;
+                X[y * LD + x] = (T)wv.x;
+                X[y * LD + x + 1] = (T)wv.y;
             }
         } else {
             const uint64_t rid = (uint64_t)((gn.row_ids ? (long long)gn.row_ids[item] : (long long)item) + gn.row_offset);
@@ -167,45 +174,45 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int e = 4 * qc + h;
-                    if (e < N) { const int y = e / n; X[y * LD + (e - y * n)] = (double)nrm[h]; }
+                    if (e < N) { const int y = e / n; X[y * LD + (e - y * n)] = (T)nrm[h]; }
                 }
             }
         }
     }
     __syncthreads();
-    grf_fft_pass<N1, NT>(X, LD, 1, tw, nullptr, 0, tid);      // rows:    w H
-    grf_fft_pass<N1, NT>(X, 1, LD, tw, amp, amp_ld, tid);     // columns: amp .* (H w H)
-    grf_fft_pass<N1, NT>(X, LD, 1, tw, nullptr, 0, tid);
-    grf_fft_pass<N1, NT>(X, 1, LD, tw, nullptr, 0, tid);      // field (x constants)
+    grf_fft_pass<N1, NT, T>(X, LD, 1, tw, nullptr, 0, tid);      // rows:    w H
+    grf_fft_pass<N1, NT, T>(X, 1, LD, tw, amp, amp_ld, tid);     // columns: amp .* (H w H)
+    grf_fft_pass<N1, NT, T>(X, LD, 1, tw, nullptr, 0, tid);
+    grf_fft_pass<N1, NT, T>(X, 1, LD, tw, nullptr, 0, tid);      // field (x constants)
     // ---- min-max normalisation to [0, 1] (ground_truths.py:31), fp64 like the reference; the field moves into registers first (the
     // cross-wave exchange of the extrema reuses the array's first row)
     constexpr int PER = (n * n + NT - 1) / NT;
-    double val[PER];
-    double lo = INFINITY, hi = -INFINITY;
+    T val[PER];
+    T lo = (T)INFINITY, hi = (T)-INFINITY;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = tid + q * NT;
         const int y = min(i, N - 1) / n, x = min(i, N - 1) - y * n;
         val[q] = X[y * LD + x];
-        if (i < N) { lo = fmin(lo, val[q]); hi = fmax(hi, val[q]); }
+        if (i < N) { lo = val[q] < lo ? val[q] : lo; hi = val[q] > hi ? val[q] : hi; }
     }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, off));
-        hi = fmax(hi, __shfl_xor(hi, off));
+        const T ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+        lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
     }
     __syncthreads();  // (every thread holds its cells)
     if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
     __syncthreads();
-    double dlo = red[0], dhi = red[16];
+    double dlo = (double)red[0], dhi = (double)red[16];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[16 + w]); }
+    for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, (double)red[w]); dhi = fmax(dhi, (double)red[16 + w]); }
     const double span = dhi - dlo;
     float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = tid + q * NT;
-        if (i < N) gt[i] = (float)((val[q] - dlo) / span);
+        if (i < N) gt[i] = (float)(((double)val[q] - dlo) / span);
     }
     if (!gt_out)
         for (int i = N + tid; i < v.Npad; i += NT) gt[i] = 0.f;

@@ -1012,7 +1012,12 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
         rd[j] = 1.0;
+#ifdef IPP_SOLVE_ABLATE
+        if (j < m) { const double d = bcast_lane(c[j], j); rd[j] = __builtin_amdgcn_rsq(d); c[j] = (lane == j) ? d * rd[j] : 0.0; }  // (timing experiment: diagonal S)
+        if (false) {
+#else
         if (j < m) {  // wave-uniform
+#endif
             double t = c[j];
 #pragma unroll
             for (int k = 0; k < j; ++k) t = fma(-c[k], bcast_lane(c[k], j), t);  // - C[i][k] C[j][k]

@@ -28,6 +28,7 @@
 // k_prepare.h (solve_wave_fast, observe_wave).  mapping/mappings.py:178-197, planning/common/rewards.py:8-31.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "ipp_common.h"
 #include "k_gain.h"
@@ -64,6 +65,7 @@ inline PatchGeo patch_geometry(int W, int H, int R) {
     // widest rectangle: 2 R + 5 columns (the widest unclipped footprint of m <= 9 blocks is 5 cells) with both ends moved out
     // to even columns; tallest: 2 R + 6 rows (a 6-row footprint only exists clipped at the border: fewer rows then)
     g.pw = std::min((W + 1) & ~1, ((2 * R + 5 + 2) / 2) * 2);
+    if (const char* pe = getenv("IPP_PATCH_PW")) { const int want = atoi(pe); if (want >= g.pw && want <= 64 && want % 2 == 0) g.pw = want; }  // A/B: row stride of a patch
     g.ph = std::min(H, 2 * R + 6);
     g.pstride = (g.pw * g.ph + 15) & ~15;
     g.pdiv = ((1 << kPatchDivShift) + g.pw - 1) / g.pw;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
                         const us2g d = __builtin_bit_cast(us2g, yx) - __builtin_bit_cast(us2g, first);
                         const bool in = __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2g, extent))) == __builtin_bit_cast(unsigned, d);
                         const unsigned voff = in ? (unsigned)(base4 + cell4) : 0xffffffffu;
-                        l[i][a] = (IPP_PATCH_ABLATE & 32) ? __uint_as_float(voff) * 1e-30f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
+                        l[i][a] = (IPP_PATCH_ABLATE & 32) ? (float)(voff & 0xffu) * 1e-30f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
                     }
                 }
             }
