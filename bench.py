@@ -404,7 +404,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
         "bytes_per_launch": bytes_per_launch, "mask_reread_bytes_per_launch": mask_reread if state == "factor" else 0.0,
         "necessary_bytes_per_launch": needed if (state == "factor" and needed > 0) else None,
-        "workgroup_threads": 64 * int(os.environ.get("IPP_PATCH_WAVES", "2")) if (state == "factor" and int(eng.info.patch_layout)) else int(eng.info.tile_threads),
+        "workgroup_threads": 64 * int(eng.info.patch_waves) if (state == "factor" and int(eng.info.patch_layout)) else int(eng.info.tile_threads),
         "formula_bytes_per_launch": formula_bytes, "achieved_gbs": achieved,
         "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
         "arena_gb": float(eng.info.arena_bytes) / 1e9,

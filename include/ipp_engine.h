@@ -107,8 +107,9 @@ typedef struct ipp_info {
     int32_t fused_step;       /* 1: ipp_step is ONE fused kernel per launch (ipp_step_autoreset folds the resets into it) */
     int32_t patch_layout;     /* 1: factor columns stored as compact patches of their rectangles (k_step_patch.h) */
     int32_t patch_waves;      /* patch layout: waves per item of the step kernel (workgroup = 64 x this many threads), else 0 */
-    int32_t patch_big_min_items; /* patch layout: launches of at least this many items take the six-waves-per-SIMD instantiation of
-                                 the step kernel (k_step_patch<2, 4, 6>), smaller ones k_step_patch<2, 8, 5>; 0: never */
+    int32_t patch_big_min_items; /* patch layout, two-wave engines (IPP_PATCH_WAVES=2) only: launches of at least this many items take
+                                 the instantiation with four rows per request group (k_step_patch<2, 4, 6>); 0: one instantiation for every
+                                 launch size (the default: k_step_patch<3, 8, 6>) */
 } ipp_info;
 
 /* Debug / test view of the last ipp_step's per-item prologue (host struct, filled by ipp_debug_step_item). */

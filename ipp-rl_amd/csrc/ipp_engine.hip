@@ -92,7 +92,7 @@ struct Engine {
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     bool patch = false;   // k_step_patch on compact column patches (View::patch)
-    int patch_waves = 2;  // waves per item of k_step_patch
+    int patch_waves = IPP_PATCH_WAVES_DEFAULT;  // waves per item of k_step_patch
     int pcap_big = 0, big_min_items = 0;  // large launches: k_step_patch<2, 4, 6> with LDS for 12 workgroups per CU (0: never)
     size_t lds_big = 0;
     bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
@@ -155,7 +155,7 @@ bool patch_layout(const ipp_config& c, int MC) {
 }
 int patch_waves_wanted() {
     if (const char* w = getenv("IPP_PATCH_WAVES")) { const int n = atoi(w); if (n >= 1 && n <= 4) return n; }
-    return 2;
+    return IPP_PATCH_WAVES_DEFAULT;
 }
 
 // Windowed factor columns: the largest length scale a reset may install and the prior covariance dropped at the
@@ -785,7 +785,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         // (the LDS of a workgroup is allocated in granules of 1280 bytes on gfx950: 16 KB would take 13 of the 128)
         int wgs = kPatchWavesPerCu / L.patch_waves;
         if (const char* wg = getenv("IPP_PATCH_WGS")) { if (atoi(wg) > 0) wgs = atoi(wg); }  // A/B: workgroups per CU to leave room for
-        const size_t budget = (size_t)160 * 1024 / wgs / 1280 * 1280;
+        // (at most 13 granules: 170 records are more than the two register pages of the unit loop hold, and the 8 workgroups of the
+        // default configuration then leave 30 KB of the CU's LDS to the ground-truth kernel that runs beside the steps)
+        const size_t budget = std::min<size_t>((size_t)160 * 1024 / wgs / 1280 * 1280, (size_t)13 * 1280);
         const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
         int pcap = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;
         if (const char* pc = getenv("IPP_PATCH_CAP")) pcap = std::max(8, atoi(pc));  // A/B experiments, overflow tests
@@ -901,6 +903,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2, IPP_PATCH_BIGKP, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<3>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
@@ -1290,10 +1293,12 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
     e->last_n = n;
     const View& v = e->v;
     if (e->patch) {  // tree nodes as patches: one fused kernel for every launch size (k_tree_patch.h)
-        // (LDS sized for the waves this kernel really has: the step kernel may run 1 or 3 waves per item -- IPP_PATCH_WAVES --, the tree kernel 2 or 4)
-        const int nw = e->patch_waves == 4 ? 4 : 2;
+        // (LDS sized for the waves this kernel really has: the step kernel may run 1 wave per item -- IPP_PATCH_WAVES --, the tree kernel 2 to 4)
+        const int nw = e->patch_waves >= 2 ? e->patch_waves : 2;
         const size_t tlds = PatchLds::bytes(v.pcap, v.plw * v.plw, nw, v.punits, v.rank_cap);
-        if (nw == 4)
+        if (nw == 3)
+            timed_launch(e, 0, k_tree_patch<3>, dim3(n), dim3(192), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
+        else if (nw == 4)
             timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
         else
             timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);

@@ -33,6 +33,9 @@
 #ifndef IPP_UNIT_STAGED
 #define IPP_UNIT_STAGED 0    // 1: the bookkeeping of a request group stage by stage over its rows (independent instructions per stage)
 #endif
+#ifndef IPP_UNIT_MDFIRST
+#define IPP_UNIT_MDFIRST 0   // 1: mean / variance of a unit's cells requested at the start of the unit
+#endif
 #ifndef IPP_UNIT_NOCOUNT
 #define IPP_UNIT_NOCOUNT 0   // A/B: no in-rectangle count (roofline.necessary_bytes reads 0)
 #endif
@@ -136,6 +139,12 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         const unsigned flat4 = (unsigned)flat * 4u;  // byte offset of the lane's cells in a (shifted) patch
 #endif
 
+#if IPP_UNIT_MDFIRST
+        // pre-step mean and variance of the unit's cells, requested FIRST: their round trip (2-3 us under load) runs under the row
+        // stream instead of in front of the epilogue (four registers held across the stream: no spills at 79 VGPRs)
+        float md_in[2][VEC];
+        io.load_pre(cell0, flat, rrow, rcol, md_in);
+#endif
         // ---- records whose rectangle meets the rows of this unit: one mask per register page (lane a <-> record a; an empty page
         // entry holds first row 0xffff and never matches)
         unsigned long long pmask[2];
@@ -388,10 +397,12 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         IPP_WT(2);
         IPP_WT_COUNT(9, (nact + KP - 1) / KP);
         IPP_WT_COUNT(10, 1);
+#if !IPP_UNIT_MDFIRST
         // pre-step mean and variance of the unit's cells (read behind the row stream: held across it, the four values were spilled
         // to scratch, per unit and wave; the L^-1 FMAs below cover the round trip)
         float md_in[2][VEC];
         io.load_pre(cell0, flat, rrow, rcol, md_in);
+#endif
         // ---- wait (first unit only) for L^-1 and y, then Wc = (P[:,F] H_F^T) L^-1 in place (column j needs the entries b <= j)
         if (!solved) {
             while (__hip_atomic_load(ua.solve_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);

@@ -48,7 +48,13 @@ constexpr int kPatchRec = 16;  // floats per column record
 #define IPP_PATCH_AUX 2  // cache policy bits of the row requests (2: nt)
 #endif
 #ifndef IPP_PATCH_MINW
-#define IPP_PATCH_MINW 5  // waves per SIMD the register allocation aims at
+#define IPP_PATCH_MINW 6  // waves per SIMD the register allocation aims at (round 4: the unit loop fits 80 VGPRs with 8 rows in flight)
+#endif
+#ifndef IPP_PATCH_WAVES_DEFAULT
+#define IPP_PATCH_WAVES_DEFAULT 3  // waves per item.  THREE at six waves per SIMD = 8 workgroups per CU = 2048 item slots: one wave for the m x m
+                                   // algebra, one for the observation, one that streams from the start; the chains of the heaviest items (which
+                                   // end a 4096-item launch) are a third shorter than with two waves at ten workgroups per CU: 0.0915 vs 0.0968 ms
+                                   // (round 3, five waves per SIMD: three waves lost, 0.1245 vs 0.1160; profiles/r04_experiments.txt 7)
 #endif
 constexpr int kPatchWavesPerCu = 4 * IPP_PATCH_MINW;
 constexpr int kPatchKP = IPP_PATCH_KP;   // stored rows requested per group

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     // n_dev: the item count lives on the device (ipp_mcts_level_steps with n < 0: the search driver queues the levels of a
     // wave of simulations without reading their request counts back); the grid then has n_items >= *n_dev workgroups
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
-    constexpr int RJ = kPatchMaxRank / NT;
-    static_assert(NW == 2 || NW == 4, "two or four waves per item");
+    constexpr int RJ = (kPatchMaxRank + NT - 1) / NT;
+    static_assert(NW >= 2 && NW <= 4, "two to four waves per item");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tp2[];
     const PatchLds lds(smem_tp2, v.pcap, v.plw * v.plw, NW, v.punits, v.rank_cap);
     if (n_dev) n_items = min(n_items, uni(*n_dev));

@@ -58,8 +58,8 @@ def test_fullsize_batch_invariants_subset_parity_and_reproducibility(grid, B, T,
     # its six-waves-per-SIMD instantiation (csrc/ipp_engine.hip patch_layout() / launch_chunk()); a regression in the selection rules
     # would put these configs back on the band-tile kernels with every numeric check below still green
     assert full.info.window_rows == 10
-    assert full.info.patch_layout == 1 and full.info.fused_step == 1 and full.info.patch_waves == 2
-    assert 0 < full.info.patch_big_min_items <= B
+    assert full.info.patch_layout == 1 and full.info.fused_step == 1 and full.info.patch_waves == 3
+    assert full.info.patch_big_min_items == 0  # (the two-wave engines' second instantiation: IPP_PATCH_WAVES=2 only)
     print(f"[{name}] arena {full.info.arena_bytes / 1e9:.1f} GB, {full.info.cov_slot_bytes / 1e6:.2f} MB of columns per env")
     white = torch.empty((B, N), dtype=torch.float32, device="cuda")
     full.normal_rows(white, N, 11, 1 << 40)
@@ -382,14 +382,14 @@ def test_fullsize_device_search_1024_roots_256_sims_200x200():
     assert np.array_equal(nsa1, mcts.t_Nsa) and all(out[j][0] == out2[j][0] for j in range(roots))
 
 
-@pytest.mark.parametrize("grid,capacity,T,node_capacity,big", [
-    (50, 64, 40, 0, False),        # configs[0] / [1]: 50x50 (the headline batch is 4096 envs: below the six-wave threshold)
-    (50, 4096, 40, 0, False),      # configs[1]
-    (100, 256, 16, 0, False),      # configs[2] geometry (the full batch: test above)
-    (50, 16384, 40, 0, True),      # configs[3] per-GPU share launches >= 16384 items
-    (200, 64, 11, 256, False),     # configs[4]: 200x200 roots + tree nodes
+@pytest.mark.parametrize("grid,capacity,T,node_capacity", [
+    (50, 64, 40, 0),        # configs[0] / [1]: 50x50
+    (50, 4096, 40, 0),      # configs[1]
+    (100, 256, 16, 0),      # configs[2] geometry (the full batch: test above)
+    (50, 16384, 40, 0),     # configs[3] per-GPU share
+    (200, 64, 11, 256),     # configs[4]: 200x200 roots + tree nodes
 ])
-def test_baseline_configs_take_the_patch_kernels(grid, capacity, T, node_capacity, big):
+def test_baseline_configs_take_the_patch_kernels(grid, capacity, T, node_capacity):
     """Kernel selection per BASELINE config: the window of the fixed example prior puts every one of them on the patch layout."""
     from ipp_rl_amd import EngineConfig, IPPEngine
 
@@ -397,6 +397,17 @@ def test_baseline_configs_take_the_patch_kernels(grid, capacity, T, node_capacit
     eng = IPPEngine(EngineConfig(x_dim=grid, y_dim=grid), capacity=capacity, state="factor", rank_cap=9 * T, window_rows=-1,
                     fixed_prior=True, node_capacity=node_capacity)
     assert eng.info.window_rows == 10
-    assert eng.info.patch_layout == 1 and eng.info.fused_step == 1 and eng.info.patch_waves == 2
-    assert (0 < eng.info.patch_big_min_items <= capacity) == big
+    assert eng.info.patch_layout == 1 and eng.info.fused_step == 1 and eng.info.patch_waves == 3
+    assert eng.info.patch_big_min_items == 0
+    eng.close()
+
+
+def test_two_wave_engines_keep_their_large_launch_instantiation(monkeypatch):
+    """IPP_PATCH_WAVES=2 (the round-3 configuration, kept for A/B): launches of >= 16384 items take k_step_patch<2, 4, 6>."""
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    fresh_gpu()
+    monkeypatch.setenv("IPP_PATCH_WAVES", "2")
+    eng = IPPEngine(EngineConfig(x_dim=50, y_dim=50), capacity=64, state="factor", rank_cap=360, window_rows=-1, fixed_prior=True)
+    assert eng.info.patch_waves == 2 and eng.info.patch_big_min_items == 16384
     eng.close()
