@@ -74,10 +74,11 @@ def build_parser():
                     help="schedule of a step: the batch as this many fixed groups of envs, one launch and one stream per group "
                          "(VecIPPEnv.step_async: a group's step t + 1 is ordered behind its own step t only, so the next launch of one "
                          "group fills the slots the slowest items of the other still hold); 1 (default) = one launch per step on one stream. "
-                         "Measured on MI355X (profiles/r04_experiments.txt 1): the partitioned schedule LOSES -- 37.9 M against 40.0 M "
-                         "env-steps/s at 2 groups, 27.8 M at 4: dependent launches of a queue start ~9 us after their predecessor "
-                         "once two queues are active (0 us on one queue) and the groups lock in phase.  With parts > 1 the "
-                         "one-launch rate is measured as well (config.sync_schedule)")
+                         "Measured on MI355X (profiles/r04_experiments.txt 1, 10): with three waves per item two groups gain 3 % (46.3 against "
+                         "45.0 M env-steps/s; each half is one round of the 2048 item slots), four lose (36.5 M); dependent launches of a "
+                         "queue start ~10 us after their predecessor once two queues are active (0 us on one queue).  The default stays one "
+                         "launch per step -- its kernel time is what rocprofv3 reports per launch --, the two-group rate is in `extra`.  "
+                         "With parts > 1 the one-launch rate is measured as well (config.sync_schedule)")
     ap.add_argument("--step-priority", type=int, default=0,
                     help="A/B: run the steps on a stream of this priority (-1: above the side stream that generates the next episodes' "
                          "ground truths, whose workgroups then only take the slots the step launches leave free)")
@@ -708,6 +709,9 @@ def main(argv=None):
              dict(grid=50, envs_local=4096, episode_steps=40, shuffle_prior=True)),
             ("BASELINE configs[1], predict-only calls (simulate_prediction_step, no state write)",
              dict(grid=50, envs_local=4096, episode_steps=40, predict_only=True)),
+            ("BASELINE configs[1] on the partitioned schedule: 2 fixed groups of envs, one launch and one stream per group, a group's step "
+             "t + 1 ordered behind its own step t only (VecIPPEnv.step_async; frac: bytes / time during which at least one launch runs)",
+             dict(grid=50, envs_local=4096, episode_steps=40, parts=2, steps=80, warmup=8)),
             ("BASELINE configs[2]: 32768 envs, 100x100 grid, 16-step episodes",
              dict(grid=100, envs_local=32768, episode_steps=16)),
             ("BASELINE configs[3] per-GPU share: 32768 envs, 50x50 grid, 40-step episodes",
@@ -715,7 +719,8 @@ def main(argv=None):
         ]
         for name, kw in todo:
             try:
-                r, _ = run_env_workload(torch, ranks, device, env_lo=0, total_envs=kw["envs_local"], steps=20, warmup=4, parts=args.parts, **kw)
+                kw = dict(dict(steps=20, warmup=4, parts=args.parts), **kw)
+                r, _ = run_env_workload(torch, ranks, device, env_lo=0, total_envs=kw["envs_local"], **kw)
                 extra.append(extra_record(name, r, kw["envs_local"]))
             except Exception as exc:
                 extra.append({"name": name, "error": repr(exc)})
