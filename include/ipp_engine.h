@@ -457,6 +457,12 @@ int ipp_fill_normal(void* engine, float* out /*[dev]*/, uint64_t count, uint64_t
 int ipp_fill_normal_rows(void* engine, float* out /*[dev]*/, int32_t planes, int32_t rows, int32_t row_len,
                          const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence, void* stream);
 
+/* Scheduling probe for ipp_step_parts: `launches` dependent 30-us kernels on each of the two streams, issued alternately; ms = the time
+ * until both chains have run (launches x 0.03 ms when the two hardware queues behind the streams dispatch independently, ~a third more
+ * when a dependent launch waits ~10 us for its queue's turn -- which depends on the queues the runtime happened to give the streams).
+ * The batched driver times a few candidate pairs and keeps the best.  Synchronises both streams. */
+int ipp_probe_stream_pair(void* engine, void* stream_a, void* stream_b, int32_t launches, double* ms /*[host]*/);
+
 /* Copy the prologue record of item `idx` of the most recent ipp_step to the host (synchronises).  The fp64 copies of S, L^-1, z
  * and y are written by the step only after ipp_debug_capture(engine, 1) (they cost 1.4 KB of stores per item); footprint, m, cost
  * and status are always there. */

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "ipp_metrics": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "ipp_fill_normal": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "ipp_fill_normal_rows": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "ipp_probe_stream_pair": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(C.c_double)]),
     "ipp_debug_capture": (C.c_int, [_P, C.c_int32]),
     "ipp_debug_step_item": (C.c_int, [_P, C.c_int32, C.POINTER(IppStepItem), _P]),
     "ipp_streamed_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int32, _P]),

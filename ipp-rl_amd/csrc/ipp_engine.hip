@@ -1707,6 +1707,34 @@ int ipp_streamed_bytes_detail(void* engine, uint64_t* bytes, uint64_t* mask_rere
     return 0;
 }
 
+int ipp_probe_stream_pair(void* engine, void* stream_a, void* stream_b, int32_t launches, double* ms) {
+    Engine* e = as_engine(engine);
+    if (!e || !ms || launches < 1 || launches > 256) return fail(-1, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t a = reinterpret_cast<hipStream_t>(stream_a), b = reinterpret_cast<hipStream_t>(stream_b);
+    hipEvent_t e0, ea, eb;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
+    HIP_TRY(hipStreamSynchronize(a)); HIP_TRY(hipStreamSynchronize(b));
+    // warm both queues, then a chain of dependent launches on each, issued alternately like the parts of a batched step
+    hipLaunchKernelGGL(k_spin, dim3(64), dim3(64), 0, a, 100ull, (int*)nullptr);
+    hipLaunchKernelGGL(k_spin, dim3(64), dim3(64), 0, b, 100ull, (int*)nullptr);
+    HIP_TRY(hipStreamSynchronize(a)); HIP_TRY(hipStreamSynchronize(b));
+    HIP_TRY(hipEventRecord(e0, a));
+    HIP_TRY(hipStreamWaitEvent(b, e0, 0));
+    for (int i = 0; i < launches; ++i) {
+        hipLaunchKernelGGL(k_spin, dim3(256), dim3(64), 0, a, 3000ull, (int*)nullptr);  // 30 us each
+        hipLaunchKernelGGL(k_spin, dim3(256), dim3(64), 0, b, 3000ull, (int*)nullptr);
+    }
+    HIP_TRY(hipEventRecord(ea, a)); HIP_TRY(hipEventRecord(eb, b));
+    HIP_TRY(hipEventSynchronize(ea)); HIP_TRY(hipEventSynchronize(eb));
+    float ta = 0.f, tb = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ta, e0, ea)); HIP_TRY(hipEventElapsedTime(&tb, e0, eb));
+    *ms = (double)std::max(ta, tb);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ipp_debug_capture(void* engine, int32_t enable) {
     Engine* e = as_engine(engine);
     if (!e) return fail(-1, "null engine");

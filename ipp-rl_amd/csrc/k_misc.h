@@ -389,4 +389,12 @@ __global__ void k_fill_normal_rows(float* __restrict__ out, int planes, int rows
         if (4 * qc + h < row_len) o[h] = nrm[h];
 }
 
+// Occupies the device for `ticks` of the 100 MHz wall clock (ipp_probe_stream_pair: dependent launches on two queues).
+__global__ void k_spin(unsigned long long ticks, int* sink) {
+    const unsigned long long t0 = wall_clock64();
+    int n = 0;
+    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); ++n; }
+    if (sink && n < 0) *sink = n;
+}
+
 }  // namespace ipp

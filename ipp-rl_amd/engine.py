@@ -522,6 +522,14 @@ class IPPEngine:
         self._keep_rows = ids
         return out
 
+    def probe_stream_pair(self, stream_a, stream_b, launches: int = 12) -> float:
+        """ms that `launches` dependent 30-us kernels on each of the two (torch) streams take when issued alternately
+        (ipp_probe_stream_pair): small = the streams' hardware queues dispatch independently."""
+        ms = C.c_double(0.0)
+        _ffi.check(self._lib.ipp_probe_stream_pair(self._h, C.c_void_p(stream_a.cuda_stream), C.c_void_p(stream_b.cuda_stream),
+                                                   int(launches), C.byref(ms)))
+        return float(ms.value)
+
     def debug_capture(self, enable: bool = True):
         """The steps that follow keep fp64 copies of S, L^-1, z and y per item for debug_item (off by default: 1.4 KB of stores per item)."""
         _ffi.check(self._lib.ipp_debug_capture(self._h, 1 if enable else 0))

@@ -110,7 +110,7 @@ class VecIPPEnv:
                 self._orders_parts.append(torch.as_tensor(np.argsort(key, kind="stable").astype(np.int32), device=dev))
             self._part_begin = [0] + [int(x) for x in np.cumsum(np.bincount(grp, minlength=self.parts))]
             self._part_envs = [torch.as_tensor(np.nonzero(grp == g)[0].astype(np.int64), device=dev) for g in range(self.parts)]
-            self._part_streams = [torch.cuda.Stream(device=dev) for _ in range(self.parts)]
+            self._part_streams, self._side_pick = self._pick_streams(dev, self.parts)
             self._part_done = [torch.cuda.Event() for _ in range(self.parts)]
             self._ev_inputs = torch.cuda.Event()
             self._async_pending = False
@@ -140,7 +140,9 @@ class VecIPPEnv:
         # staggered runs prepare the next resets' ground truths on a side stream while the step kernels run
         # (the GRF convolution is fp64-compute-bound, the step is HBM-bound: they overlap on the chip); the field
         # for the resets after step t+1 is started at the beginning of step t, so it has two steps to finish
-        self._side = torch.cuda.Stream(device=dev) if stagger else None
+        self._side = None
+        if stagger:
+            self._side = self._side_pick if self._part_streams is not None else self._pick_streams(dev, 1)[1]
         self._grf_rows = None if os.environ.get("IPP_GRF_ROWS", "1") != "0" else False  # (False: the engine has no in-generator noise / A/B)
         # Staging in BLOCKS of K steps: the fields of all resets of block b + 1 are generated while block b runs, into one of
         # two buffer sets, and the streams meet ONCE per block (main waits for the block's `ready` event before its first step
@@ -423,6 +425,49 @@ class VecIPPEnv:
         return self.reward, self.status
 
     # ------------------------------------------------------------------ partitioned batch: one launch and one stream per part
+    def _pick_streams(self, dev, n_parts: int):
+        """The streams of the part launches (n_parts > 1) and of the ground-truth staging, one hardware queue each.
+        The runtime binds a stream to one of a few hardware queues (four by default) at first use; two streams on ONE queue
+        take turns, whatever the events say.  Measured at 4096 envs of 50x50 with two groups (profiles/r04_experiments.txt
+        item 12): staging stream and both part streams on three queues 59.5 us per step (68.8 M env-steps/s), staging stream
+        on a part stream's queue 70-75 us (every GRF launch holds that group's next step back), both part streams on one
+        queue 106-108 us -- slower than the single launch (88-91 us).  Which streams share a queue is not visible through the
+        API, so it is measured: ipp_probe_stream_pair runs two chains of dependent 30-us launches, twice as long on a shared
+        queue.  New streams are classed against one representative per queue found so far (a handful of probes, ~0.5 ms
+        each) until there are enough queues; the part streams avoid the caller's queue when they can.
+        IPP_PARTS_PROBE=0: streams as they come (A/B).  Returns (part streams | None, staging stream)."""
+        torch = self.torch
+        want_parts = n_parts if n_parts > 1 else 0
+        if os.environ.get("IPP_PARTS_PROBE", "1") == "0" or not hasattr(self.engine._lib, "ipp_probe_stream_pair"):
+            self._queues = None
+            return ([torch.cuda.Stream(device=dev) for _ in range(want_parts)] or None), torch.cuda.Stream(device=dev)
+        launches = 12
+        shared = launches * 0.030 * 1.5  # ms: the two chains ran one after the other
+        main = torch.cuda.current_stream(dev)
+        reps, members = [main], [[]]  # queue 0 = the caller's
+        pool = []
+        while len(pool) < 16 and len(reps) - 1 < want_parts + 1:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                torch.zeros(16, device=dev).add_(1)  # first use binds the queue
+            pool.append(st)
+            for q, r in enumerate(reps):
+                if self.engine.probe_stream_pair(st, r, launches) > shared:
+                    members[q].append(st)
+                    break
+            else:
+                reps.append(st)
+                members.append([st])
+        others = [m[0] for m in members[1:]]  # one stream per queue that is not the caller's
+        picks = others[:want_parts]
+        free = others[want_parts:]
+        while len(picks) < want_parts:  # fewer queues than groups: share the caller's, then anything
+            picks.append(members[0][0] if members[0] and members[0][0] not in picks else torch.cuda.Stream(device=dev))
+        side = free[0] if free else (members[0][0] if members[0] and members[0][0] not in picks else
+                                     (others[-1] if others and not want_parts else torch.cuda.Stream(device=dev)))
+        self._queues = {"n_queues": len(reps), "pool": pool, "members": members, "probes_ms_shared": shared}
+        return (picks or None), side
+
     def part_stream(self, p: int):
         """The stream that steps part p (run that part's policy on it and no event is needed around step_async)."""
         return self._part_streams[p]
