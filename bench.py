@@ -70,15 +70,15 @@ def build_parser():
                     help="scheduled episode resets inside the step launch (ipp_step_autoreset; VecIPPEnv's default)")
     ap.add_argument("--no-fused-resets", dest="fused_resets", action="store_false",
                     help="A/B: the scheduled resets as their own launch after every step")
-    ap.add_argument("--parts", type=int, default=1,
+    ap.add_argument("--parts", type=int, default=2,
                     help="schedule of a step: the batch as this many fixed groups of envs, one launch and one stream per group "
-                         "(VecIPPEnv.step_async: a group's step t + 1 is ordered behind its own step t only, so the next launch of one "
-                         "group fills the slots the slowest items of the other still hold); 1 (default) = one launch per step on one stream. "
-                         "Measured on MI355X (profiles/r04_experiments.txt 1, 10): with three waves per item two groups gain 3 % (46.3 against "
-                         "45.0 M env-steps/s; each half is one round of the 2048 item slots), four lose (36.5 M); dependent launches of a "
-                         "queue start ~10 us after their predecessor once two queues are active (0 us on one queue).  The default stays one "
-                         "launch per step -- its kernel time is what rocprofv3 reports per launch --, the two-group rate is in `extra`.  "
-                         "With parts > 1 the one-launch rate is measured as well (config.sync_schedule)")
+                         "(VecIPPEnv.step_async: a group's step t + 1 is ordered behind its OWN step t only -- envs are independent --, so the "
+                         "next launch of one group fills the slots that the slowest items of the other still hold); 1 = one launch per step on "
+                         "one stream (rounds 1-3).  Measured on MI355X at configs[1] (profiles/r04_experiments.txt 10-13): two groups 55-56 M "
+                         "env-steps/s against 45 M for one launch, provided the two part streams and the ground-truth staging stream sit on "
+                         "three different hardware queues (VecIPPEnv probes for that; on a shared queue 43-47 M); three groups equal two.  "
+                         "With parts > 1 the one-launch rate of the same env is measured as well (config.sync_schedule) and the roofline leg "
+                         "times both forms")
     ap.add_argument("--step-priority", type=int, default=0,
                     help="A/B: run the steps on a stream of this priority (-1: above the side stream that generates the next episodes' "
                          "ground truths, whose workgroups then only take the slots the step launches leave free)")
@@ -258,6 +258,9 @@ def pmc_traffic(kernel_name, key):
     REPLAYED from the named file, not measured in this run."""
     import glob
 
+    # the counter passes run the batch as ONE launch per step (--parts 1: per-dispatch counters of overlapping launches are not
+    # separable, and the groups' launches of a step move the same bytes as the single launch)
+    key = dict(key, parts=1)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json")), reverse=True):
         try:
             with open(path) as fh:
@@ -565,9 +568,12 @@ def schedule_text(rec):
 
 def kernel_ms_text(rec):
     if rec["parts"] > 1:
-        return ("per STEP: time during which at least one of the step's launches runs (union of the dispatches' HIP-event intervals over the "
-                "roofline leg / steps) -- the launches of the groups overlap, their individual durations (part_launch_ms_avg) add up to more "
-                "than the wall time; single_launch_ms_avg: the whole batch as ONE launch, alone on the device (the figure of rounds 1-3)")
+        return ("per STEP: time during which at least one of the step's launches runs (union of the dispatches' HIP-event intervals over a "
+                "leg of `steps` steps on the partitioned schedule, with an event pair around every dispatch -- which costs the overlap a few us per "
+                "step, so this can exceed ms_per_step of the timed regions, which run without events; tools/trace_overlap.py gives the same union "
+                "from the rocprofv3 kernel trace, profiles/r04_trace_overlap.txt).  The groups' launches overlap: their individual durations "
+                "(part_launch_ms_avg, what rocprofv3 --stats averages together with the one-launch legs) add up to more than the wall time.  "
+                "single_launch_ms_avg / single_launch_frac: the whole batch as ONE launch, alone on the device (the figure of rounds 1-3)")
     return "average HIP-event duration of the step kernel's dispatches over the roofline leg"
 
 
@@ -663,10 +669,11 @@ def main(argv=None):
             "roofline": {
                 "bound": "hbm", "achieved": rec["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_definition": "HBM bytes per step (2 x FETCH_SIZE + WRITE_SIZE, KiB) of the whole batch run as one launch (--parts 1 under --pmc)",
                 "traffic_over_algorithmic": (traffic / rec["bytes_per_launch"]) if traffic and rec["bytes_per_launch"] else None,
                 "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "launches": rec["launches"],
-                "kernel_ms_definition": kernel_ms_text(rec),
+                "kernel_ms_definition": kernel_ms_text(rec), "launches_per_step": rec["parts"],
                 "single_launch_ms_avg": rec["single_launch_ms"],
                 "single_launch_frac": (rec["bytes_per_launch"] / (rec["single_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rec["single_launch_ms"] else None,
                 "part_launch_ms_avg": rec["part_launch_ms_avg"], "part_launches": rec["part_launches"],
@@ -682,12 +689,13 @@ def main(argv=None):
                                                 "stored rows = the columns that contribute to this step (non-zero row of H U^T), touched cells = the "
                                                 "cells of the rectangle within window_rows of the footprint in BOTH directions (a stored column IS that "
                                                 "rectangle, as a compact patch; the padding columns a patch row may have are neither counted nor read)",
-                "note": "columns of U are stored as compact patches of their rectangles (k_step_patch.h + k_patch_units.h): one 2-wave workgroup per item, "
-                        "units of 128 valid cells, active columns as bit masks walked with scalar instructions.  What bounds the launch at 4096 items "
-                        "(profiles/r04_experiments.txt): the per-item chain -- prologue (dependent loads + fp64 header) 11.6 us, m x m algebra 7.7 us, "
-                        "then rows at 0.16 us per 512-byte request for a lone wave / 0.3 us under load (8 requests per round trip); the heaviest item takes "
-                        "0.10 ms under load (0.063 ms alone) and the second round of items starts at 0.04-0.05 ms; overlapping consecutive launches on two "
-                        "queues loses to the queue gap (item 1 of that log)",
+                "note": "columns of U are stored as compact patches of their rectangles (k_step_patch.h + k_patch_units.h): one 3-wave workgroup per item, "
+                        "units of 128 valid cells, active columns as bit masks walked with scalar instructions.  What bounds a step at 4096 items "
+                        "(profiles/r04_experiments.txt 12-13, per-item timeline of tools/timeline_parts.py): items hold a workgroup slot for 31.6 us on "
+                        "average (prologue 13 us of dependent loads + fp64 header + m x m algebra, units 19 us), 2048 slots -> 63 us per step if no slot "
+                        "ever idled; one launch per step idles them behind its stragglers (a launch lasts as long as its longest item, 65-75 us, and the "
+                        "second round of items starts at 40-50 us: 89 us), two groups on two queues overlap one group's stragglers with the other's start "
+                        "(73 us; each group's launch still lasts 67 us = its longest item)",
                 "bytes_per_launch_incl_mask_reread": rec["bytes_per_launch"] + rec["mask_reread_bytes_per_launch"],
                 "full_column_formula_bytes_per_launch": rec["formula_bytes_per_launch"],
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],
@@ -709,9 +717,8 @@ def main(argv=None):
              dict(grid=50, envs_local=4096, episode_steps=40, shuffle_prior=True)),
             ("BASELINE configs[1], predict-only calls (simulate_prediction_step, no state write)",
              dict(grid=50, envs_local=4096, episode_steps=40, predict_only=True)),
-            ("BASELINE configs[1] on the partitioned schedule: 2 fixed groups of envs, one launch and one stream per group, a group's step "
-             "t + 1 ordered behind its own step t only (VecIPPEnv.step_async; frac: bytes / time during which at least one launch runs)",
-             dict(grid=50, envs_local=4096, episode_steps=40, parts=2, steps=80, warmup=8)),
+            ("BASELINE configs[1] with one launch per step on one stream (the schedule of rounds 1-3; frac: bytes / that launch's duration)",
+             dict(grid=50, envs_local=4096, episode_steps=40, parts=1, steps=80, warmup=8)),
             ("BASELINE configs[2]: 32768 envs, 100x100 grid, 16-step episodes",
              dict(grid=100, envs_local=32768, episode_steps=16)),
             ("BASELINE configs[3] per-GPU share: 32768 envs, 50x50 grid, 40-step episodes",

@@ -13,27 +13,26 @@ grep -v amdgpu.ids $O/extras.txt | tail -12
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # kernel trace of the headline command line (no extras: one workload per trace)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o kt -- python3 bench.py --no-cpu-baseline --no-extra > $O/trace.log 2>&1
-python tools/trace_phases.py $O/trace/kt_kernel_trace.csv $O/trace.log > $O/trace_phases.txt 2>&1; cat $O/trace_phases.txt
+python tools/trace_overlap.py $O/trace/kt_kernel_trace.csv k_step_patch 300 $O/trace.log > $O/trace_overlap.txt 2>&1; grep -v "^  queue" $O/trace_overlap.txt | head -12
 # and of configs[2]
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2 -o kt -- python3 bench.py --no-cpu-baseline --no-extra --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/trace_cfg2.log 2>&1
 # configs[4]: the tree wave (k_tree_patch) and the device-side search (k_mcts_*)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tree -o kt -- python3 tools/tree_wave.py --reps 2 > $O/trace_tree.log 2>&1; tail -1 $O/trace_tree.log | cut -c1-300
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_mcts -o kt -- python3 tools/mcts_bench.py --reps 2 > $O/trace_mcts.log 2>&1; tail -1 $O/trace_mcts.log | cut -c1-300
 # PMC passes (separate runs, counters only)
-bash tools/pmc_run.sh $O/pmc > $O/pmc_run.log 2>&1
+bash tools/pmc_run.sh $O/pmc --parts 1 > $O/pmc_run.log 2>&1
 python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json
-PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_w12 --shuffle-prior > $O/pmc_run_w12.log 2>&1
+PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_w12 --parts 1 --shuffle-prior > $O/pmc_run_w12.log 2>&1
 python tools/pmc_summary.py $O/pmc_w12 40 > $O/pmc_summary_w12.json 2>>$O/pmc_summary.err
-PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
+PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --parts 1 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
 python tools/pmc_summary.py $O/pmc_cfg2 16 > $O/pmc_summary_cfg2.json 2>>$O/pmc_summary.err
 # address-pattern probe of the column layouts (GB/s + FETCH_SIZE per pattern: the FETCH_SIZE calibration on the step kernel's own
 # request shapes) and the occupancy timeline of one k_step_patch launch (needs `make -C ipp-rl_amd/csrc timeline` before gpurun)
 # round 4: issue cost of the kernels' instruction kinds, wave priority, the partitioned schedule against one launch per step
 hipcc --offload-arch=gfx950 -O3 tools/probes/issue_probe.hip -o /tmp/issue_probe 2>/dev/null && /tmp/issue_probe > $O/issue_probe.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/prio_probe.hip -o /tmp/prio_probe 2>/dev/null && /tmp/prio_probe > $O/prio_probe.txt 2>&1
-rm -f gpurun_out/ab/ab_parts.txt; bash tools/ab_parts.sh 1 2 > /dev/null 2>&1; cp gpurun_out/ab/ab_parts.txt $O/ab_parts.txt
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_parts -o kt -- python3 bench.py --no-cpu-baseline --no-extra --parts 2 --regions 2 > $O/trace_parts.log 2>&1
-python tools/trace_overlap.py $(find $O/trace_parts -name "*kernel_trace.csv" | head -1) k_step_patch 300 > $O/trace_parts_overlap.txt 2>&1
+rm -f gpurun_out/ab/ab_parts.txt; bash tools/ab_parts.sh 1 2 3 > /dev/null 2>&1; cp gpurun_out/ab/ab_parts.txt $O/ab_parts.txt
+python tools/parts_probe.py 2>&1 | grep -v amdgpu.ids > $O/parts_probe.txt
 python tools/grf_bench.py 50:102 50:819 100:2048 > $O/grf_bench.txt 2>&1; IPP_GRF_FFT=0 python tools/grf_bench.py 50:102 50:819 100:2048 >> $O/grf_bench.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/patch_probe.hip -o tools/probes/patch_probe || echo "patch_probe build failed"
 [ -x tools/probes/patch_probe ] && bash tools/probe_run.sh > $O/probe_run.log 2>&1 && cp gpurun_out/probe/patch_probe.txt $O/patch_probe.txt

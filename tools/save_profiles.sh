@@ -6,7 +6,7 @@ cp $R/trace/kt_kernel_stats.csv $P/${tag}_bench_kernel_stats.csv 2>/dev/null || 
 cp $(find $R/trace_cfg2 -name "*kernel_stats.csv" | head -1) $P/${tag}_cfg2_kernel_stats.csv
 cp $(find $R/trace_tree -name "*kernel_stats.csv" | head -1) $P/${tag}_tree_kernel_stats.csv
 cp $(find $R/trace_mcts -name "*kernel_stats.csv" | head -1) $P/${tag}_mcts_kernel_stats.csv
-cp $R/trace_phases.txt $P/${tag}_trace_phases.txt
+[ -f $R/trace_phases.txt ] && cp $R/trace_phases.txt $P/${tag}_trace_phases.txt
 cp $R/pmc_summary.json $P/${tag}_pmc_summary.json
 cp $R/pmc_summary_w12.json $P/${tag}_pmc_summary_w12.json
 cp $R/pmc_summary_cfg2.json $P/${tag}_pmc_summary_cfg2.json
@@ -15,5 +15,5 @@ cp $R/timeline.txt $P/${tag}_timeline.txt
 cp $R/write_probe_calibration.txt $P/${tag}_write_probe_calibration.txt
 grep -v amdgpu.ids $R/extras.txt > $P/${tag}_extras.txt
 tail -3 $R/pytest_gpu.log > $P/${tag}_pytest_gpu.txt
-for f in issue_probe prio_probe ab_parts trace_parts_overlap grf_bench; do [ -f $R/$f.txt ] && grep -v amdgpu.ids $R/$f.txt > $P/${tag}_$f.txt; done
+for f in issue_probe prio_probe ab_parts trace_overlap parts_probe grf_bench; do [ -f $R/$f.txt ] && grep -v amdgpu.ids $R/$f.txt > $P/${tag}_$f.txt; done
 ls -la $P | grep ${tag}_
