@@ -1738,7 +1738,11 @@ int ipp_probe_stream_pair(void* engine, void* stream_a, void* stream_b, int32_t 
 int ipp_debug_capture(void* engine, int32_t enable) {
     Engine* e = as_engine(engine);
     if (!e) return fail(-1, "null engine");
+#if IPP_EXIT_POINTS || defined(IPP_ISSUE_TEST)
+    e->v.dbg_capture = enable;  // (instruction-count build: enable = 1 + exit point, k_step_patch.h)
+#else
     e->v.dbg_capture = enable != 0;
+#endif
     return 0;
 }
 

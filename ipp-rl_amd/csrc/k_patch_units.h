@@ -93,6 +93,13 @@ struct UnitArgs {
 // The loop.  mcofs / mlo / mex: offset word, (first row | first column << 16) and (rows - 1 | columns - 1 << 16) of record a in lane
 // a & 63 of page a >> 6.  Returns the floats this wave streamed (SURVEY 8(d) count) in `units` and the floats of the lanes that really
 // were inside a stored column's rectangle in `needed`; `dead`: S was not positive definite.
+// (instruction-count build, tools/valu_sections.py: section k of the unit loop is skipped when ipp_debug_capture(1 + k) is set)
+#if defined(IPP_EXIT_POINTS) && IPP_EXIT_POINTS
+#define IPP_UNIT_SKIP(k) (v.dbg_capture == (k) + 1)
+#else
+#define IPP_UNIT_SKIP(k) false
+#endif
+
 template <int KP, class Io>
 __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, Io& io, const UnitArgs& ua, const UnitGeo& g,
                                             const unsigned (&mcofs)[2], const unsigned (&mlo)[2], const unsigned (&mex)[2],
@@ -215,7 +222,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
                     }
                 }
             };
-            if (IPP_PATCH_ABLATE & 4) { acc[0][0] = (float)rrow; acc[1][0] = (float)rcol; }
+            if ((IPP_PATCH_ABLATE & 4) || IPP_UNIT_SKIP(6)) { acc[0][0] = (float)rrow; acc[1][0] = (float)rcol; }
             else if (ua.rf1) base_term(std::integral_constant<int, 1>{});
             else base_term(std::integral_constant<int, 4>{});
         }
@@ -341,6 +348,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         };
 #pragma unroll 1
         for (int page = 0; page < 2; ++page) {
+            if (IPP_UNIT_SKIP(7)) break;
             unsigned long long mk = page ? pmask[1] : pmask[0];
             int left = __popcll(mk);
             typedef std::integral_constant<int, KP> n_kp;
@@ -392,6 +400,14 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
             fma_rows(std::integral_constant<int, KP>{}, uu, qr);
         }
 
+#if defined(IPP_ISSUE_TEST) && IPP_ISSUE_TEST  // (tools/skip_timing.py; costs registers: a build of its own)
+        if (v.dbg_capture >= 11) {  // (issue-bound test: 128 / 256 independent-ish vector instructions per unit that change nothing)
+            float d0 = (float)lane, d1 = 1.f, d2 = 2.f, d3 = 3.f;
+            for (int q = 0; q < 32 * (v.dbg_capture - 10); ++q)
+                asm volatile("v_fmac_f32 %0, %4, %4\n v_fmac_f32 %1, %4, %4\n v_fmac_f32 %2, %4, %4\n v_fmac_f32 %3, %4, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0.f));
+            if (d0 + d1 + d2 + d3 == 12345.678f) acc[0][0] += 1.f;
+        }
+#endif
         IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 0, ((unsigned long long)u << 32) | (unsigned)nact);
         IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 2, wall_clock64());
         IPP_WT(2);
@@ -416,7 +432,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
 #pragma unroll
         for (int b = 0; b < MC; ++b) lrow[b] = Ls[b * MC + min(lane & 15, MC - 1)];
         if (Io::kMean) yreg = ys[min(lane & 15, MC - 1)];
-        if (!(IPP_PATCH_ABLATE & 8)) {
+        if (!(IPP_PATCH_ABLATE & 8) && !IPP_UNIT_SKIP(8)) {
             linv_col<8>(acc, lrow); linv_col<7>(acc, lrow); linv_col<6>(acc, lrow); linv_col<5>(acc, lrow); linv_col<4>(acc, lrow);
             linv_col<3>(acc, lrow); linv_col<2>(acc, lrow); linv_col<1>(acc, lrow); linv_col<0>(acc, lrow);
         }
@@ -447,7 +463,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         units += (unsigned long long)(nact + fixed) * in_cells;
         needed += (unsigned long long)in_rect * VEC + (unsigned long long)fixed * in_cells;
         IPP_WT(4);
-        io.store(commit, lane_valid, cell0, flat, flat4, acc, md_in, dred, dmean);
+        if (!IPP_UNIT_SKIP(9)) io.store(commit, lane_valid, cell0, flat, flat4, acc, md_in, dred, dmean);
         __builtin_amdgcn_wave_barrier();
         IPP_WT(5);
         IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 3, wall_clock64());

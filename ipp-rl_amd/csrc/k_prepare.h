@@ -1002,7 +1002,7 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
     double c[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) c[k] = (lane < m && k < m) ? S[min(lane, MC - 1) * LD + k] : ((k == lane) ? 1.0 : 0.0);
-    const bool capture = v.dbg_capture != 0;  // (1.4 KB of fp64 stores per item: 6 MB per launch of the headline batch -- only on request)
+    const bool capture = v.dbg_capture == 1;  // (1.4 KB of fp64 stores per item: 6 MB per launch of the headline batch -- only on request)
     if (capture && lane < MC) {  // debug copy of S (tests read it through ipp_debug_step_item)
 #pragma unroll
         for (int k = 0; k < MC; ++k) dbg[lane * MC + k] = (lane < m && k < m) ? c[k] : 0.0;

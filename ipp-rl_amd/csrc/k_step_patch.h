@@ -41,6 +41,16 @@ constexpr int kPatchRec = 16;  // floats per column record
 #ifndef IPP_PATCH_KP
 #define IPP_PATCH_KP 8  // (8 rows in flight per wave fit 96 VGPRs: 5 waves per SIMD; 12 rows at 4 waves per SIMD measured 3 % slower)
 #endif
+// Instruction-count build (tools/valu_sections.py): the launch returns at exit point v.dbg_capture - 1 (ipp_debug_capture); the
+// hardware's SQ_INSTS_VALU of that dispatch is the count up to the point.  Results are wrong from there on.
+#ifndef IPP_EXIT_POINTS
+#define IPP_EXIT_POINTS 0
+#endif
+#if IPP_EXIT_POINTS
+#define IPP_EXIT_POINT(k) do { if (v.dbg_capture == (k) + 1) return; } while (0)
+#else
+#define IPP_EXIT_POINT(k) do { } while (0)
+#endif
 #ifndef IPP_PATCH_ABLATE
 #define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads, 256 no rectangle test per row
 #endif
@@ -235,6 +245,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         if (__builtin_amdgcn_readfirstlane(wave) != 0) h = *pl.hs;
     }
     h = uniform_hdr(h);
+    IPP_EXIT_POINT(1);
     const int r0n = max(0, h.yu - R), r1n = min(v.H - 1, h.yd + R);
     const int c0n = max(0, h.xl - R) & ~(VEC - 1), c1n = min(v.W - 1, min(v.W - 1, h.xr + R) | (VEC - 1));
     const int hn = r1n - r0n + 1, wn = c1n - c0n + 1;
@@ -305,6 +316,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     }
     patch_sync<ONE>();
     if (tid == 0) IPP_MARK(item, 4);
+    IPP_EXIT_POINT(2);
     int pos[RJ];
     int n_c = 0;
 #pragma unroll
@@ -454,6 +466,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     patch_sync<ONE>();
     if (tid == 0) IPP_MARK(item, 1);
     IPP_WT(6);
+    IPP_EXIT_POINT(3);
 
     // ------------------------------------------------------------------ m x m algebra (wave 0) / observation (wave OW)
     if (ONE) {
@@ -477,6 +490,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     }
 
     IPP_WT(7);
+    IPP_EXIT_POINT(4);
     // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
     // v_readlane: no LDS round trip per stored row)
     const int n_fast = min(n_lds, 2 * kWave);
@@ -512,6 +526,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     unsigned long long units = 0, needed = 0;
     bool dead = false;
     patch_units<KP>(v, lds, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
+    IPP_EXIT_POINT(5);
     IPP_WT_RESET;
     IPP_WT_COUNT(11, 1);
 
