@@ -143,3 +143,30 @@ def test_step_parts_argument_checks():
     with pytest.raises(IppError):
         dense.set_item_order(torch.arange(4, dtype=torch.int32, device="cuda"))
         dense.step_parts(a[:4], prev[:4], nz[:4], 4 | 8, reward[:4], status[:4], [0, 2, 4], sts)
+
+
+def test_part_and_staging_streams_sit_on_different_hardware_queues():
+    """ipp_probe_stream_pair: two chains of dependent 30-us launches take twice as long on ONE hardware queue as on two.
+    VecIPPEnv(parts=2) classes new streams by queue with it and must end up with its two part streams and the
+    ground-truth staging stream on pairwise different queues (on one queue a staging launch holds back a group's next
+    step: 43-47 M env-steps/s instead of 55-56 M at configs[1], profiles/r04_experiments.txt item 12)."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    env = VecIPPEnv(cfg, 256, episode_steps=8, stagger=True, window_rows=-1, seed=5, parts=2)
+    eng = env.engine
+    launches = 12
+    serial = launches * 0.030 * 2
+    st = torch.cuda.Stream()
+    t_same = eng.probe_stream_pair(st, st, launches)
+    assert t_same > 0.9 * serial, t_same  # one stream: the 2 x 12 launches run one after the other
+    assert env._queues is not None and env._queues["n_queues"] >= 2
+    if env._queues["n_queues"] >= 4:  # the runtime's default: enough queues for both groups, the staging and the caller
+        shared = env._queues["probes_ms_shared"]
+        a, b, s = env.part_stream(0), env.part_stream(1), env._side
+        for x, y in ((a, b), (a, s), (b, s), (a, torch.cuda.current_stream()), (b, torch.cuda.current_stream())):
+            assert min(eng.probe_stream_pair(x, y, launches) for _ in range(2)) < shared, "two of the env's streams share a queue"
+    with pytest.raises(Exception):
+        eng.probe_stream_pair(st, st, 0)
