@@ -1009,6 +1009,19 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
 }
 
 int ipp_engine_destroy(void* engine) {
+#if IPP_MCTS_CLOCKS
+    {
+        unsigned long long c[16];
+        if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_mclk), sizeof c) == hipSuccess && c[8]) {
+            const double lv = (double)c[8], ds = (double)c[9];
+            fprintf(stderr, "[k_mcts_select, us per level (lane 0, sections serialised)] rows + min/max %.2f  PUCT + argmax %.2f  edge fields + cost %.2f  "
+                            "hash lookup %.2f  child record %.2f  bookkeeping %.2f | per descent: start %.2f  leaf + fence %.2f | levels %.0f descents %.0f (%.2f levels each)\n",
+                    c[1] / lv / 100, c[2] / lv / 100, c[3] / lv / 100, c[4] / lv / 100, c[5] / lv / 100, c[6] / lv / 100, c[0] / ds / 100, c[7] / ds / 100, lv, ds, lv / ds);
+            memset(c, 0, sizeof c);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mclk), c, sizeof c);
+        }
+    }
+#endif
     Engine* e = as_engine(engine);
     if (!e) return 0;
     for (auto& p : e->prof) prof_drain(p);

@@ -58,6 +58,18 @@ __device__ __forceinline__ double mc_cost(const ipp_mcts_tables& m, const double
     return (dist - 2 * ramp) / m.vmax + 2 * sqrt(2 * ramp / m.amax);
 }
 
+// (timing build -DIPP_MCTS_CLOCKS=1: lane 0 stamps the sections of a level with the 100 MHz wall clock -- every stamp waits for the
+// loads before it, so the sections do not overlap as they do in the product build; sums printed when the engine is destroyed)
+#ifndef IPP_MCTS_CLOCKS
+#define IPP_MCTS_CLOCKS 0
+#endif
+#if IPP_MCTS_CLOCKS
+__device__ unsigned long long g_mclk[16];
+#define MC_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wall_clock64(); mclk_[k] += n_ - mt_; mt_ = n_; } while (0)
+#else
+#define MC_STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------- selection
 // One wave per root, W descents one after the other.  A descent is a chain of dependent memory round trips (node
 // record -> edge rows -> the chosen edge -> child), so the kernel's time is the number of round trips per level:
@@ -76,6 +88,9 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
     const bool virt = W > 1;
     uint64_t* hk = m.h_keys + (size_t)j * m.table_size;
     int32_t* hv = m.h_vals + (size_t)j * m.table_size;
+#if IPP_MCTS_CLOCKS
+    unsigned long long mclk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mt_ = wall_clock64(), mlev_ = 0;
+#endif
     for (int w = 0; w < W; ++w) {
         int cur = base, plen = 0, leafnode = -1;
         double prev[3] = {prev0[3 * j], prev0[3 * j + 1], prev0[3 * j + 2]};
@@ -84,6 +99,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
         unsigned char fl = m.n_flags[cur];
         int K = m.n_k[cur];
         double ns = m.n_ns[cur];
+        MC_STAMP(0);
         for (int d = depth0; d <= m.horizon; ++d) {
             if (!(budget > 0)) break;  // mcts.py:175-176
             if (!(fl & kNodeExpanded)) {
@@ -136,6 +152,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                 hi = fmax(hi, mc_shfl_xor(hi, o));
                 nz |= __shfl_xor(nz, o, 64);
             }
+            MC_STAMP(1);
             if (K < m.num_actions) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); }  // the zeros of the invalid actions take part (mcts.py:267-278)
             const bool allzero = nz == 0;
             const double pc = m.puct_init + log((ns + m.puct_base + 1) / m.puct_base);
@@ -169,6 +186,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     best = ob; best_k = ok; best_u = ou; best_nsa = on; best_a = oa;
                 }
             }
+            MC_STAMP(2);
             const int k = best_k, a_idx = best_a;  // (K >= 1 for an expanded node)
             // ---- the chosen edge: everything it needs in one round trip
             const double action[3] = {m.actions[3 * (size_t)a_idx], m.actions[3 * (size_t)a_idx + 1], m.actions[3 * (size_t)a_idx + 2]};
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             const double num = m.t_num[row + k];
             const uint64_t zk = m.zkey[a_idx], hcur = m.n_hash[cur];
             const double cost = mc_cost(m, action, prev);
+            MC_STAMP(3);
             if (child < 0) {  // (wave-uniform) transposition lookup: the same measurements in any order are one node
                 if (lane == 0) {
                     uint64_t key = hcur + zk;
@@ -200,10 +219,12 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                 }
                 child = __builtin_amdgcn_readfirstlane(child);
             }
+            MC_STAMP(4);
             // ---- the child's record (the next level's node) next to this level's bookkeeping
             const unsigned char cfl = m.n_flags[child];
             const int cK = m.n_k[child];
             const double cns = m.n_ns[child];
+            MC_STAMP(5);
             if (lane == 0) {
                 if (isnan(num)) {  // first traversal of the edge: one device step
                     m.t_num[row + k] = INFINITY;
@@ -238,6 +259,10 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     m.n_ns[cur] = ns + 1;
                 }
             }
+            MC_STAMP(6);
+#if IPP_MCTS_CLOCKS
+            mlev_ += 1;
+#endif
             plen += 1;
             budget -= cost;
             prev[0] = action[0]; prev[1] = action[1]; prev[2] = action[2];
@@ -249,7 +274,11 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             m.leaf[w * m.roots + j] = leafnode;
         }
         __threadfence();  // lane 0's stores (virtual visits, children, flags) before the next descent's loads
+        MC_STAMP(7);
     }
+#if IPP_MCTS_CLOCKS
+    if (lane == 0) { for (int q = 0; q < 8; ++q) atomicAdd(&g_mclk[q], mclk_[q]); atomicAdd(&g_mclk[8], mlev_); atomicAdd(&g_mclk[9], (unsigned long long)W); }
+#endif
 }
 
 // Inputs of the level's ipp_tree_step that depend on the previous level's results: the parents' device paths.
