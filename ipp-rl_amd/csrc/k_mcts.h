@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             m.p_len[w * m.roots + j] = plen;
             m.leaf[w * m.roots + j] = leafnode;
         }
-        __threadfence();  // lane 0's stores (virtual visits, children, flags) before the next descent's loads
+        // lane 0's stores (virtual visits, children, flags) before the next descent's loads: the SAME wave reads them, through the
+        // same L1, so workgroup scope is enough (wait for the stores; no cache action) -- __threadfence() is an agent-scope
+        // release, which writes the L2 back: 11 of the 43 us of a descent (lane-0 clocks of the -DIPP_MCTS_CLOCKS build)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         MC_STAMP(7);
     }
 #if IPP_MCTS_CLOCKS
