@@ -677,6 +677,10 @@ def main(argv=None):
                 "single_launch_ms_avg": rec["single_launch_ms"],
                 "single_launch_frac": (rec["bytes_per_launch"] / (rec["single_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rec["single_launch_ms"] else None,
                 "part_launch_ms_avg": rec["part_launch_ms_avg"], "part_launches": rec["part_launches"],
+                # one group's launch on its own: its share of the step's bytes / its own duration -- while the other group's launch runs
+                # beside it (two of these overlap; the step-level figure above is bytes / the union of their intervals)
+                "part_launch_frac_each": (rec["bytes_per_launch"] / rec["parts"] / (rec["part_launch_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                         if rec["part_launch_ms_avg"] else None,
                 "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
                 "necessary_bytes_per_launch": rec["necessary_bytes_per_launch"],
                 "frac_necessary": (rec["necessary_bytes_per_launch"] / (rec["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)

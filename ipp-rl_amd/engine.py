@@ -378,8 +378,12 @@ class IPPEngine:
         tensors (the batched driver's loop); nothing joins the streams here."""
         n = int(actions.shape[0])
         P = len(streams)
-        begins = (C.c_int32 * (P + 1))(*[int(b) for b in part_begin])
-        sts = (C.c_void_p * P)(*[C.c_void_p(st.cuda_stream) for st in streams])
+        key = (tuple(part_begin), tuple(st.cuda_stream for st in streams))
+        cached = getattr(self, "_parts_c", None)
+        if cached is None or cached[0] != key:  # (the batched driver passes the same partition and streams every step)
+            cached = self._parts_c = (key, (C.c_int32 * (P + 1))(*[int(b) for b in part_begin]),
+                                      (C.c_void_p * P)(*[C.c_void_p(st.cuda_stream) for st in streams]))
+        begins, sts = cached[1], cached[2]
         init = (C.c_double * 3)(*[float(x) for x in init_action]) if init_action is not None else None
         _ffi.check(self._lib.ipp_step_parts(self._h, n, self._ptr(actions), self._ptr(prev_actions), self._ptr(meas_noise), int(flags),
                                             self._ptr(reward), self._ptr(status), self._ptr(reset_src), self._ptr(reset_gt), init,

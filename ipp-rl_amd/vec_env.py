@@ -492,11 +492,10 @@ class VecIPPEnv:
             raise RuntimeError("step_async needs the scheduled resets inside the step launch (fused_reset)")
         a = actions if (torch.is_tensor(actions) and actions.dtype == torch.float64 and actions.is_cuda and actions.is_contiguous()) \
             else self.engine._dev(actions, torch.float64).reshape(-1, 3).contiguous()
-        main = torch.cuda.current_stream(self.device)
         streams = self._part_streams
         if not inputs_ready or self._main_dirty:
             self._main_dirty = False
-            self._ev_inputs.record(main)
+            self._ev_inputs.record(torch.cuda.current_stream(self.device))
             for st in streams:
                 st.wait_event(self._ev_inputs)
         scheduled = None
@@ -518,7 +517,8 @@ class VecIPPEnv:
             n = int(self._reset_ids_by_phase[p].numel())
             scheduled = (p, set_ * K + j, n) if n > 0 else None
             blk = (set_, j == K - 1)
-        nz = self._noise_plane_parts(main, streams)
+        # (the caller's stream is looked up only when a noise ring is refilled: torch.cuda.current_stream costs ~5 us)
+        nz = self._noise_plane_parts(None if self._noise_pos else torch.cuda.current_stream(self.device), streams)
         fused = {}
         if scheduled is not None:
             p, k, n = scheduled
