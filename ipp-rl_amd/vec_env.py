@@ -129,9 +129,10 @@ class VecIPPEnv:
         # Only where the engine runs the fused step kernel: on the split path of large batches (k_prepare + k_gain_factor in
         # chunks) the resets are a launch of their own either way and the folded form is slower (32768 envs: 24.9 vs 28.7 M).
         # (with shuffled priors the folded form is available -- fused_reset="always" -- but not the default: measured equal
-        # to the separate launch, 19.4-19.5 vs 19.3-20.3 M env-steps/s at window 12)
+        # to the separate launch, 19.4-19.5 vs 19.3-20.3 M env-steps/s at window 12; a partitioned env takes it: step_async needs the
+        # resets inside the step launches)
         self._fused_reset = bool(fused_reset and stagger and state == "factor" and
-                                 (not shuffle_prior_cov or fused_reset == "always") and
+                                 (not shuffle_prior_cov or fused_reset == "always" or self.parts > 1) and
                                  self.engine.info.fused_step == 1 and self.engine.info.window_rows > 0 and
                                  4 * B * self.episode_steps <= (64 << 20))
         self._reset_src_by_phase = {}

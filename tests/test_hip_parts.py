@@ -36,15 +36,18 @@ def _same_state(a, b, envs_to_check):
         assert torch.equal(a.ground_truth(e), b.ground_truth(e)), e
 
 
-@pytest.mark.parametrize("parts,window_rows,tile_threads", [(2, -1, 0), (3, -1, 0), (2, 12, 256)])
-def test_async_parts_equal_single_launch(parts, window_rows, tile_threads):
+@pytest.mark.parametrize("parts,window_rows,tile_threads,shuffle", [(2, -1, 0, False), (3, -1, 0, False), (2, 12, 256, False), (2, 12, 0, True)])
+def test_async_parts_equal_single_launch(parts, window_rows, tile_threads, shuffle):
     """Full-size batch (races and stale reads show at 4096 envs, not at 64), 5 episodes of 8 steps: > 2 noise rings, > 4 staged
     ground-truth blocks; the async steps are never joined inside the loop except every 7th step."""
     import torch
     from ipp_rl_amd.vec_env import cell_centre_actions
 
     B, T = 4096, 8
-    cfg, (one, many) = _pair(parts, B=B, T=T, window_rows=window_rows, tile_threads=tile_threads)
+    # shuffle: per-episode priors (shuffle_prior_cov, window 12): the partitioned env installs them through the resets folded into
+    # its step launches (ipp_set_reset_prior), the single-launch env through its separate reset launch
+    cfg, (one, many) = _pair(parts, B=B, T=T, window_rows=window_rows, tile_threads=tile_threads, shuffle_prior_cov=shuffle)
+    assert bool(many._fused_reset) and bool(one._fused_reset) == (not shuffle)
     assert int(many.engine.info.fused_step) == 1
     assert int(many.engine.info.patch_layout) == (1 if tile_threads == 0 else 0)  # (explicit tile_threads: the band-tile fused kernel)
     acts = [torch.as_tensor(cell_centre_actions(cfg, t, 0, B, B, ALTS), device="cuda") for t in range(5 * T)]
