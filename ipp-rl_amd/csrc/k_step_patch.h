@@ -54,6 +54,12 @@ constexpr int kPatchRec = 16;  // floats per column record
 #ifndef IPP_PATCH_ABLATE
 #define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads, 256 no rectangle test per row
 #endif
+#ifndef IPP_MD_STREAM
+#define IPP_MD_STREAM 0  // non-temporal hint on the units' mean / variance: 1 loads, 2 stores (A/B: see profiles/r04_experiments.txt 18)
+#endif
+#ifndef IPP_STORE_AUX
+#define IPP_STORE_AUX (IPP_NT_STORES ? 2 : 0)  // cache policy bits of the new rows' stores (1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef IPP_PATCH_AUX
 #define IPP_PATCH_AUX 2  // cache policy bits of the row requests (2: nt)
 #endif
@@ -144,6 +150,7 @@ struct StepIo {
     }
     __device__ __forceinline__ void load_pre(int cell0, int flat, int rrow, int rcol, float (&md)[2][2]) const {
         if (IPP_PATCH_ABLATE & 128) { md[0][0] = md[0][1] = 0.5f; md[1][0] = md[1][1] = 1.f; }
+        else if (IPP_MD_STREAM & 1) { load_stream<2>(mean_rw + cell0, md[0]); load_stream<2>(diag_rw + cell0, md[1]); }
         else { load_vec<2>(mean_rw + cell0, md[0]); load_vec<2>(diag_rw + cell0, md[1]); }
     }
     __device__ __forceinline__ void store(bool commit, bool lane_valid, int cell0, int flat, unsigned flat4, const float (&acc)[2][9],
@@ -153,11 +160,11 @@ struct StepIo {
             float outv[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) outv[c] = md[1][c] - dred[c];
-            store_vec<2>(diag_rw + cell0, outv);
+            if (IPP_MD_STREAM & 2) store_stream<2>(diag_rw + cell0, outv); else store_vec<2>(diag_rw + cell0, outv);
             if (!cov_only) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) outv[c] = md[0][c] + dmean[c];
-                store_vec<2>(mean_rw + cell0, outv);
+                if (IPP_MD_STREAM & 2) store_stream<2>(mean_rw + cell0, outv); else store_vec<2>(mean_rw + cell0, outv);
             }
         }
         // the m new rows (buffer stores through the item's resource: the row as scalar offset, lanes outside the rectangle out of
@@ -169,7 +176,7 @@ struct StepIo {
                 rowv t;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) t[c] = acc[c][j];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, lane_valid ? flat4 : 0xffffffffu, row0_bytes + j * pstride_bytes, IPP_NT_STORES ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, lane_valid ? flat4 : 0xffffffffu, row0_bytes + j * pstride_bytes, IPP_STORE_AUX);
             }
     }
 };
