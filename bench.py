@@ -291,7 +291,8 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
                     stagger=True, tile_threads=tile_threads, window_rows=window_rows, fused_reset=fused_resets,
                     shuffle_prior_cov=shuffle_prior, parts=1 if predict_only else parts)
     eng = env.engine
-    use_parts = env.parts > 1 and bool(env._fused_reset)
+    # (a runtime with fewer hardware queues than groups -- GPU_MAX_HW_QUEUES -- makes the groups' launches take turns: one launch per step then)
+    use_parts = env.parts > 1 and bool(env._fused_reset) and env.part_queues_distinct
     n_total = T + warmup + (2 * regions + 2) * steps
     # synthetic inputs resident in HBM before the timed region
     actions = torch.stack([

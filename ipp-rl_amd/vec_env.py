@@ -466,8 +466,17 @@ class VecIPPEnv:
             picks.append(members[0][0] if members[0] and members[0][0] not in picks else torch.cuda.Stream(device=dev))
         side = free[0] if free else (members[0][0] if members[0] and members[0][0] not in picks else
                                      (others[-1] if others and not want_parts else torch.cuda.Stream(device=dev)))
-        self._queues = {"n_queues": len(reps), "pool": pool, "members": members, "probes_ms_shared": shared}
+        # parts_distinct: every group got a hardware queue of its own (if not -- fewer queues than groups, GPU_MAX_HW_QUEUES -- the
+        # partitioned schedule is slower than one launch per step: callers that only want throughput should step synchronously)
+        self._queues = {"n_queues": len(reps), "pool": pool, "members": members, "probes_ms_shared": shared,
+                        "parts_distinct": len(others) >= want_parts}
         return (picks or None), side
+
+    @property
+    def part_queues_distinct(self) -> bool:
+        """False when two part streams had to share a hardware queue (their launches then take turns: step_async still gives
+        the same results, but slower than step())."""
+        return self._queues is None or bool(self._queues.get("parts_distinct", True))
 
     def part_stream(self, p: int):
         """The stream that steps part p (run that part's policy on it and no event is needed around step_async)."""

@@ -166,6 +166,7 @@ def test_part_and_staging_streams_sit_on_different_hardware_queues():
     t_same = eng.probe_stream_pair(st, st, launches)
     assert t_same > 0.9 * serial, t_same  # one stream: the 2 x 12 launches run one after the other
     assert env._queues is not None and env._queues["n_queues"] >= 2
+    assert env.part_queues_distinct == (env._queues["n_queues"] >= 3)
     if env._queues["n_queues"] >= 4:  # the runtime's default: enough queues for both groups, the staging and the caller
         shared = env._queues["probes_ms_shared"]
         a, b, s = env.part_stream(0), env.part_stream(1), env._side
