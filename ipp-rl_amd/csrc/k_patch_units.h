@@ -33,6 +33,9 @@
 #ifndef IPP_UNIT_STAGED
 #define IPP_UNIT_STAGED 0    // 1: the bookkeeping of a request group stage by stage over its rows (independent instructions per stage)
 #endif
+#ifndef IPP_UNIT_SKIP_SURPLUS
+#define IPP_UNIT_SKIP_SURPLUS 0  // 1: no FMAs for the masked surplus rows of remainder groups (-0.44 M of 31.9 M vector instructions, no time: profiles/r04_experiments.txt 19)
+#endif
 #ifndef IPP_UNIT_MDFIRST
 #define IPP_UNIT_MDFIRST 0   // 1: mean / variance of a unit's cells requested at the start of the unit
 #endif
@@ -124,6 +127,14 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= g.n_units) break;
         IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 1, wall_clock64());
+#if defined(IPP_ISSUE_TEST) && IPP_ISSUE_TEST  // (tools/skip_timing.py: extra independent vector instructions at the top of a unit, where few registers are live)
+        if (v.dbg_capture >= 11) {
+            float d0 = (float)lane, d1 = 1.f, d2 = 2.f, d3 = 3.f;
+            for (int q = 0; q < 32 * (v.dbg_capture - 10); ++q)
+                asm volatile("v_fmac_f32 %0, %4, %4\n v_fmac_f32 %1, %4, %4\n v_fmac_f32 %2, %4, %4\n v_fmac_f32 %3, %4, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0.f));
+            if (d0 + d1 + d2 + d3 == 12345.678f) units += 1;
+        }
+#endif
         const int idx = 2 * (u * kWave + lane);
         const int prow = (int)(((unsigned)idx * g.wdiv) >> kUnitDivShift), pcol = idx - prow * g.wn;
 #if IPP_UNIT_PWSTRIDE
@@ -234,10 +245,16 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
         // off.  The row's -HT values live in the lanes of ONE register (value l & 15 in lane l) and reach the 18 FMAs through
         // v_fmac_f32_dpp row_newbcast.
         int in_rect = 0;  // lanes inside the stored columns' rectangles, summed over the rows of the unit
-        auto fma_rows = [&](auto n_tag, const rowv* uu, const float* qr) {
+        // nreal < N (remainder groups): the surplus rows (requests masked off) skip their FMAs too -- a wave-uniform branch per row instead
+        // of 18 vector instructions on zeros (a third of the row requests of the headline workload are such rows: 3 M of 32 M
+        // vector instructions per launch, profiles/r04_valu_sections.txt)
+        auto fma_rows = [&](auto n_tag, const rowv* uu, const float* qr, int nreal = 1 << 30) {
             constexpr int N = decltype(n_tag)::value;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
+#if IPP_UNIT_SKIP_SURPLUS
+                if (i >= nreal) continue;  // (wave-uniform)
+#endif
                 if (IPP_PATCH_ABLATE & 16) { acc[0][0] = fmaf(uu[i][0], qr[i], acc[0][0]); acc[1][0] = fmaf(uu[i][1], qr[i], acc[1][0]); continue; }
                 const float ur[VEC] = {uu[i][0], uu[i][1]};
                 fmac_row<VEC, MC>(acc, qr[i], ur);
@@ -323,7 +340,7 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
                 qr[i] = lds.rec[(size_t)(page * kWave + e) * kPatchRec + (lane & 15)];  // (read while the requests are in flight)
             }
             __builtin_amdgcn_sched_barrier(0);  // all N requests leave before the first wait
-            fma_rows(n_tag, uu, qr);
+            if (FULL) fma_rows(n_tag, uu, qr); else fma_rows(n_tag, uu, qr, nreal);
         };
         // (IPP_UNIT_PIPE) whole groups software-pipelined: the requests of group g + 1 leave before the FMAs of group g, so a wave keeps
         // 2 KP rows in flight and the round trip of a group hides behind the arithmetic of its predecessor
@@ -400,14 +417,6 @@ __device__ __forceinline__ void patch_units(const View& v, const PatchLds& lds, 
             fma_rows(std::integral_constant<int, KP>{}, uu, qr);
         }
 
-#if defined(IPP_ISSUE_TEST) && IPP_ISSUE_TEST  // (tools/skip_timing.py; costs registers: a build of its own)
-        if (v.dbg_capture >= 11) {  // (issue-bound test: 128 / 256 independent-ish vector instructions per unit that change nothing)
-            float d0 = (float)lane, d1 = 1.f, d2 = 2.f, d3 = 3.f;
-            for (int q = 0; q < 32 * (v.dbg_capture - 10); ++q)
-                asm volatile("v_fmac_f32 %0, %4, %4\n v_fmac_f32 %1, %4, %4\n v_fmac_f32 %2, %4, %4\n v_fmac_f32 %3, %4, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0.f));
-            if (d0 + d1 + d2 + d3 == 12345.678f) acc[0][0] += 1.f;
-        }
-#endif
         IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 0, ((unsigned long long)u << 32) | (unsigned)nact);
         IPP_UNIT_TRACE(ua.item, (int)(threadIdx.x >> 6), tslot, 2, wall_clock64());
         IPP_WT(2);

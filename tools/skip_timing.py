@@ -1,6 +1,6 @@
 """Step time of the two-group schedule with EXTRA vector instructions in every unit (the -DIPP_EXIT_POINTS=1 build; results
 unchanged): does the time follow the instruction count (tools/valu_sections.sh), i.e. is the step bound by vector issue?
-    IPP_HIP_LIB=tools/probes/libipp_exit.so python tools/skip_timing.py"""
+    IPP_HIP_LIB=tools/probes/libipp_issue.so python tools/skip_timing.py"""
 import os
 import sys
 import time
