@@ -289,11 +289,11 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     B, T = envs_local, episode_steps
     env = VecIPPEnv(cfg, B, state=state, episode_steps=T, device=device, seed=1234, env_id_offset=env_lo,
                     stagger=True, tile_threads=tile_threads, window_rows=window_rows, fused_reset=fused_resets,
-                    shuffle_prior_cov=shuffle_prior, parts=1 if predict_only else parts)
+                    shuffle_prior_cov=shuffle_prior, parts=parts)
     eng = env.engine
     # (a runtime with fewer hardware queues than groups -- GPU_MAX_HW_QUEUES -- makes the groups' launches take turns: one launch per step then)
     use_parts = env.parts > 1 and bool(env._fused_reset) and env.part_queues_distinct
-    n_total = T + warmup + (2 * regions + 2) * steps
+    n_total = T + warmup + (2 * regions + 3) * steps
     # synthetic inputs resident in HBM before the timed region
     actions = torch.stack([
         torch.as_tensor(cell_centre_actions(cfg, t, env_lo, env_lo + B, total_envs, ALTITUDES), dtype=torch.float64)
@@ -304,10 +304,18 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     for _ in range(T):  # pre-roll: reach the stationary mix of episode phases (untimed setup, not warmup)
         env.step(actions[t_idx]); t_idx += 1
 
+    from ipp_rl_amd import _ffi
+
+    predict_flags = _ffi.IPP_COV_ONLY | _ffi.IPP_PREDICT_ONLY | _ffi.IPP_ADAPTIVE | _ffi.IPP_USE_FLIGHT_TIME
+
     def run_steps(k):
         nonlocal t_idx
         for _ in range(k):
-            if predict_only:
+            if predict_only and use_parts:
+                # rewards of candidate actions, no state write: the two groups' launches alternate on their queues (ipp_step_parts)
+                eng.set_item_order(env._orders_parts[env.t % T])
+                eng.step_parts(actions[t_idx], env.prev, None, predict_flags, env.reward, env.status, env._part_begin, env._part_streams)
+            elif predict_only:
                 eng.step(actions[t_idx], env.prev, predict_only=True, cov_only=True, reward_out=env.reward,
                          status_out=env.status)
             elif use_parts:
@@ -320,7 +328,11 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     def run_steps_sync(k):  # one launch per step on one stream (the schedule of rounds 1-3), same env, same kernels
         nonlocal t_idx
         for _ in range(k):
-            env.step(actions[t_idx], after_step_hook=_no_hook)
+            if predict_only:
+                eng.set_item_order(env._orders[env.t % T])
+                eng.step(actions[t_idx], env.prev, predict_only=True, cov_only=True, reward_out=env.reward, status_out=env.status)
+            else:
+                env.step(actions[t_idx], after_step_hook=_no_hook)
             t_idx += 1
 
     def median_region(regs):
@@ -346,7 +358,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     ranks_buf = torch.empty(B, dtype=torch.int32, device=device)
     for _ in range(steps):
         if predict_only:
-            run_steps(1)
+            run_steps_sync(1)
             rank_sum += eng.ranks(ranks_buf).double().sum()  # rows streamed (nothing appended)
         else:
             # rows streamed + columns appended by this step = ranks right after the step kernel and before

@@ -205,6 +205,8 @@ int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const do
  *   part_begin  [host] int32[n_parts + 1], increasing, part_begin[0] == 0, part_begin[n_parts] == n
  *   streams     [host] hipStream_t[n_parts]
  * Other arguments: ipp_step_autoreset.  Results are bit-identical to the single launch (same kernel, same items).
+ * With IPP_PREDICT_ONLY (rewards of candidate actions, Mapping.simulate_prediction_step without the state write: no resets, no
+ * IPP_UPDATE_PREV) consecutive calls do not depend on each other at all; the parts still keep two launches in flight.
  */
 int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_action, const float* meas_noise,
                    uint32_t flags, float* reward, int32_t* status, const int32_t* reset_src, const float* reset_gt,

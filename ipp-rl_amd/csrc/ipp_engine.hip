@@ -1154,8 +1154,9 @@ int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_a
     if (!action || !prev_action || !reward || !part_begin || !streams) return fail(-1, "null argument");
     if (e->v.mode != IPP_FACTOR || !(e->fused || e->patch) || e->pipe || e->v.meas_cap != 9 || e->v.vec != 2)
         return fail(-1, "ipp_step_parts: engines whose step is one fused kernel only (ipp_info.fused_step)");
-    if (flags & IPP_PREDICT_ONLY) return fail(-1, "ipp_step_parts: not with IPP_PREDICT_ONLY");
-    if (flags & ~(IPP_COV_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_GIVEN_OBSERVATION | IPP_UPDATE_PREV)) return fail(-1, "unknown flag bits 0x%x", flags);
+    // (predict-only parts: reward / status of every item, no state write -- consecutive calls do not depend on each other at all)
+    if ((flags & IPP_PREDICT_ONLY) && (reset_src || (flags & IPP_UPDATE_PREV))) return fail(-1, "ipp_step_parts: IPP_PREDICT_ONLY with resets or IPP_UPDATE_PREV");
+    if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME | IPP_GIVEN_OBSERVATION | IPP_UPDATE_PREV)) return fail(-1, "unknown flag bits 0x%x", flags);
     if (n <= 0 || n > e->v.max_batch || n > e->v.cap) return fail(-1, "n = %d outside [1, min(max_batch, capacity)]", n);
     if (!e->v.item_order || e->v.item_order_n != n) return fail(-1, "ipp_step_parts: needs the dispatch order of all n items (ipp_set_item_order)");
     if (n_parts < 1 || n_parts > kMaxChunks) return fail(-1, "n_parts = %d outside [1, %d]", n_parts, kMaxChunks);

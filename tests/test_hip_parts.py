@@ -134,8 +134,15 @@ def test_step_parts_argument_checks():
     for bad in ([0, 64, 64], [0, 32, 63], [1, 32, 64]):
         with pytest.raises(IppError):
             eng.step_parts(a, prev, nz, 4 | 8, reward, status, bad, sts)
-    with pytest.raises(IppError):  # predict-only steps are not partitioned
-        eng.step_parts(a, prev, nz, 2, reward, status, [0, 32, 64], sts)
+    with pytest.raises(IppError):  # predict-only parts do not move the UAVs (IPP_PREDICT_ONLY | IPP_UPDATE_PREV)
+        eng.step_parts(a, prev, nz, 2 | 32, reward, status, [0, 32, 64], sts)
+    # predict-only parts = the predict-only launch: rewards of the candidate actions, state untouched
+    r0, s0 = eng.step(a, prev, meas_noise=nz, predict_only=True, cov_only=True)
+    torch.cuda.synchronize()
+    ranks0 = eng.ranks().clone()
+    eng.step_parts(a, prev, None, 1 | 2 | 4 | 8, reward, status, [0, 32, 64], sts)  # (the flags of the call above)
+    torch.cuda.synchronize()
+    assert torch.equal(reward, r0) and torch.equal(status, s0) and torch.equal(eng.ranks(), ranks0)
     eng.step_parts(a, prev, nz, 4 | 8, reward, status, [0, 32, 64], sts)
     torch.cuda.synchronize()
     ref = IPPEngine(cfg, capacity=64, state="factor", rank_cap=90, window_rows=-1, fixed_prior=True)
