@@ -167,6 +167,16 @@ class Ranks:
         self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
         return [float(x.item()) for x in out], float(tmax.item())
 
+    def all_agree(self, flag: bool) -> bool:
+        """True iff `flag` holds on EVERY rank (a choice that changes how many collectives a rank enters must be the same everywhere)."""
+        if self.dist is None:
+            return bool(flag)
+        import torch
+
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -292,7 +302,9 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
                     shuffle_prior_cov=shuffle_prior, parts=parts)
     eng = env.engine
     # (a runtime with fewer hardware queues than groups -- GPU_MAX_HW_QUEUES -- makes the groups' launches take turns: one launch per step then)
-    use_parts = env.parts > 1 and bool(env._fused_reset) and env.part_queues_distinct
+    # the schedule is the job's, not a rank's: a rank whose streams had to share a queue takes every rank to one launch per step
+    # (the one-launch legs add timed regions = barriers: a per-rank choice would leave ranks in different collectives)
+    use_parts = ranks.all_agree(env.parts > 1 and bool(env._fused_reset) and env.part_queues_distinct)
     n_total = T + warmup + (2 * regions + 3) * steps
     # synthetic inputs resident in HBM before the timed region
     actions = torch.stack([

@@ -47,11 +47,13 @@ def _worker(rank, world, port, out_dir):
             time.sleep(0.004 * (rank + 1))
             calls.append(1)
 
+    # a choice that changes the number of collectives a rank enters (the schedule of the step) holds only if every rank makes it
+    agree = [ranks.all_agree(True), ranks.all_agree(rank == 0), ranks.all_agree(False)]
     per_rank, tmax = bench.timed_region(run_steps, 5, lambda: None, ranks)
     value = bench.aggregate_rate(total, 5, tmax)
     np.save(os.path.join(out_dir, f"acts{rank}.npy"), acts)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
-        json.dump({"weak": weak, "strong": strong, "per_rank": per_rank, "tmax": tmax, "value": value, "calls": len(calls)}, fh)
+        json.dump({"weak": weak, "strong": strong, "per_rank": per_rank, "tmax": tmax, "value": value, "calls": len(calls), "agree": agree}, fh)
     ranks.close()
 
 
@@ -71,6 +73,7 @@ def test_two_rank_sharding_and_timing_through_bench_functions(tmp_path):
     # timing: exactly 5 steps each; every rank sees the same per-rank list; the max is rank 1's time (>= 5 x 8 ms);
     # rank 0's own time includes waiting at the closing barrier, so it is >= its own 20 ms of work
     for o in out:
+        assert o["agree"] == [True, False, False]
         assert o["calls"] == 5 and len(o["per_rank"]) == 2
         assert o["per_rank"] == out[0]["per_rank"] and o["tmax"] == out[0]["tmax"]
         assert o["tmax"] == max(o["per_rank"]) and o["tmax"] >= 0.040 and o["per_rank"][0] >= 0.020
