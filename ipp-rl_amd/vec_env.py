@@ -443,8 +443,10 @@ class VecIPPEnv:
             self._queues = None
             return ([torch.cuda.Stream(device=dev) for _ in range(want_parts)] or None), torch.cuda.Stream(device=dev)
         launches = 12
-        shared = launches * 0.030 * 1.5  # ms: the two chains ran one after the other
         main = torch.cuda.current_stream(dev)
+        # "shared" = the two chains ran one after the other: calibrated on ONE stream paired with itself (2 x 12 launches in a row), so
+        # that other work on the device while the env is built stretches both sides of the comparison (nominal: 0.72 ms -> 0.54 ms)
+        shared = max(launches * 0.030 * 1.5, 0.75 * min(self.engine.probe_stream_pair(main, main, launches) for _ in range(2)))
         reps, members = [main], [[]]  # queue 0 = the caller's
         pool = []
         while len(pool) < 16 and len(reps) - 1 < want_parts + 1:
