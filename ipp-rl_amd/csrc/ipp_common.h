@@ -170,6 +170,7 @@ struct View {
     int W, H, N, Npad, T, n_tiles, vec, env_base;  // env_base: first env of a chunk when env_ids == NULL
     int mode, cap, rank_cap, max_batch;
     int window_rows, tile_cells;
+    int tile_shift;  // log2(tile_cells) when it is a power of two, else -1 (the header's tile span then takes the division)
     const int* item_order;  // [n] dispatch order of the items of a launch (ipp_set_item_order), NULL: xcd_item
     int item_order_n;
     int clip_cols;  // windowed factor state: new columns are zero on the grid COLUMNS farther than window_rows from the footprint too

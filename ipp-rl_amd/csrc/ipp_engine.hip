@@ -754,6 +754,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
     v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
+    v.tile_shift = -1;
+    for (int sh = 0; sh < 20; ++sh) if ((1 << sh) == v.tile_cells) v.tile_shift = sh;
     // two-dimensional windows (k_gain_factor.h): every kernel that appends columns of a windowed state clips them (the
     // one-wave-per-item kernel of tile_threads = 64 and the pipelined kernel do not: off for those engines)
     v.clip_cols = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0 && L.T != 64 && cfg->x_dim > 2 * cfg->window_rows + 13) ? 1 : 0;

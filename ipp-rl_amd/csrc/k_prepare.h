@@ -109,8 +109,11 @@ __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int
     h.rf = (az > v.rf_alt) ? 2 : 1;                                               // cameras.py:125
     h.w = xr - xl + 1;
     h.h = yd - yu + 1;
-    h.nx = (h.w - 1) / h.rf + 1;                                                  // sensor_models.py:57
-    h.ny = (h.h - 1) / h.rf + 1;
+    // (rf is 1 or 2 and the operands are >= 0: a shift is the division -- a runtime integer division is ~35 vector instructions,
+    // the header had six of them)
+    const int rsh = h.rf - 1;
+    h.nx = ((h.w - 1) >> rsh) + 1;                                                // sensor_models.py:57
+    h.ny = ((h.h - 1) >> rsh) + 1;
     h.m = h.nx * h.ny;                                                            // mappings.py:125-126
     h.f = h.w * h.h;
 #ifdef IPP_HDR_ABLATE
@@ -137,7 +140,7 @@ __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int
     if (!ok || h.m > MC || h.f > FC) h.status = IPP_STATUS_BAD_FOOTPRINT;
     if (h.status == IPP_STATUS_OK && h.rf > 1 && !(flags & IPP_COV_ONLY)) {
         // area resampler is only restated for shrinking scales
-        const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
+        const int ocols = (h.h + h.rf - 1) >> rsh, orows = (h.w + h.rf - 1) >> rsh;
         if (h.w < ocols || h.h < orows) h.status = IPP_STATUS_BAD_FOOTPRINT;
     }
     if (MODE == IPP_FACTOR && h.status == IPP_STATUS_OK && h.commit && h.rank + h.m > v.rank_cap) {
@@ -147,8 +150,13 @@ __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int
     if (MODE == IPP_FACTOR && v.window_rows > 0 && ok) {
         // the appended columns are kept on the grid rows within window_rows of the footprint (whole tiles)
         const int row_lo = max(0, yu - v.window_rows), row_hi = min(v.H - 1, yd + v.window_rows);
-        h.t_lo = (row_lo * v.W) / v.tile_cells;
-        h.t_hi = ((row_hi + 1) * v.W - 1) / v.tile_cells;
+        if (v.tile_shift >= 0) {  // (uniform)
+            h.t_lo = (row_lo * v.W) >> v.tile_shift;
+            h.t_hi = ((row_hi + 1) * v.W - 1) >> v.tile_shift;
+        } else {
+            h.t_lo = (row_lo * v.W) / v.tile_cells;
+            h.t_hi = ((row_hi + 1) * v.W - 1) / v.tile_cells;
+        }
     }
     h.rows = (MODE == IPP_FACTOR) ? h.rank : h.f;
     if (h.status == IPP_STATUS_BAD_FOOTPRINT) { h.m = 0; h.f = 0; h.rows = 0; h.commit = 0; }
