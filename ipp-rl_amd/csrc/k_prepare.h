@@ -935,6 +935,9 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
 }
 
 
+#ifndef IPP_SOLVE_MFMA
+#define IPP_SOLVE_MFMA 0  // 1: H U^T (H U^T)^T of the m x m system on the matrix unit (186 GPU tests green, +0-1 %: profiles/r04_experiments.txt 24); 0: the pair loop of rounds 2-3
+#endif
 template <int MC>
 __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, const int item, unsigned flags,
                                                unsigned char* small, const float* ht, int si, int sk, float* linv_f,
@@ -975,6 +978,50 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         }
         if (pi == pj) mine += R;
     }
+#if IPP_SOLVE_MFMA
+    // ---- factor part: - sum_k HT[i][k] HT[j][k] = -(HT HT^T)[i][j] on the matrix unit: v_mfma_f64_16x16x4_f64 with A = B =
+    // HT[i = lane & 15][k0 + (lane >> 4)] (one LDS read and one conversion per lane and four columns k; fp64 products of fp32 values
+    // are exact), D[row = (lane >> 4) + 4 reg][col = lane & 15].  The pair loop below was 5 vector instructions per column k on all
+    // 45 pair lanes (fp64: ~1.3 M of a launch's 31 M, more of its vector time); this is 1.5 per k.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    v4d sacc0 = {0.0, 0.0, 0.0, 0.0}, sacc1 = {0.0, 0.0, 0.0, 0.0};
+    {
+        const int ai = lane & 15, ak = lane >> 4;
+        const bool ion = ai < m;
+        const float* hp = ht + ai * si + ak * sk;
+        int k0 = 0;
+        for (; k0 + 8 <= r; k0 += 8) {  // (two independent accumulation chains)
+            const float x0 = ion ? hp[k0 * sk] : 0.f, x1 = ion ? hp[(k0 + 4) * sk] : 0.f;
+            sacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0, (double)x0, sacc0, 0, 0, 0);
+            sacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x1, (double)x1, sacc1, 0, 0, 0);
+        }
+        for (; k0 < r; k0 += 4) {
+            const float x0 = (ion && k0 + ak < r) ? hp[k0 * sk] : 0.f;
+            sacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0, (double)x0, sacc0, 0, 0, 0);
+        }
+        if (ht2) {
+            const float* hp2 = ht2 + ai * si + ak * sk;
+            for (int k2 = 0; k2 < r_ht2; k2 += 4) {
+                const float x0 = (ion && k2 + ak < r_ht2) ? hp2[k2 * sk] : 0.f;
+                sacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0, (double)x0, sacc1, 0, 0, 0);
+            }
+        }
+    }
+    if (pair_on) {
+        S[pi * LD + pj] = mine;
+        S[pj * LD + pi] = mine;
+    }
+    wave_lds_sync();
+    {
+        const int col = lane & 15, row0 = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {  // rows row0 + 4 q <= 11; every (row, col) of S sits in exactly one lane and register
+            const int row = row0 + 4 * q;
+            if (row < m && col < m) S[row * LD + col] -= sacc0[q] + sacc1[q];
+        }
+    }
+    wave_lds_sync();
+#else
     // ---- factor part: - sum_k HT[i][k] HT[j][k] by the pair's own lane, all pairs in lock step (two LDS reads per k,
     // eight k in flight; no cross-lane reduction: 45 wave-wide fp64 butterflies through ds_bpermute took 25 us);
     // fp64 products of fp32 values are exact
@@ -1005,6 +1052,7 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         S[pj * LD + pi] = mine;
     }
     wave_lds_sync();
+#endif
 
     // ---- Cholesky S = C C^T in registers: lane i holds row i (c[k] = C[i][k]); the reference uses L = C^T.  mappings.py:185
     double c[MC];
