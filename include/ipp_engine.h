@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 11
+#define IPP_ABI_VERSION 12
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -110,6 +110,9 @@ typedef struct ipp_info {
     int32_t patch_big_min_items; /* patch layout, two-wave engines (IPP_PATCH_WAVES=2) only: launches of at least this many items take
                                  the instantiation with four rows per request group (k_step_patch<2, 4, 6>); 0: one instantiation for every
                                  launch size (the default: k_step_patch<3, 8, 6>) */
+    int32_t patch_split_min_items; /* patch layout: launches of at least this many items run the SPLIT step -- an item-parallel prologue
+                                 kernel and a unit-parallel streaming kernel (csrc/k_step_split.h) -- instead of the fused kernel; results are
+                                 bit-identical; 0: never */
 } ipp_info;
 
 /* Debug / test view of the last ipp_step's per-item prologue (host struct, filled by ipp_debug_step_item). */

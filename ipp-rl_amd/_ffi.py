@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class IppConfig(C.Structure):
@@ -39,6 +39,7 @@ class IppInfo(C.Structure):
         ("n_tiles", C.c_int32), ("meas_cap", C.c_int32), ("fp_cap", C.c_int32), ("window_rows", C.c_int32),
         ("arena_bytes", C.c_uint64), ("cov_slot_bytes", C.c_uint64), ("step_lds_bytes", C.c_uint64),
         ("fused_step", C.c_int32), ("patch_layout", C.c_int32), ("patch_waves", C.c_int32), ("patch_big_min_items", C.c_int32),
+        ("patch_split_min_items", C.c_int32),
     ]
 
 
@@ -169,7 +170,7 @@ def load():
             raise
         fn.restype = res
         fn.argtypes = args
-    if lib.ipp_abi_version() != ABI_VERSION:
+    if lib.ipp_abi_version() != ABI_VERSION and not os.environ.get("IPP_AB_OLD_LIB"):  # (A/B runs may time the previous ABI's build: new trailing ipp_info fields read 0)
         raise IppError(f"libipp_hip.so ABI {lib.ipp_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     _lib = lib
     return lib

@@ -18,7 +18,7 @@
 #include "k_gain_factor.h"
 #include "k_step_factor.h"
 #include "k_step_patch.h"
-#include "k_step_pipe.h"
+#include "k_step_split.h"
 #include "k_gain_wave.h"
 #include "k_misc.h"
 #include "k_grf_dft.h"
@@ -60,8 +60,9 @@ inline uint64_t up(uint64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 #define IPP_PATCH_BIGKP 4  // rows per request group of the six-waves-per-SIMD instantiation of k_step_patch
 #endif
 
+struct ProfEvent { hipEvent_t a, b; int kind; };
+constexpr int kProfKinds = 4;  // 0 streaming kernel, 1 dense downdate, 2 prologue kernel; 3: every launch of a step (busy time only)
 struct ProfSlot {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0.0;
     int64_t launches = 0;
     double busy_ms = 0.0;       // union of the dispatches' [start, stop] intervals (launches of different streams overlap)
@@ -92,10 +93,13 @@ struct Engine {
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
     bool patch = false;   // k_step_patch on compact column patches (View::patch)
-    int patch_waves = IPP_PATCH_WAVES_DEFAULT;  // waves per item of k_step_patch
+    int patch_waves = kPatchWavesDefault;  // waves per item of k_step_patch
+    int split_min_items = 0;  // launches of at least this many items run the SPLIT step (k_step_split.h: prologue kernel + unit kernel); 0: never
+    int split_waves = 3;      // waves per item of its prologue kernel
+    int pcap_p = 0;           // records the prologue kernel of the split step stages in LDS (a multiple of 8)
+    size_t lds_p = 0, lds_u = 0;
     int pcap_big = 0, big_min_items = 0;  // large launches: k_step_patch<2, 4, 6> with LDS for 12 workgroups per CU (0: never)
     size_t lds_big = 0;
-    bool pipe = false;    // k_step_pipe (persistent producer / consumer workgroups) instead of k_step_factor
     const double* reset_prior = nullptr;  // ipp_set_reset_prior: priors of the episodes started by ipp_step_autoreset
     bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
     bool rect_commit = false;  // ... used for committed steps too (else for predict-only calls only)
@@ -104,13 +108,11 @@ struct Engine {
     int tree_T = kStepThreads;  // workgroup size of k_tree_gain
     size_t tree_step_lds = 0;   // k_tree_step: the fused kernel's LDS + the column-pointer table
     size_t tree_gain_lds = 0;
-    size_t pipe_lds = 0;
-    int pipe_grid = 0;    // resident workgroups of k_step_pipe on this device
-    unsigned launch_seq = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_prep[8] = {};
-    ProfSlot prof[3];
+    ProfSlot prof[kProfKinds];
+    std::vector<ProfEvent> prof_pending;
     int last_n = 0;
     uint64_t last_needed_bytes = 0;  // of the last ipp_streamed_bytes(_detail) read
 };
@@ -120,7 +122,7 @@ struct Layout {
     bool patch;
     int patch_waves;
     PatchGeo pg;
-    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_icnt, off_tick, off_cov, off_hdr, off_linv, off_yv, off_q, off_wc,
+    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_icnt, off_cov, off_blk, off_hdr, off_linv, off_yv, off_q, off_wc,
         off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfhp, off_grfamp, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
 };
 
@@ -147,15 +149,18 @@ bool patch_layout(const ipp_config& c, int MC) {
     if (!(c.x_dim > 2 * c.window_rows + 13)) return false;
     if (c.rank_cap > kPatchMaxRank) return false;
     if (c.window_rows > 25) return false;  // (prior table of (R + 7)^2 floats and patches of (2 R + 6) x (2 R + 7) cells: small windows only)
-    if (!patch_division_exact(patch_geometry(c.x_dim, c.y_dim, c.window_rows))) return false;
-    for (const char* name : {"IPP_RECT_META", "IPP_RECT", "IPP_CLIP_COLS", "IPP_FUSED", "IPP_PIPE", "IPP_VEC", "IPP_STEP_CHUNKS"})
+    {   // the units map a cell index to (row, column) of a rectangle through a reciprocal: exact for every width and index this geometry has
+        const PatchGeo g = patch_geometry(c.x_dim, c.y_dim, c.window_rows);
+        if (!patch_units_exact(g.pw, g.ph)) return false;
+    }
+    for (const char* name : {"IPP_RECT_META", "IPP_RECT", "IPP_CLIP_COLS", "IPP_FUSED", "IPP_VEC", "IPP_STEP_CHUNKS"})
         if (getenv(name)) return false;
     if (const char* p = getenv("IPP_PATCH")) return atoi(p) != 0;
     return true;
 }
 int patch_waves_wanted() {
     if (const char* w = getenv("IPP_PATCH_WAVES")) { const int n = atoi(w); if (n >= 1 && n <= 4) return n; }
-    return IPP_PATCH_WAVES_DEFAULT;
+    return kPatchWavesDefault;
 }
 
 // Windowed factor columns: the largest length scale a reset may install and the prior covariance dropped at the
@@ -264,8 +269,8 @@ int plan(const ipp_config& c, Layout& L, bool allow_patch = true) {
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(2 * cap * (uint64_t)c.rank_cap * 4) : 0;  // tile spans, then rectangles
     L.off_cnt = o; o += up((uint64_t)kCountSlots * 128);
     L.off_icnt = o; o += up((uint64_t)c.max_batch * 16);
-    L.off_tick = o; o += up((uint64_t)kTicketSlots * 4);
     L.off_cov = o; o += up(cap * L.cov_slot_floats * 4);
+    L.off_blk = o; o += L.patch ? up(mb * SplitBlk::floats(L.pg.plw, c.rank_cap) * 4) : 0;  // item blocks of the split step (k_step_split.h)
     L.off_hdr = o; o += up(mb * sizeof(ItemHdr));
     L.off_linv = o; o += up(mb * L.MC * L.MC * 4);
     L.off_yv = o; o += up(mb * L.MC * 4);
@@ -387,32 +392,39 @@ void timed_launch(Engine* e, int kind, void (*kernel)(P...), dim3 grid, dim3 blo
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
     hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, a, b, 0, static_cast<P>(args)...);
-    e->prof[kind].pending.emplace_back(a, b);
+    e->prof_pending.push_back({a, b, kind});
 }
 
-void prof_drain(ProfSlot& p) {
-    std::vector<std::pair<float, float>> iv;  // [start, stop] of every dispatch, ms behind the first start of this batch
-    for (auto& pr : p.pending) (void)hipEventSynchronize(pr.second);
-    for (auto& pr : p.pending) {
+void prof_drain(Engine* e) {
+    // per kind: sum of the dispatches' durations + the union of their [start, stop] intervals (launches of different streams
+    // overlap); slot 3: the union over EVERY launch (a split step is a prologue launch and a unit launch: both are the step)
+    auto& pend = e->prof_pending;
+    if (pend.empty()) return;
+    std::vector<std::pair<float, float>> iv[kProfKinds];  // ms behind the first start of this batch
+    for (auto& pr : pend) (void)hipEventSynchronize(pr.b);
+    for (auto& pr : pend) {
         float ms = 0.f, t0 = 0.f;
-        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-            p.total_ms += ms;
-            p.launches += 1;
-            if (hipEventElapsedTime(&t0, p.pending.front().first, pr.first) == hipSuccess) iv.emplace_back(t0, t0 + ms);
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+            e->prof[pr.kind].total_ms += ms;
+            e->prof[pr.kind].launches += 1;
+            if (hipEventElapsedTime(&t0, pend.front().a, pr.a) == hipSuccess) { iv[pr.kind].emplace_back(t0, t0 + ms); iv[3].emplace_back(t0, t0 + ms); }
         }
     }
-    for (auto& pr : p.pending) {
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+    for (auto& pr : pend) {
+        (void)hipEventDestroy(pr.a);
+        (void)hipEventDestroy(pr.b);
     }
-    p.pending.clear();
-    std::sort(iv.begin(), iv.end());
-    float end = -1e30f;
-    for (auto& x : iv) {
-        if (x.first > end) { p.busy_ms += x.second - x.first; end = x.second; }
-        else if (x.second > end) { p.busy_ms += x.second - end; end = x.second; }
+    pend.clear();
+    for (int k = 0; k < kProfKinds; ++k) {
+        std::sort(iv[k].begin(), iv[k].end());
+        float end = -1e30f;
+        ProfSlot& p = e->prof[k];
+        for (auto& x : iv[k]) {
+            if (x.first > end) { p.busy_ms += x.second - x.first; end = x.second; }
+            else if (x.second > end) { p.busy_ms += x.second - end; end = x.second; }
+        }
+        p.busy_launches += (int64_t)iv[k].size();
     }
-    p.busy_launches += (int64_t)iv.size();
 }
 
 size_t gain_lds_bytes(const View& v, int q_chunk, int lut_cap) {
@@ -428,16 +440,20 @@ template <int MC, int VEC>
 void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_t* dst_ids, int n, const double* action,
                   const double* prev, const float* noise, unsigned flags, float* reward, int32_t* status, hipStream_t s,
                   hipEvent_t prep_done, const AutoReset& ar) {
-    if (e->pipe && !ar.src) {  // persistent producer / consumer workgroups drawing items from a ticket counter
-        const int slot = (int)(e->launch_seq++ & (kTicketSlots - 1));
-        timed_launch(e, 0, k_step_pipe<MC, VEC>, dim3(std::min(n, e->pipe_grid)), dim3(kPipeThreads), e->pipe_lds, s, v, env_ids, n, action,
-                     prev, noise, flags, e->lut_rows, status, reward, slot);
-        if (prep_done) (void)hipEventRecord(prep_done, s);
-        return;
-    }
     if (e->patch) {  // compact column patches: one fused kernel, one small workgroup per item (k_step_patch.h)
         if constexpr (MC == 9 && VEC == 2) {
-            if (e->patch_waves == 1)
+            if (e->split_min_items > 0 && n >= e->split_min_items) {
+                // split step (k_step_split.h): item-parallel prologue kernel, then one wave per (item, unit)
+                View vp = v;
+                vp.pcap = e->pcap_p;
+                if (e->split_waves == 1)
+                    timed_launch(e, 2, k_step_patch<1, kPatchKP, kSplitMinWP, true>, dim3(n), dim3(64), e->lds_p, s, vp, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                else if (e->split_waves == 2)
+                    timed_launch(e, 2, k_step_patch<2, kPatchKP, kSplitMinWP, true>, dim3(n), dim3(128), e->lds_p, s, vp, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                else
+                    timed_launch(e, 2, k_step_patch<3, kPatchKP, kSplitMinWP, true>, dim3(n), dim3(192), e->lds_p, s, vp, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                timed_launch(e, 0, k_step_units<>, dim3(split_grid(n, v.punits)), dim3(64), e->lds_u, s, v, n, flags, reward, ar);
+            } else if (e->patch_waves == 1)
                 timed_launch(e, 0, k_step_patch<1>, dim3(n), dim3(64), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else if (e->patch_waves == 4)
                 timed_launch(e, 0, k_step_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
@@ -751,7 +767,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.dbg_capture = 0;
     v.counters = reinterpret_cast<unsigned long long*>(base + L.off_cnt);
     v.item_counts = reinterpret_cast<unsigned long long*>(base + L.off_icnt);
-    v.tickets = reinterpret_cast<int*>(base + L.off_tick);
     v.window_rows = (cfg->state_repr == IPP_FACTOR) ? std::max(0, cfg->window_rows) : 0;
     v.tile_cells = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0) ? 64 * L.VEC : L.T * L.VEC;
     v.tile_shift = -1;
@@ -780,13 +795,14 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     // else the env columns are written on band tiles and carry full rectangles), tree steps always.
     if (v.rect_meta) { e->rect_commit = e->rect_ok; e->rect_tree = true; }
     v.patch = L.patch ? 1 : 0;
-    v.pw = v.ph = v.pstride = v.pdiv = v.plw = v.pcap = v.punits = 0;
+    v.pw = v.ph = v.pstride = v.plw = v.pcap = v.punits = 0;
+    v.blk = nullptr; v.blk_stride = 0; v.blk_pos0 = 0;
     e->patch = L.patch;
     e->patch_waves = L.patch_waves;
     if (L.patch) {
         v.clip_cols = 1;
         v.rect_meta = 1;
-        v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.pdiv = L.pg.pdiv; v.plw = L.pg.plw; v.punits = L.pg.punits;
+        v.pw = L.pg.pw; v.ph = L.pg.ph; v.pstride = L.pg.pstride; v.plw = L.pg.plw; v.punits = L.pg.punits;
         // column records in LDS: what fits the share of a workgroup when kPatchWavesPerCu waves of the kernel are resident per CU
         // (the LDS of a workgroup is allocated in granules of 1280 bytes on gfx950: 16 KB would take 13 of the 128)
         int wgs = kPatchWavesPerCu / L.patch_waves;
@@ -797,7 +813,23 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, L.patch_waves, v.punits, cfg->rank_cap);
         int pcap = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;
         if (const char* pc = getenv("IPP_PATCH_CAP")) pcap = std::max(8, atoi(pc));  // A/B experiments, overflow tests
-        v.pcap = std::min(pcap, cfg->rank_cap);
+        // (a staging capacity below the rank is a multiple of 8: the m x m algebra sums the records in groups of eight, so S does not
+        // depend on where a record is staged -- solve_wave_fast)
+        v.pcap = pcap >= cfg->rank_cap ? cfg->rank_cap : (pcap & ~7);
+        v.blk = reinterpret_cast<float*>(base + L.off_blk);
+        v.blk_stride = (int)SplitBlk::floats(v.plw, cfg->rank_cap);
+        {   // split step: LDS of the prologue kernel for kSplitMinWP workgroups per SIMD, of the unit kernel as it comes
+            if (const char* pwv = getenv("IPP_SPLIT_WAVES")) { const int w = atoi(pwv); if (w >= 1 && w <= 3) e->split_waves = w; }  // A/B
+            const size_t budget = (size_t)160 * 1024 / (4 * kSplitMinWP / e->split_waves) / 1280 * 1280;
+            const size_t fixed = PatchLds::bytes(0, 0, 1, v.punits, cfg->rank_cap);
+            int pc = fixed + 8 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) & ~7 : 8;
+            e->pcap_p = pc >= cfg->rank_cap ? cfg->rank_cap : pc;
+            e->lds_p = PatchLds::bytes(e->pcap_p, 0, 1, v.punits, cfg->rank_cap);
+            e->lds_u = SplitLds::bytes(v.plw, cfg->rank_cap);
+            // IPP_SPLIT=<n>: launches of at least n items take the split step (1: all of them, 0: never)
+            e->split_min_items = 0;
+            if (const char* sp = getenv("IPP_SPLIT")) e->split_min_items = std::max(0, atoi(sp));
+        }
     }
     v.win_tiles = L.win_tiles;
     v.cov = reinterpret_cast<float*>(base + L.off_cov);
@@ -872,15 +904,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                 e->big_min_items = min_items;
             }
         }
-        if (e->fused && !e->patch) {
-            e->pipe_lds = (v.meas_cap == 9) ? PipeLds<9>::bytes(v.rank_cap, lutf, v.win_tiles) : PipeLds<25>::bytes(v.rank_cap, lutf, v.win_tiles);
-            e->pipe = e->pipe_lds <= 160 * 1024;
-            // off by default: one producer wave needs ~50 us per item against ~37 us of its three consumers, so the
-            // pipeline is producer-bound (0.357 vs 0.313 ms at 4096 items of 50x50); IPP_PIPE=1 opts in
-            const char* pp = getenv("IPP_PIPE");
-            e->pipe = e->pipe && pp && atoi(pp) != 0;
-            if (e->pipe) v.rect_meta = 0;  // (the pipelined kernel's consumers do not stage the rectangles)
-        }
         if (v.T == kWave && !e->patch)
             e->gain_lds = (LQ + kTileLut) * 4 + (size_t)v.rank_cap * 4 + (8 * MCs) * 4 +
                           (size_t)(v.rank_cap + 8) * 2;
@@ -908,6 +931,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2, IPP_PATCH_BIGKP, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<1, kPatchKP, kSplitMinWP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2, kPatchKP, kSplitMinWP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3, kPatchKP, kSplitMinWP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<3>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
@@ -923,18 +949,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
-    if (e->pipe) {
-        const void* kfn = (v.meas_cap == 9) ? (v.vec == 2 ? reinterpret_cast<const void*>(&k_step_pipe<9, 2>) : reinterpret_cast<const void*>(&k_step_pipe<9, 4>))
-                                            : reinterpret_cast<const void*>(&k_step_pipe<25, 2>);
-        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->pipe_lds);
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPipeThreads, e->pipe_lds) != hipSuccess || per_cu <= 0) per_cu = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
-        if (const char* g = getenv("IPP_PIPE_WGS")) per_cu = atoi(g);  // experiments: workgroups per CU
-        e->pipe_grid = per_cu * cus;
-        if (e->pipe_grid <= 0) e->pipe = false;
-        (void)hipGetLastError();
-    }
     e->tree_step_lds = (e->gain_lds + (size_t)v.rank_cap * 8 + 15) & ~(size_t)15;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
@@ -1030,7 +1044,7 @@ int ipp_engine_destroy(void* engine) {
 #endif
     Engine* e = as_engine(engine);
     if (!e) return 0;
-    for (auto& p : e->prof) prof_drain(p);
+    prof_drain(e);
     if (e->side) {
         (void)hipStreamSynchronize(e->side);
         (void)hipStreamDestroy(e->side);
@@ -1060,6 +1074,7 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     out->patch_layout = e->patch ? 1 : 0;
     out->patch_waves = e->patch ? e->patch_waves : 0;
     out->patch_big_min_items = e->patch ? e->big_min_items : 0;
+    out->patch_split_min_items = e->patch ? e->split_min_items : 0;
     return 0;
 }
 
@@ -1158,7 +1173,7 @@ int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_a
     Engine* e = as_engine(engine);
     if (!e) return fail(-1, "null engine");
     if (!action || !prev_action || !reward || !part_begin || !streams) return fail(-1, "null argument");
-    if (e->v.mode != IPP_FACTOR || !(e->fused || e->patch) || e->pipe || e->v.meas_cap != 9 || e->v.vec != 2)
+    if (e->v.mode != IPP_FACTOR || !(e->fused || e->patch) || e->v.meas_cap != 9 || e->v.vec != 2)
         return fail(-1, "ipp_step_parts: engines whose step is one fused kernel only (ipp_info.fused_step)");
     // (predict-only parts: reward / status of every item, no state write -- consecutive calls do not depend on each other at all)
     if ((flags & IPP_PREDICT_ONLY) && (reset_src || (flags & IPP_UPDATE_PREV))) return fail(-1, "ipp_step_parts: IPP_PREDICT_ONLY with resets or IPP_UPDATE_PREV");
@@ -1176,6 +1191,7 @@ int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_a
     e->last_n = n;
     for (int p = 0; p < n_parts; ++p) {
         View v = e->v;  // (the per-item arrays keep their batch indexing: a part is a range of positions of the order)
+        v.blk_pos0 = part_begin[p];  // (the split step's item blocks are indexed by the dispatch position)
         v.item_order = e->v.item_order + part_begin[p];
         v.item_order_n = part_begin[p + 1] - part_begin[p];
         launch_chunk<9, 2>(e, v, nullptr, nullptr, v.item_order_n, action, prev_action, meas_noise, flags, reward, status,
@@ -1785,7 +1801,7 @@ int ipp_profile_read(void* engine, int32_t kind, double* avg_ms, int64_t* launch
     if (!e || kind < 0 || kind > 2) return fail(-1, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     ProfSlot& p = e->prof[kind];
-    prof_drain(p);
+    prof_drain(e);
     if (avg_ms) *avg_ms = p.launches ? p.total_ms / (double)p.launches : 0.0;
     if (launches) *launches = p.launches;
     if (reset) { p.total_ms = 0.0; p.launches = 0; }
@@ -1794,10 +1810,10 @@ int ipp_profile_read(void* engine, int32_t kind, double* avg_ms, int64_t* launch
 
 int ipp_profile_read_busy(void* engine, int32_t kind, double* busy_ms, int64_t* launches, int32_t reset) {
     Engine* e = as_engine(engine);
-    if (!e || kind < 0 || kind > 2) return fail(-1, "bad argument");
+    if (!e || kind < 0 || kind > 3) return fail(-1, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     ProfSlot& p = e->prof[kind];
-    prof_drain(p);
+    prof_drain(e);
     if (busy_ms) *busy_ms = p.busy_ms;
     if (launches) *launches = p.busy_launches;
     if (reset) { p.busy_ms = 0.0; p.busy_launches = 0; }

@@ -116,11 +116,7 @@ __device__ __forceinline__ ItemHdr make_item_header(const View& v, int env0, int
     h.ny = ((h.h - 1) >> rsh) + 1;
     h.m = h.nx * h.ny;                                                            // mappings.py:125-126
     h.f = h.w * h.h;
-#ifdef IPP_HDR_ABLATE
-    h.nv_d = v.coeff_a * 0.8; with_cost = false;  // (timing experiment: no exp, no flight time)
-#else
     h.nv_d = v.coeff_a * (1.0 - exp(-v.coeff_b * az));                            // sensor_models.py:30
-#endif
     h.nv = (float)h.nv_d;
     double cost = 0.0;
     if (with_cost) {
@@ -413,10 +409,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     // ~30 fp64 calls with divisions per lane, 10 us of the prologue for 40 % of the items
     double* wyt = L;           // [orows][h.h]
     double* wxt = L + 2 * MC;  // [ocols][h.w]
-#ifndef IPP_PREP_ABLATE
-#define IPP_PREP_ABLATE 0  // timing experiments only: 1 = no INTER_AREA arithmetic (rf = 2 observations are wrong)
-#endif
-    if (!cov_only && h.rf > 1 && !(IPP_PREP_ABLATE & 1)) {
+    if (!cov_only && h.rf > 1) {
         const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
         for (int idx = tid; idx < orows * h.h; idx += kPrepThreads) wyt[idx] = area_weight(h.h, orows, idx / h.h, idx % h.h);
         for (int idx = tid; idx < ocols * h.w; idx += kPrepThreads) wxt[idx] = area_weight(h.w, ocols, idx / h.w, idx % h.w);
@@ -425,7 +418,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     if (!cov_only) {
         if (tid < m) {
             double val;
-            if (h.rf == 1 || (IPP_PREP_ABLATE & 1)) {
+            if (h.rf == 1) {
                 val = sub[tid];
             } else {
                 // cv2.resize(sub, dsize=(ceil(h/rf), ceil(w/rf))) -> width=ceil(h/rf), height=ceil(w/rf)
@@ -884,11 +877,7 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
     if (lane < f) sub[lane] = (double)gt_f;
     double* wyt = L;           // [orows][h.h]   (the L / Li scratch is not used by solve_wave_fast)
     double* wxt = L + 2 * MC;  // [ocols][h.w]
-#ifdef IPP_OBS_ABLATE
-    if (false) {
-#else
     if (h.rf > 1) {
-#endif
         const int ocols = (h.h + h.rf - 1) / h.rf, orows = (h.w + h.rf - 1) / h.rf;
         for (int idx = lane; idx < orows * h.h; idx += kWave) wyt[idx] = area_weight(h.h, orows, idx / h.h, idx % h.h);
         for (int idx = lane; idx < ocols * h.w; idx += kWave) wxt[idx] = area_weight(h.w, ocols, idx / h.w, idx % h.w);
@@ -897,11 +886,7 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
     if (lane < m) {
         const Block myb = block_of(lane, h.nx, h.rf, h.w, h.h);
         double val;
-#ifdef IPP_OBS_ABLATE
-        if (true) {
-#else
         if (h.rf == 1) {
-#endif
             val = sub[lane];
         } else {
             const int ocols = (h.h + h.rf - 1) / h.rf;
@@ -935,9 +920,6 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
 }
 
 
-#ifndef IPP_SOLVE_MFMA
-#define IPP_SOLVE_MFMA 0  // 1: H U^T (H U^T)^T of the m x m system on the matrix unit (186 GPU tests green, +0-1 %: profiles/r04_experiments.txt 24); 0: the pair loop of rounds 2-3
-#endif
 template <int MC>
 __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, const int item, unsigned flags,
                                                unsigned char* small, const float* ht, int si, int sk, float* linv_f,
@@ -978,73 +960,31 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         }
         if (pi == pj) mine += R;
     }
-#if IPP_SOLVE_MFMA
-    // ---- factor part: - sum_k HT[i][k] HT[j][k] = -(HT HT^T)[i][j] on the matrix unit: v_mfma_f64_16x16x4_f64 with A = B =
-    // HT[i = lane & 15][k0 + (lane >> 4)] (one LDS read and one conversion per lane and four columns k; fp64 products of fp32 values
-    // are exact), D[row = (lane >> 4) + 4 reg][col = lane & 15].  The pair loop below was 5 vector instructions per column k on all
-    // 45 pair lanes (fp64: ~1.3 M of a launch's 31 M, more of its vector time); this is 1.5 per k.
-    typedef double v4d __attribute__((ext_vector_type(4)));
-    v4d sacc0 = {0.0, 0.0, 0.0, 0.0}, sacc1 = {0.0, 0.0, 0.0, 0.0};
-    {
-        const int ai = lane & 15, ak = lane >> 4;
-        const bool ion = ai < m;
-        const float* hp = ht + ai * si + ak * sk;
-        int k0 = 0;
-        for (; k0 + 8 <= r; k0 += 8) {  // (two independent accumulation chains)
-            const float x0 = ion ? hp[k0 * sk] : 0.f, x1 = ion ? hp[(k0 + 4) * sk] : 0.f;
-            sacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0, (double)x0, sacc0, 0, 0, 0);
-            sacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x1, (double)x1, sacc1, 0, 0, 0);
-        }
-        for (; k0 < r; k0 += 4) {
-            const float x0 = (ion && k0 + ak < r) ? hp[k0 * sk] : 0.f;
-            sacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0, (double)x0, sacc0, 0, 0, 0);
-        }
-        if (ht2) {
-            const float* hp2 = ht2 + ai * si + ak * sk;
-            for (int k2 = 0; k2 < r_ht2; k2 += 4) {
-                const float x0 = (ion && k2 + ak < r_ht2) ? hp2[k2 * sk] : 0.f;
-                sacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0, (double)x0, sacc1, 0, 0, 0);
-            }
-        }
-    }
-    if (pair_on) {
-        S[pi * LD + pj] = mine;
-        S[pj * LD + pi] = mine;
-    }
-    wave_lds_sync();
-    {
-        const int col = lane & 15, row0 = lane >> 4;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {  // rows row0 + 4 q <= 11; every (row, col) of S sits in exactly one lane and register
-            const int row = row0 + 4 * q;
-            if (row < m && col < m) S[row * LD + col] -= sacc0[q] + sacc1[q];
-        }
-    }
-    wave_lds_sync();
-#else
     // ---- factor part: - sum_k HT[i][k] HT[j][k] by the pair's own lane, all pairs in lock step (two LDS reads per k,
     // eight k in flight; no cross-lane reduction: 45 wave-wide fp64 butterflies through ds_bpermute took 25 us);
     // fp64 products of fp32 values are exact
+    // (order of the sum: groups of eight columns on four accumulators, then the remainder on the first -- the same for a column
+    // wherever it is staged, so S does not depend on how many records fit the LDS of the kernel that runs the solve: the staging
+    // capacities are multiples of eight, ht2 continues the groups of ht)
     if (pair_on) {
         const float* hi = ht + pi * si;
         const float* hj = ht + pj * si;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int k = 0;
-        for (; k + 8 <= r; k += 8) {
-            float x[8], y[8];
+        auto groups = [&](const float* xi, const float* xj, int n) {
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                float x[8], y[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { x[u] = hi[(k + u) * sk]; y[u] = hj[(k + u) * sk]; }
-            a0 = fma((double)x[0], (double)y[0], a0); a1 = fma((double)x[1], (double)y[1], a1);
-            a2 = fma((double)x[2], (double)y[2], a2); a3 = fma((double)x[3], (double)y[3], a3);
-            a0 = fma((double)x[4], (double)y[4], a0); a1 = fma((double)x[5], (double)y[5], a1);
-            a2 = fma((double)x[6], (double)y[6], a2); a3 = fma((double)x[7], (double)y[7], a3);
-        }
-        for (; k < r; ++k) a0 = fma((double)hi[k * sk], (double)hj[k * sk], a0);
-        if (ht2) {
-            const float* hi2 = ht2 + pi * si;
-            const float* hj2 = ht2 + pj * si;
-            for (int k2 = 0; k2 < r_ht2; ++k2) a1 = fma((double)hi2[k2 * sk], (double)hj2[k2 * sk], a1);
-        }
+                for (int u = 0; u < 8; ++u) { x[u] = xi[(k + u) * sk]; y[u] = xj[(k + u) * sk]; }
+                a0 = fma((double)x[0], (double)y[0], a0); a1 = fma((double)x[1], (double)y[1], a1);
+                a2 = fma((double)x[2], (double)y[2], a2); a3 = fma((double)x[3], (double)y[3], a3);
+                a0 = fma((double)x[4], (double)y[4], a0); a1 = fma((double)x[5], (double)y[5], a1);
+                a2 = fma((double)x[6], (double)y[6], a2); a3 = fma((double)x[7], (double)y[7], a3);
+            }
+            for (; k < n; ++k) a0 = fma((double)xi[k * sk], (double)xj[k * sk], a0);
+        };
+        groups(hi, hj, r);
+        if (ht2) groups(ht2 + pi * si, ht2 + pj * si, r_ht2);  // (r is then a multiple of eight: no remainder in front of these)
         mine -= (a0 + a1) + (a2 + a3);
     }
     if (pair_on) {
@@ -1052,7 +992,6 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
         S[pj * LD + pi] = mine;
     }
     wave_lds_sync();
-#endif
 
     // ---- Cholesky S = C C^T in registers: lane i holds row i (c[k] = C[i][k]); the reference uses L = C^T.  mappings.py:185
     double c[MC];
@@ -1068,12 +1007,7 @@ __device__ __forceinline__ int solve_wave_fast(const View& v, const ItemHdr& h, 
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
         rd[j] = 1.0;
-#ifdef IPP_SOLVE_ABLATE
-        if (j < m) { const double d = bcast_lane(c[j], j); rd[j] = __builtin_amdgcn_rsq(d); c[j] = (lane == j) ? d * rd[j] : 0.0; }  // (timing experiment: diagonal S)
-        if (false) {
-#else
         if (j < m) {  // wave-uniform
-#endif
             double t = c[j];
 #pragma unroll
             for (int k = 0; k < j; ++k) t = fma(-c[k], bcast_lane(c[k], j), t);  // - C[i][k] C[j][k]

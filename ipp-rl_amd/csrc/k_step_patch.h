@@ -1,4 +1,4 @@
-// Fused factor-state env step on COMPACT COLUMN PATCHES: ONE kernel, one small workgroup (NW waves, default 2) per item.
+// Factor-state env step on COMPACT COLUMN PATCHES.
 //
 // Storage (View::patch).  A column of U appended by a step is non-zero only on the rectangle of grid rows / columns within
 // window_rows of that step's footprint (two-dimensional windows).  Here the column IS that rectangle:
@@ -6,26 +6,28 @@
 //     U_k[row][col] = patch_k[(row - r0_k) * pw + (col - c0_k)],      (r0_k, r1_k, c0_k, c1_k) = View::colrect[env][k],
 // patch_k = cov + env * cov_slot + k * pstride.  Because every patch has the same row stride, the cells of the NEW step's
 // rectangle, enumerated in its own patch order (flat = prow * pw + pcol), sit at flat + shift_k in stored column k with the
-// wave-uniform shift_k = (r0_new - r0_k) * pw + (c0_new - c0_k): a wave's request for a stored row is 512 CONSECUTIVE bytes
-// of that column (lanes outside the column's rectangle masked), whatever the grid width -- on row-major band tiles the same
-// request crossed ~5 grid rows at a stride of W floats (12 sectors for 512 B used at 50x50, more on wider grids) and a
-// column slot was Npad floats (10 KB at 50x50, 160 KB at 200x200) instead of 2.6 KB.  The appended columns are written
-// the same way: m fully coalesced row writes per unit.
+// wave-uniform shift_k = (r0_new - r0_k) * pw + (c0_new - c0_k): a wave's request for a stored row is a run of consecutive bytes
+// of that column (lanes outside the column's rectangle masked), whatever the grid width, and a column slot is 2.6 KB instead
+// of Npad floats.  The appended columns are written the same way: m coalesced row writes per unit.
 //
-// Workgroup = NW waves (2), 5 waves per SIMD -> 10 items resident per CU at 95 VGPRs and 15 KB of LDS.  What bounds the kernel
-// is the chain of short dependent phases of an item (launch time ~ the longest item alone + 10-12 ns per further item) -- not
-// HBM and not the FMA rate: pipelined requests, more waves per item, priorities and even dropping the stream's FMAs change
-// little; removing phases and iterations did (profiles/r03_experiments.txt 13-20).  LDS diet against k_step_factor (36 -> 15 KB):
-//   * HT = H_F U[F,:]^T is gathered and staged only for the columns whose rectangle reaches the footprint (the others have
-//     an exactly zero row): per such column one 64-byte RECORD  [-HT(0..11) | byte offset of its shifted patch | rectangle as
-//     two packed 16-bit pairs | k]  -- the stream reads the record (LDS broadcast) instead of a scalar load from a global
-//     scratch block (no store -> s_load round trip, no scalar-cache invalidate);
-//   * the prior table is P0(|drow| < plw, |dcol| < plw), not lut_rows x W;
-//   * records beyond View::pcap (clustered revisits) live in the item's global scratch block and are read through flat
-//     loads by the request groups that touch them (a second instantiation of the group body only).
-// Arithmetic per cell (prior term, order of the stored rows, L^-1 in the epilogue, reward sums in unit order) is the one
-// of gain_tiles<PRE, RECT> (k_gain_factor.h); the m x m algebra and the observation are the shared device functions of
-// k_prepare.h (solve_wave_fast, observe_wave).  mapping/mappings.py:178-197, planning/common/rewards.py:8-31.
+// k_step_patch<NW, KP, MINW, SPLIT = false>: the FUSED step, one workgroup of NW waves per item (default 3 waves at MINW = 6 waves per
+// SIMD: 80 VGPRs, 8 workgroups = 2048 item slots per CU x 256).  Per item:
+//   prologue   inputs + the rectangles of all stored columns in one batch of loads; wave 0 evaluates the fp64 header and hands it over
+//              through LDS; the CONTRIBUTING columns (rectangle meets the footprint: the others have an exactly zero row of H U^T)
+//              are compacted in increasing k and change hands (thread t takes the t-th), so the gather of HT = H_F U[F,:]^T runs over
+//              n_c columns; per contributing column one 64-byte RECORD [-HT(0..11) | byte offset of its shifted patch | rectangle as
+//              two packed 16-bit pairs | k] in LDS (beyond View::pcap: in the item's global scratch block); the prior table
+//              P0(|drow| < plw, |dcol| < plw) is built under the gather's round trip
+//   algebra    wave 0: S, Cholesky, L^-1, y in registers (solve_wave_fast, fp64); wave 1: the observation (observe_wave); the other
+//              wave(s) stream from the start
+//   units      k_patch_units.h (shared with k_tree_patch and the split step), drawn from an LDS ticket
+//   results    last wave: reward = sum of the units' reductions IN UNIT ORDER / (cost + 1), rank, rectangles, the scheduled reset
+// k_step_patch<NW, KP, MINW, SPLIT = true>: the PROLOGUE KERNEL of the split step (k_step_split.h): the same code up to the m x m
+// algebra; instead of running the units it leaves header, tables, L^-1 | y and the records in the item's block of
+// View::blk for the unit-parallel kernel k_step_units.
+// Arithmetic per cell (prior term, order of the stored rows, L^-1 in the epilogue, reward sums in unit order) is the one of
+// gain_tiles<PRE, RECT> (k_gain_factor.h); the m x m algebra and the observation are the shared device functions of k_prepare.h.
+// mapping/mappings.py:178-197, planning/common/rewards.py:8-31.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -38,68 +40,31 @@
 namespace ipp {
 
 constexpr int kPatchRec = 16;  // floats per column record
-#ifndef IPP_PATCH_KP
-#define IPP_PATCH_KP 8  // (8 rows in flight per wave fit 96 VGPRs: 5 waves per SIMD; 12 rows at 4 waves per SIMD measured 3 % slower)
-#endif
-// Instruction-count build (tools/valu_sections.py): the launch returns at exit point v.dbg_capture - 1 (ipp_debug_capture); the
-// hardware's SQ_INSTS_VALU of that dispatch is the count up to the point.  Results are wrong from there on.
-#ifndef IPP_EXIT_POINTS
-#define IPP_EXIT_POINTS 0
-#endif
-#if IPP_EXIT_POINTS
-#define IPP_EXIT_POINT(k) do { if (v.dbg_capture == (k) + 1) return; } while (0)
-#else
-#define IPP_EXIT_POINT(k) do { } while (0)
-#endif
-#ifndef IPP_PATCH_ABLATE
-#define IPP_PATCH_ABLATE 0  // timing experiments only (results are wrong): 1 no row requests, 2 no stores, 4 no prior term, 8 no L^-1 in the epilogue, 16 no FMAs of the stream, 32 no gather requests, 64 no compaction per unit (all records), 128 no mean / diag loads, 256 no rectangle test per row
-#endif
-#ifndef IPP_MD_STREAM
-#define IPP_MD_STREAM 0  // non-temporal hint on the units' mean / variance: 1 loads, 2 stores (A/B: see profiles/r04_experiments.txt 18)
-#endif
-#ifndef IPP_STORE_AUX
-#define IPP_STORE_AUX (IPP_NT_STORES ? 2 : 0)  // cache policy bits of the new rows' stores (1 sc0, 2 nt, 16 sc1)
-#endif
-#ifndef IPP_PATCH_AUX
-#define IPP_PATCH_AUX 2  // cache policy bits of the row requests (2: nt)
-#endif
-#ifndef IPP_PATCH_MINW
-#define IPP_PATCH_MINW 6  // waves per SIMD the register allocation aims at (round 4: the unit loop fits 80 VGPRs with 8 rows in flight)
-#endif
-#ifndef IPP_PATCH_WAVES_DEFAULT
-#define IPP_PATCH_WAVES_DEFAULT 3  // waves per item.  THREE at six waves per SIMD = 8 workgroups per CU = 2048 item slots: one wave for the m x m
-                                   // algebra, one for the observation, one that streams from the start; the chains of the heaviest items (which
-                                   // end a 4096-item launch) are a third shorter than with two waves at ten workgroups per CU: 0.0915 vs 0.0968 ms
-                                   // (round 3, five waves per SIMD: three waves lost, 0.1245 vs 0.1160; profiles/r04_experiments.txt 7)
-#endif
-constexpr int kPatchWavesPerCu = 4 * IPP_PATCH_MINW;
-constexpr int kPatchKP = IPP_PATCH_KP;   // stored rows requested per group
+constexpr int kPatchKP = 8;    // stored rows requested per group (8 rows in flight per wave and the unit body fit 80 VGPRs: 6 waves per SIMD)
+constexpr int kPatchRowAux = 2;                      // cache policy bits of the row requests (2: nt)
+constexpr int kPatchStoreAux = IPP_NT_STORES ? 2 : 0;  // ... of the new rows' stores (1 sc0, 2 nt, 16 sc1)
+constexpr int kPatchMinW = 6;  // waves per SIMD the register allocation of the streaming kernels aims at
+constexpr int kPatchWavesDefault = 3;  // waves per item of the fused kernel.  THREE at six waves per SIMD = 8 workgroups per CU = 2048 item slots: one wave
+                                       // for the m x m algebra, one for the observation, one that streams from the start (profiles/r04_experiments.txt 7)
+constexpr int kPatchWavesPerCu = 4 * kPatchMinW;
 constexpr int kPatchCtl = 32;  // control words
-constexpr int kPatchDivShift = 18;  // flat / pw == (flat * pdiv) >> 18, pdiv = ceil(2^18 / pw) (verified per engine: patch_division_exact)
 constexpr int kPatchMaxRank = 512;  // largest rank_cap of a patch engine (every thread tests kPatchMaxRank / threads rectangles)
 
 // Geometry of the patches for a config (host + device).
 struct PatchGeo {
-    int pw, ph, pstride, pdiv, plw, punits;
+    int pw, ph, pstride, plw, punits;
 };
 inline PatchGeo patch_geometry(int W, int H, int R) {
     PatchGeo g;
     // widest rectangle: 2 R + 5 columns (the widest unclipped footprint of m <= 9 blocks is 5 cells) with both ends moved out
     // to even columns; tallest: 2 R + 6 rows (a 6-row footprint only exists clipped at the border: fewer rows then)
+    // (row strides of 28 / 32 floats -- 128-byte rows -- measured slower than the dense 26: profiles/r04_experiments.txt 9)
     g.pw = std::min((W + 1) & ~1, ((2 * R + 5 + 2) / 2) * 2);
-    if (const char* pe = getenv("IPP_PATCH_PW")) { const int want = atoi(pe); if (want >= g.pw && want <= 64 && want % 2 == 0) g.pw = want; }  // A/B: row stride of a patch
     g.ph = std::min(H, 2 * R + 6);
     g.pstride = (g.pw * g.ph + 15) & ~15;
-    g.pdiv = ((1 << kPatchDivShift) + g.pw - 1) / g.pw;
     g.plw = std::min(std::max(W, H), R + 7);
     g.punits = (g.ph * g.pw + 2 * kWave - 1) / (2 * kWave);
     return g;
-}
-
-inline bool patch_division_exact(const PatchGeo& g) {
-    for (int flat = 0; flat < g.ph * g.pw + 2 * kWave; ++flat)
-        if ((int)(((unsigned)flat * (unsigned)g.pdiv) >> kPatchDivShift) != flat / g.pw) return false;
-    return true;
 }
 
 struct PatchLds {
@@ -129,12 +94,29 @@ struct PatchLds {
     }
 };
 
+// The item's BLOCK of the split step (View::blk, one per dispatch position of a launch; k_step_split.h): written by the prologue
+// kernel (k_step_patch<1, ., ., true>), read by the unit-parallel kernel.  Offsets in floats from the block's start; every part
+// starts on a 128-byte line.
+struct SplitBlk {
+    static constexpr int kHdr = 0;      // 32 ints: the words below
+    static constexpr int kSync = 32;    // 64 words = 32 x 8 bytes: [0] arrival counter of the units, [1 + u] reduction of unit u (fp64; <= 31 units)
+    static constexpr int kTab = 96;     // fb_yx [36] | fb_w [36] | L^-1 [81] y [9] pad [6] | prior table [lutf4]: copied to LDS by every unit
+    static constexpr int kTabFixed = 72 + PatchLds::LQ;
+    // header words
+    enum { ITEM = 0, ENV, M, NC, NUNITS, RANK, BITS, RECT, TSPAN, RESET, COST_LO, COST_HI, HDR_WORDS };
+    enum { B_RF1 = 1, B_COMMIT = 2, B_DEAD = 4 };
+    __host__ __device__ static int lutf4(int plw) { return (plw * plw + 3) & ~3; }
+    __host__ __device__ static int rec_off(int plw) { return (kTab + kTabFixed + lutf4(plw) + 31) & ~31; }
+    __host__ __device__ static size_t floats(int plw, int rank_cap) { return ((size_t)rec_off(plw) + (size_t)rank_cap * kPatchRec + 31) & ~(size_t)31; }
+};
+
 }  // namespace ipp
 #include "k_patch_units.h"
 namespace ipp {
 
-// Io policy of the env step for patch_units: pre-step mean / variance from the env's planes, stored rows through the item's
-// single buffer resource (patch offset = scalar offset), results into the env's planes and the next m patches of its slot.
+// Io policy of the env step: pre-step mean / variance from the env's planes, stored rows through the item's single buffer resource
+// (patch offset = scalar offset), -HT of a record from the workgroup's LDS staging, results into the env's planes and the next m
+// patches of its slot.
 struct StepIo {
     static constexpr bool kMean = true;
     typedef float rowv __attribute__((ext_vector_type(2)));
@@ -142,33 +124,40 @@ struct StepIo {
     float* mean_rw;
     float* diag_rw;
     bool cov_only;
+    bool wt_planes;  // mean / variance stores write-through (split step, envs reset by the launch)
     int m, row0_bytes, pstride_bytes;
     __device__ __forceinline__ rowv row_load(unsigned cofs, unsigned voff) const {
         // one resource for the whole item, the patch offset as the request's scalar offset (a resource per row was four
         // scalar instructions per row)
-        return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(row_rs, voff, (int)cofs, IPP_PATCH_AUX));  // (aux 2: nt)
+        return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(row_rs, voff, (int)cofs, kPatchRowAux));
     }
+    __device__ __forceinline__ float coef(const UnitLds& ul, int a, int l15) const { return ul.rec[(size_t)a * kPatchRec + l15]; }
     __device__ __forceinline__ void load_pre(int cell0, int flat, int rrow, int rcol, float (&md)[2][2]) const {
-        if (IPP_PATCH_ABLATE & 128) { md[0][0] = md[0][1] = 0.5f; md[1][0] = md[1][1] = 1.f; }
-        else if (IPP_MD_STREAM & 1) { load_stream<2>(mean_rw + cell0, md[0]); load_stream<2>(diag_rw + cell0, md[1]); }
-        else { load_vec<2>(mean_rw + cell0, md[0]); load_vec<2>(diag_rw + cell0, md[1]); }
+        load_vec<2>(mean_rw + cell0, md[0]);
+        load_vec<2>(diag_rw + cell0, md[1]);
     }
     __device__ __forceinline__ void store(bool commit, bool lane_valid, int cell0, int flat, unsigned flat4, const float (&acc)[2][9],
                                           const float (&md)[2][2], const float (&dred)[2], const float (&dmean)[2]) const {
-        if (!commit || ((IPP_PATCH_ABLATE & 2) && acc[0][0] != 12345.f)) return;
+        if (!commit) return;
         if (lane_valid) {
-            float outv[2];
+            float od[2], om[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) outv[c] = md[1][c] - dred[c];
-            if (IPP_MD_STREAM & 2) store_stream<2>(diag_rw + cell0, outv); else store_vec<2>(diag_rw + cell0, outv);
-            if (!cov_only) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) outv[c] = md[0][c] + dmean[c];
-                if (IPP_MD_STREAM & 2) store_stream<2>(mean_rw + cell0, outv); else store_vec<2>(mean_rw + cell0, outv);
+            for (int c = 0; c < 2; ++c) { od[c] = md[1][c] - dred[c]; om[c] = md[0][c] + dmean[c]; }
+            if (!wt_planes) {
+                store_vec<2>(diag_rw + cell0, od);
+                if (!cov_only) store_vec<2>(mean_rw + cell0, om);
+            } else {
+                // split step, an env that this launch resets: 8-byte agent-scope stores = write-through (sc1), in memory before this
+                // wave's arrival whatever XCD it runs on (k_step_split.h)
+                typedef unsigned long long u64;
+                __hip_atomic_store(reinterpret_cast<u64*>(diag_rw + cell0), ((u64)__float_as_uint(od[1]) << 32) | __float_as_uint(od[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!cov_only)
+                    __hip_atomic_store(reinterpret_cast<u64*>(mean_rw + cell0), ((u64)__float_as_uint(om[1]) << 32) | __float_as_uint(om[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // the m new rows (buffer stores through the item's resource: the row as scalar offset, lanes outside the rectangle out of
-        // range -- no 64-bit address per lane and row)
+        // range -- no 64-bit address per lane and row).  (The loop stays in this function: handed on to a helper by reference, `acc`
+        // is not promoted to registers -- 86 scratch instructions in the unit body, 20 % of the step)
         typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(row_rs, 0, 0, 0)) raw2;
 #pragma unroll
         for (int j = 0; j < 9; ++j)
@@ -176,7 +165,7 @@ struct StepIo {
                 rowv t;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) t[c] = acc[c][j];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, lane_valid ? flat4 : 0xffffffffu, row0_bytes + j * pstride_bytes, IPP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw2, t), row_rs, lane_valid ? flat4 : 0xffffffffu, row0_bytes + j * pstride_bytes, kPatchStoreAux);
             }
     }
 };
@@ -186,10 +175,9 @@ __device__ __forceinline__ void patch_sync() {
     if (ONE) wave_lds_sync(); else __syncthreads();
 }
 
-// KPN rows per request group at MINW waves per SIMD: (8, 5) = 95 VGPRs is the default; (4, 6) = 80 VGPRs, 12 workgroups per CU, is
-// 5 % faster for launches of 32768 items and 27 % slower for 4096 (3072 slots: a short, late second round) -- the engine takes it
-// for large launches only.
-template <int NW, int KPN = kPatchKP, int MINW = IPP_PATCH_MINW>
+// (KPN = 4 rows per request group: 12 workgroups of two waves per CU, 5 % faster for launches of 32768 items and 27 % slower for 4096
+// -- two-wave engines take it for large launches only, ipp_info.patch_big_min_items)
+template <int NW, int KPN = kPatchKP, int MINW = kPatchMinW, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     View v, const int* __restrict__ env_ids, int n_items, const double* __restrict__ action,
     const double* __restrict__ prev_action, const float* __restrict__ meas_noise, unsigned flags,
@@ -200,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     constexpr int OW = (NW > 1) ? 1 : 0;                   // the wave that evaluates the observation
     constexpr bool ONE = (NW == 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
-    const PatchLds lds(smem_sp, v.pcap, v.plw * v.plw, NW, v.punits, v.rank_cap);
+    const PatchLds lds(smem_sp, v.pcap, SPLIT ? 0 : v.plw * v.plw, SPLIT ? 1 : NW, v.punits, v.rank_cap);  // (split step: no prior table, one list area)
     if ((int)blockIdx.x >= n_items) return;
     const int item = launch_item(v, blockIdx.x, n_items);
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -208,6 +196,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     IPP_WT_DECL;
     int* next_unit = lds.ctl; int* done_waves = lds.ctl + 1; int* solve_flag = lds.ctl + 2; int* obs_flag = lds.ctl + 3;
     int* wcnt = lds.ctl + 8;  // [RJ][NW] contributing columns found by wave w among its columns j
+    // split step: the item's block, indexed by the DISPATCH POSITION of this workgroup (the unit kernel maps its workgroups to
+    // positions the same way: no lookup of the item order in front of its first load)
+    float* blk = SPLIT ? v.blk + (size_t)(v.blk_pos0 + (int)blockIdx.x) * v.blk_stride : nullptr;
+    int* bh = reinterpret_cast<int*>(blk);
 
     // ------------------------------------------------------------------ batch 1: everything that does not depend on the footprint
     const int env0 = env_ids ? env_ids[item] : item + v.env_base;
@@ -262,6 +254,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
             v.hdr[item] = h;
             if (status_out) status_out[item] = h.status;
             reward_out[item] = 0.f;
+            if (SPLIT) { bh[SplitBlk::ITEM] = item; bh[SplitBlk::NUNITS] = 0; }  // (no unit runs)
         }
         patch_sync<ONE>();  // (every thread holds its copy of prev_action)
         if ((flags & IPP_UPDATE_PREV) && tid == 0) {
@@ -279,8 +272,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     const float* mean_env = v.mean + (size_t)h.env * v.Npad;
     const float* gt_env = v.gt + (size_t)h.env * v.Npad;
     float* slot = v.cov + (size_t)h.env * v.cov_slot;
-    float* ovf = v.q + (size_t)item * v.q_item;  // records that do not fit the LDS staging (global scratch block of the item)
+    // records that do not fit the LDS staging: the item's global scratch block (split step: the record area of the item's block, which
+    // receives EVERY record -- record a at blk_rec + a * 16 -- the first pcap of them are staged in LDS as well, for the m x m algebra)
+    float* blk_rec = SPLIT ? blk + SplitBlk::rec_off(v.plw) : nullptr;
     const int cap = v.pcap, pw = v.pw;
+    float* ovf = SPLIT ? blk_rec + (size_t)cap * kPatchRec : v.q + (size_t)item * v.q_item;
 
     // ------------------------------------------------------------------ batch 2: inputs of the observation (lanes of wave OW)
     ObsRegs oregs;
@@ -394,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
                         const us2g d = __builtin_bit_cast(us2g, yx) - __builtin_bit_cast(us2g, first);
                         const bool in = __builtin_bit_cast(unsigned, __builtin_elementwise_min(d, __builtin_bit_cast(us2g, extent))) == __builtin_bit_cast(unsigned, d);
                         const unsigned voff = in ? (unsigned)(base4 + cell4) : 0xffffffffu;
-                        l[i][a] = (IPP_PATCH_ABLATE & 32) ? (float)(voff & 0xffu) * 1e-30f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
+                        l[i][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slot_rs, voff, 0, 0));
                     }
                 }
             }
@@ -426,8 +422,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
             float4* dst = reinterpret_cast<float4*>(lds.rec + (size_t)a_pos * kPatchRec);
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-        } else {
-            float4* dst = reinterpret_cast<float4*>(ovf + (size_t)(a_pos - cap) * kPatchRec);
+        }
+        if (SPLIT || a_pos >= cap) {
+            float4* dst = reinterpret_cast<float4*>(SPLIT ? blk_rec + (size_t)a_pos * kPatchRec : ovf + (size_t)(a_pos - cap) * kPatchRec);
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
         }
@@ -440,9 +437,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         {
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
             const int lw = v.plw;
+            float* lut_dst = SPLIT ? blk + SplitBlk::kTab + SplitBlk::kTabFixed : lds.lut;  // (split step: straight into the item's block)
             for (int i = tid; i < lw * lw; i += NT) {
                 const int dr = div_small(i, lw), dc = i - dr * lw;
-                lds.lut[i] = matern_f(dr, dc, s3, h.sv);
+                lut_dst[i] = matern_f(dr, dc, s3, h.sv);
             }
             if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
@@ -476,28 +474,54 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     IPP_EXIT_POINT(3);
 
     // ------------------------------------------------------------------ m x m algebra (wave 0) / observation (wave OW)
+    float* linv_dst = SPLIT ? blk + SplitBlk::kTab + 72 : lds.Ls;  // (split step: L^-1 | y straight into the item's block)
+    int status_w0 = 0;  // (wave 0: the status of the m x m algebra)
     if (ONE) {
         observe_wave<MC>(v, h, flags, lds.small, oregs);
-        const int status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.rec, 1, kPatchRec, lds.Ls, lds.ys, nullptr, status_out,
-                                               nullptr, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
+        status_w0 = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.rec, 1, kPatchRec, linv_dst, linv_dst + 81, nullptr, status_out,
+                                        nullptr, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
         wave_lds_sync();
-        if (lane == 0) *solve_flag = (status == IPP_STATUS_NOT_PD) ? 2 : 1;
+        if (lane == 0) *solve_flag = (status_w0 == IPP_STATUS_NOT_PD) ? 2 : 1;
         wave_lds_sync();
         if (lane == 0) IPP_MARK(item, 7);
     } else if (wave == 0) {
-        const int status = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.rec, 1, kPatchRec, lds.Ls, lds.ys, nullptr, status_out,
-                                               obs_flag, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
+        status_w0 = solve_wave_fast<MC>(v, h, item, flags, lds.small, lds.rec, 1, kPatchRec, linv_dst, linv_dst + 81, nullptr, status_out,
+                                        obs_flag, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(solve_flag, status_w0 == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0) IPP_MARK(item, 7);
     } else if (wave == OW) {
         observe_wave<MC>(v, h, flags, lds.small, oregs);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(obs_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-
     IPP_WT(7);
     IPP_EXIT_POINT(4);
+    const UnitGeo ug = unit_geometry(r0n, c0n, hn, wn);
+    const int n_units = ug.n_units;
+
+    if constexpr (SPLIT) {
+        // ---------------------------------------------------------------- split step: the rest of the item's block (wave 0), and out
+        if (!ONE && __builtin_amdgcn_readfirstlane(wave) != 0) return;
+        const bool dead_p = status_w0 == IPP_STATUS_NOT_PD;
+        if (lane < 4 * MC) {  // footprint tables of the units' prior term
+            bh[SplitBlk::kTab + lane] = lds.fb_yx[lane];
+            blk[SplitBlk::kTab + 36 + lane] = lds.fb_w[lane];
+        }
+        if (lane == 0) {
+            bh[SplitBlk::ITEM] = item; bh[SplitBlk::ENV] = h.env; bh[SplitBlk::M] = m; bh[SplitBlk::NC] = n_c;
+            bh[SplitBlk::NUNITS] = n_units; bh[SplitBlk::RANK] = r;
+            bh[SplitBlk::BITS] = ((h.rf == 1) ? SplitBlk::B_RF1 : 0) | ((h.commit != 0) ? SplitBlk::B_COMMIT : 0) | (dead_p ? SplitBlk::B_DEAD : 0);
+            bh[SplitBlk::RECT] = (int)rect_pack(r0n, r1n, c0n, c1n);
+            bh[SplitBlk::TSPAN] = pl.hs->t_lo | (pl.hs->t_hi << 16);
+            bh[SplitBlk::RESET] = ar.src ? ar.src[item] : -1;
+            const double cost_d = pl.hs->cost_d;
+            bh[SplitBlk::COST_LO] = __double2loint(cost_d); bh[SplitBlk::COST_HI] = __double2hiint(cost_d);
+            bh[SplitBlk::kSync] = 0;  // arrival counter of the units
+            IPP_MARK(item, 2);
+        }
+        return;
+    } else {
     // rectangles and patch offsets of the first 128 records, record a in lane a & 63 of set a >> 6 (read by the unit loop through
     // v_readlane: no LDS round trip per stored row)
     const int n_fast = min(n_lds, 2 * kWave);
@@ -515,13 +539,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     // ------------------------------------------------------------------ units of the new patch (k_patch_units.h)
     const bool commit_u = h.commit != 0;
     const int env_u = h.env;
-    const UnitGeo ug = unit_geometry(r0n, c0n, hn, wn, pw);
-    const int n_units = ug.n_units;
     StepIo io;
     io.row_rs = row_rs;
     io.mean_rw = v.mean + (size_t)env_u * v.Npad;
     io.diag_rw = v.diag + (size_t)env_u * v.Npad;
     io.cov_only = cov_only;
+    io.wt_planes = false;
     io.m = m;
     io.row0_bytes = (r + 1) * v.pstride * 4;  // first new row, from one patch in front of the slot (row_rs)
     io.pstride_bytes = v.pstride * 4;
@@ -530,9 +553,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     ua.n_c = n_c; ua.n_fast = n_fast; ua.cap = cap; ua.ovf = ovf;
     ua.next_unit = next_unit; ua.solve_flag = solve_flag; ua.item = item;
     ua.ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
+    const UnitLds ul = {lds.rec, lds.Ls, lds.ys, lds.lut, lds.fb_yx, lds.fb_w};
     unsigned long long units = 0, needed = 0;
     bool dead = false;
-    patch_units<KP>(v, lds, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
+    patch_units<KP>(v, ul, lds.unit_red, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
     IPP_EXIT_POINT(5);
     IPP_WT_RESET;
     IPP_WT_COUNT(11, 1);
@@ -575,6 +599,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     if (reset_k >= 0) wave_reset_env(v, ar, env_u, reset_k, lane);  // (after the rank store above, same lane 0)
     IPP_WT(8);
     IPP_WT_FLUSH(lane);
+    }
 }
 
 // Patch-layout factor state -> dense P = P0 - U U^T (ipp_read_cov_dense: tests, np.diag(state), feature planes).

@@ -37,8 +37,9 @@ struct TreeIo {
     int m, pw, pstride;
     __device__ __forceinline__ rowv row_load(unsigned cofs8, unsigned voff) const {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0) + ((unsigned long long)cofs8 << 3), 0, 0x7ffffff0, 0x00020000);
-        return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, IPP_PATCH_AUX));
+        return __builtin_bit_cast(rowv, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, kPatchRowAux));
     }
+    __device__ __forceinline__ float coef(const UnitLds& ul, int a, int l15) const { return ul.rec[(size_t)a * kPatchRec + l15]; }
     __device__ __forceinline__ void load_pre(int cell0, int flat, int rrow, int rcol, float (&md)[2][2]) const {
         load_vec<2>(mean_ro + cell0, md[0]);
         const float* src = diag_root + cell0;
@@ -69,7 +70,7 @@ struct TreeIo {
 };
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
+__global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
     int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
     int* __restrict__ status_out, float* __restrict__ reward_out, const int* __restrict__ n_dev) {
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
 
     // ------------------------------------------------------------------ units of the new node's patch (k_patch_units.h)
     const bool commit_u = h.commit != 0 && expand;
-    const UnitGeo ug = unit_geometry(r0n, c0n, hn, wn, pw);
+    const UnitGeo ug = unit_geometry(r0n, c0n, hn, wn);
     const int n_units = ug.n_units;
     TreeIo io;
     io.base0 = base0;
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(64 * NW, IPP_PATCH_MINW) void k_tree_patch(
     ua.ridx = lds.ridx + (size_t)wave * (v.rank_cap + KP);
     unsigned long long units = 0, needed = 0;
     bool dead = false;
-    patch_units<KP>(v, lds, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
+    const UnitLds ul = {lds.rec, lds.Ls, lds.ys, lds.lut, lds.fb_yx, lds.fb_w};
+    patch_units<KP>(v, ul, lds.unit_red, io, ua, ug, mcofs, mlo, mex, units, needed, dead);
 
     // ------------------------------------------------------------------ per-item results (last wave to arrive)
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(lds.red);

@@ -271,53 +271,6 @@ def test_pickled_mapping_in_spawned_pool_and_forked_child():
     assert msg.startswith("IppError") and "spawn" in msg, msg
 
 
-def test_pipelined_step_kernel_matches_default_and_oracle(monkeypatch):
-    """k_step_pipe (persistent producer / consumer workgroups, opt-in through IPP_PIPE=1) against the default fused kernel
-    on 512 staggered envs x 60 steps (ranks 0..351, resets, every altitude class) and against the fp64 oracle on one env."""
-    import torch
-    from oracle import ipp_oracle as orc
-    from ipp_rl_amd import EngineConfig
-    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
-
-    cfg = EngineConfig(x_dim=50, y_dim=50)
-    B, T, steps = 512, 40, 60
-    ref = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=5)
-    monkeypatch.setenv("IPP_PIPE", "1")
-    pipe = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=5)
-    monkeypatch.delenv("IPP_PIPE")
-    for env in (ref, pipe):
-        env.reset()
-    worst = 0.0
-    for t in range(steps):
-        acts = cell_centre_actions(cfg, t, 0, B, B, ALTS)
-        r0, s0 = ref.step(acts)
-        r1, s1 = pipe.step(acts)
-        assert int(s0.abs().sum()) == 0 and int(s1.abs().sum()) == 0
-        worst = max(worst, float((r0.double() - r1.double()).abs().max()))
-        assert torch.equal(ref.engine.ranks(), pipe.engine.ranks())
-    assert worst < TOL
-    for e in (0, 39, 40, 511):
-        assert float((ref.mean(e).double() - pipe.mean(e).double()).abs().max()) < TOL
-        assert float((ref.diag(e).double() - pipe.diag(e).double()).abs().max()) < TOL
-    # one env from scratch against the oracle (explicit noise)
-    ocfg = orc.OracleConfig(x_dim=50, y_dim=50)
-    rs = np.random.RandomState(3)
-    white = rs.normal(size=(1, 50, 50))
-    pipe.engine.reset(env_ids=[7], white_noise=white)
-    st = orc.env_reset(ocfg, white[0])
-    prev = np.array([2.0, 2.0, 14.0])
-    for t in range(12):
-        a = np.array([4.0 * rs.randint(20, 28) + 2, 4.0 * rs.randint(20, 28) + 2, float(rs.randint(5, 15))])
-        eps = rs.normal(size=9)
-        m = orc.num_measurements(orc.project_fov(ocfg, a), orc.resolution_factor(a))
-        r, s = pipe.engine.step(a[None], prev[None], env_ids=[7], meas_noise=eps[None])
-        out = orc.env_step(ocfg, st, a, eps[:m])
-        assert int(s[0]) == 0 and abs(float(r[0]) - out["reward"]) < TOL
-        prev = a
-    assert np.max(np.abs(host(pipe.engine.read_mean(7)) - st.mean)) < TOL
-    assert np.max(np.abs(host(pipe.engine.read_diag(7)) - np.diag(st.P))) < TOL
-
-
 @pytest.mark.parametrize("n", [50, 100, 64])
 def test_generator_drawn_noise_equals_fill_then_generate(n):
     """ipp_generate_grf_rows (white noise drawn inside the fast Hartley generator: 50x50 / 100x100) against ipp_fill_normal_rows +
