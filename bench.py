@@ -184,14 +184,16 @@ class Ranks:
             self.dist = None
 
 
-def timed_region(run_steps, steps, sync, ranks):
+def timed_region(run_steps, steps, sync, ranks, info=None):
     """Time EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns (per-rank seconds,
-    max over ranks)."""
+    max over ranks).  info (optional list): receives this rank's host time to ISSUE the steps (before the closing sync)."""
     sync()
     ranks.barrier()
     sync()
     t0 = time.perf_counter()
     run_steps(steps)
+    if info is not None:
+        info.append(time.perf_counter() - t0)
     sync()
     ranks.barrier()
     sync()
@@ -354,7 +356,8 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     run_steps(warmup)
     # `regions` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + device sync on both sides; the
     # reported region is the MEDIAN one (by the max-over-ranks time), the spread goes into the record
-    timed_regions = [timed_region(run_steps, steps, torch.cuda.synchronize, ranks) for _ in range(max(1, regions))]
+    issue_s = []  # host time to issue a region's steps (the launches queue up behind the device: issue time < region time = device-bound)
+    timed_regions = [timed_region(run_steps, steps, torch.cuda.synchronize, ranks, issue_s) for _ in range(max(1, regions))]
     per_rank, elapsed_max = median_region(timed_regions)
     sync_regions = None
     if use_parts:
@@ -428,7 +431,9 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "grid": grid, "envs_local": B, "episode_steps": T, "state": state, "predict_only": bool(predict_only),
         "window_rows": int(eng.info.window_rows), "tile_threads": int(eng.info.tile_threads),
         "per_rank_s": per_rank, "elapsed_max_s": elapsed_max, "steps": steps, "warmup": warmup,
-        "region_elapsed_max_s": [r[1] for r in timed_regions],
+        "region_elapsed_max_s": [r[1] for r in timed_regions], "region_issue_s": issue_s,
+        "queues": getattr(env, "queue_report", None),
+        "split_min_items": int(getattr(eng.info, "patch_split_min_items", 0)),
         "mean_rank_after_step": mean_rank_after, "bad_status": bad, "bad_rewards": bad_rewards,
         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
         "bytes_per_launch": bytes_per_launch, "mask_reread_bytes_per_launch": mask_reread if state == "factor" else 0.0,
@@ -438,7 +443,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
         "arena_gb": float(eng.info.arena_bytes) / 1e9,
     }
-    env.engine.close()
+    env.close()
     del env, eng, actions
     torch.cuda.empty_cache()
     return rec, cfg
@@ -688,6 +693,12 @@ def main(argv=None):
                 "value_is": "median of the timed regions (each exactly `steps` steps, max over ranks)",
                 "per_rank_ms_per_step": [1e3 * t / args.steps for t in rec["per_rank_s"]],
                 "per_rank_env_steps_per_s": [B * args.steps / t for t in rec["per_rank_s"]],
+                # flat scalars (a parser that keeps only scalars still sees where the streams landed and how the regions spread)
+                "region_ms_min": 1e3 * min(rec["region_elapsed_max_s"]) / args.steps, "region_ms_max": 1e3 * max(rec["region_elapsed_max_s"]) / args.steps,
+                "region_ms_first": 1e3 * rec["region_elapsed_max_s"][0] / args.steps,
+                "host_issue_ms_per_step": (1e3 * sorted(rec["region_issue_s"])[len(rec["region_issue_s"]) // 2] / args.steps) if rec["region_issue_s"] else None,
+                "schedule_parts": rec["parts"], "split_min_items": rec["split_min_items"],
+                **{"queues_" + k: v for k, v in (rec["queues"] or {}).items()},
                 "schedule": schedule_text(rec),
                 "sync_schedule": sync_record(rec, total_envs, args.steps),
             },

@@ -276,6 +276,8 @@ int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream);
  * planning/mcts_zero/device_mcts.py allocates them as torch tensors) and keeps them alive for the search.
  * One wave owns one root: root j uses the node ids [j nodes_per_root, (j+1) nodes_per_root) (the first is the root node),
  * the device-node ids [j dev_per_root, (j+1) dev_per_root) of the engine's node pool and its own hash table.
+ * (This is an ORDERING invariant too: between a root's descents the select kernel only waits for its own stores -- a
+ * workgroup-scope fence, csrc/k_mcts.h -- which is correct exactly because no table row is shared between two waves.)
  * Before a search: n_flags = 0 except the root nodes (2 = stored), n_value = 0, n_devpath = -1, n_hash[root node] = any
  * distinct non-zero key, root_count = 1, dev_count = 0, h_keys = 0, err = 0; before every wave: pend_count = rq_count = 0.
  */

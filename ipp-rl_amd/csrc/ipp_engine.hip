@@ -381,11 +381,7 @@ void grf_kernel_host(int H, int W, double c, std::vector<double>& h) {
 template <typename... P, typename... A>
 void timed_launch(Engine* e, int kind, void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
     if (!e->profile) {
-        // IPP_ANY_ORDER=1 (timing experiment, predict-only launches only: they write no state): the dispatch does not wait for the
-        // queue's previous one -- what a step costs without any launch boundary (profiles/r04_experiments.txt 22)
-        static const bool any_order = getenv("IPP_ANY_ORDER") && atoi(getenv("IPP_ANY_ORDER")) != 0;
-        if (any_order) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, nullptr, nullptr, hipExtAnyOrderLaunch, static_cast<P>(args)...);
-        else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
         return;
     }
     hipEvent_t a = nullptr, b = nullptr;

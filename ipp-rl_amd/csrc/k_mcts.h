@@ -275,8 +275,15 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
         }
         // lane 0's stores (virtual visits, children, flags) before the next descent's loads: the SAME wave reads them, through the
         // same L1, so workgroup scope is enough (wait for the stores; no cache action) -- __threadfence() is an agent-scope
-        // release, which writes the L2 back: 11 of the 43 us of a descent (lane-0 clocks of the -DIPP_MCTS_CLOCKS build)
+        // release, which writes the L2 back: 11 of the 43 us of a descent (lane-0 clocks of the -DIPP_MCTS_CLOCKS build).
+        // INVARIANT this rests on: every table a root touches (n_*, t_*, the hash table, root_count: all indexed by the root j) is
+        // private to ONE wave for the whole launch.  A table shared between roots or a second wave per root needs the agent-scope
+        // fence back: -DIPP_MCTS_AGENT_FENCE=1 restores it (A/B, debugging).
+#if defined(IPP_MCTS_AGENT_FENCE) && IPP_MCTS_AGENT_FENCE
+        __threadfence();
+#else
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
         MC_STAMP(7);
     }
 #if IPP_MCTS_CLOCKS

@@ -165,10 +165,18 @@ class IPPEngine:
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
+        """Destroys the engine and releases the arena -- after EVERYTHING issued on the device has finished: launches of
+        step_parts / VecIPPEnv.step_async run on streams the caching allocator does not associate with the arena tensor."""
         if getattr(self, "_h", None):
+            try:
+                _torch().cuda.synchronize(self.device)
+            except Exception:
+                pass
             self._lib.ipp_engine_destroy(self._h)
             self._h = None
             self.arena = None
+            self._parts_ring = None
+            self._keep = None
 
     def __del__(self):
         try:
@@ -388,7 +396,30 @@ class IPPEngine:
         _ffi.check(self._lib.ipp_step_parts(self._h, n, self._ptr(actions), self._ptr(prev_actions), self._ptr(meas_noise), int(flags),
                                             self._ptr(reward), self._ptr(status), self._ptr(reset_src), self._ptr(reset_gt), init,
                                             P, begins, sts))
-        self._keep = (actions, prev_actions, meas_noise, reset_src, reset_gt)
+        # Lifetime of the inputs: the launches run on the PART streams, the caching allocator only knows the caller's stream -- a tensor
+        # the caller drops after this call could be handed out again while a part stream still reads it.  The tuples of the last
+        # 2 x 8 calls are kept; a tuple is dropped only after an event recorded on every part stream BEHIND its launches has
+        # completed (one event record per stream every 8 calls, one synchronize -- long complete -- before a half of the ring is
+        # reused: ~1 us per call; record_stream on five tensors and two streams would be ~15 us of host time per step).
+        ring = getattr(self, "_parts_ring", None)
+        if ring is None or ring[0] != key[1]:
+            torch = _torch()
+            if ring is not None:
+                for evs in ring[2]:
+                    for ev in evs:
+                        ev.synchronize()
+            ring = self._parts_ring = [key[1], [None] * 16, [[torch.cuda.Event() for _ in streams] for _ in range(2)], 0, [False, False]]
+        i = ring[3]
+        half = i // 8
+        if i % 8 == 0 and ring[4][half]:
+            for ev in ring[2][half]:
+                ev.synchronize()  # the launches that read this half's tuples are done
+        ring[1][i] = (actions, prev_actions, meas_noise, reset_src, reset_gt)
+        if i % 8 == 7:
+            for ev, st in zip(ring[2][half], streams):
+                ev.record(st)
+            ring[4][half] = True
+        ring[3] = (i + 1) % 16
 
     def step_raw(self, n, actions, prev_actions, meas_noise, flags, reward, status, env_ids=None):
         """Zero-overhead variant for the benchmark loop: all arguments are preallocated device tensors."""

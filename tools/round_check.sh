@@ -3,7 +3,20 @@
 # Outputs under gpurun_out/round/ (copy the summaries to profiles/rNN_*).  usage: bash tools/round_check.sh
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/round; rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+# the DRIVER's protocol first (20-step regions): this is the line BENCH_rNN.json records -- keep it as profiles/rNN_bench_line_driver.json
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.log 2>&1; tail -1 $O/bench_driver.log | cut -c1-300
 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
+# region length against the per-step time (fill / drain of the two-group pipeline, the staged blocks inside short regions)
+for k in 10 20 50 200; do python bench.py --no-cpu-baseline --no-extra --steps $k --warmup 5 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['config']
+print('steps', d['steps'], 'value %.2f M' % (d['value']/1e6), 'ms/step %.4f' % d['ms_per_step'], 'host issue %.4f' % (c.get('host_issue_ms_per_step') or 0), 'regions', ['%.4f' % x for x in c['region_ms_per_step']])"; done > $O/region_sweep.txt 2>&1; cat $O/region_sweep.txt
+# the split step (prologue kernel + unit kernel) against the fused kernel, same box: headline, one launch per step, configs[2], configs[3] share
+{ CFG="--parts 2" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"
+  CFG="--parts 1 --steps 100" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"
+  CFG="--grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"
+  CFG="--grid 50 --envs 32768 --steps 20 --warmup 4" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"; } > $O/ab_split.txt 2>&1
+[ -f tools/probes/libipp_timing.so ] && { for w in 1 3; do echo "=== split step, prologue kernel with $w waves per item, 2 groups"; IPP_SPLIT_WAVES=$w python tools/timeline_split.py 2 2>&1 | grep -v amdgpu.ids | head -40; done; } > $O/timeline_split.txt 2>&1
 {
   python tools/compat_bench.py
   python tools/score_bench.py --steps 12
