@@ -406,6 +406,14 @@ void prof_drain(Engine* e) {
             if (hipEventElapsedTime(&t0, pend.front().a, pr.a) == hipSuccess) { iv[pr.kind].emplace_back(t0, t0 + ms); iv[3].emplace_back(t0, t0 + ms); }
         }
     }
+    if (const char* dump = getenv("IPP_PROFILE_DUMP")) {  // tools/region_timeline.py: every dispatch's [start, stop] of this batch
+        if (FILE* f = fopen(dump, "a")) {
+            fprintf(f, "# batch of %zu dispatches: kind start_us stop_us\n", pend.size());
+            for (int k = 0; k < 3; ++k)
+                for (auto& x : iv[k]) fprintf(f, "%d %.2f %.2f\n", k, 1e3 * x.first, 1e3 * x.second);
+            fclose(f);
+        }
+    }
     for (auto& pr : pend) {
         (void)hipEventDestroy(pr.a);
         (void)hipEventDestroy(pr.b);

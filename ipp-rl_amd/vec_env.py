@@ -164,6 +164,7 @@ class VecIPPEnv:
                 for ev in evs:
                     ev.record(torch.cuda.current_stream(dev))
             self._blk_tag = [-1, -1]   # block index staged in each buffer set
+            self._blk_prog = [(-1, 0), (-1, 0)]  # (block, fields staged so far) of a block that is being staged field by field
             self._blk_waited = -1      # block whose `ready` event the main stream has waited for
         # measurement noise for NOISE_RING steps per generator launch
         self._noise_ring = torch.empty((self.NOISE_RING, B, self.engine.meas_cap), dtype=torch.float32, device=dev)
@@ -268,14 +269,22 @@ class VecIPPEnv:
         """Phase whose envs finish their episode with step index t: env e has done (t + 1 + phase_e) steps."""
         return (self.episode_steps - ((t + 1) % self.episode_steps)) % self.episode_steps
 
-    def _stage_block(self, b: int):
-        """Start, on the side stream, the ground truths of every reset of the steps [b K, (b + 1) K) into buffer set b % 2."""
+    def _stage_block(self, b: int, upto: Optional[int] = None):
+        """Start, on the side stream, the ground truths of the resets of the steps [b K, b K + upto) into buffer set b % 2 (upto = K: the
+        whole block, then its `ready` event).  Called with growing `upto` it stages a block field by field: the prefetch of the NEXT
+        block is spread over the steps of the running one, one field behind every step's launches -- staged at once (eight generator
+        calls, 160-190 us of host time) in front of a step's launches it was a bubble of that length whenever the host had no lead
+        over the device, i.e. at the start of every timed region (tools/host_step_times.py)."""
         torch = self.torch
         K, set_ = self._blk_K, b % 2
-        for ev in self._blk_free[set_]:
-            self._side.wait_event(ev)
+        upto = K if upto is None else min(int(upto), K)
+        j0 = self._blk_prog[set_][1] if self._blk_prog[set_][0] == b else 0
+        if j0 == 0:
+            for ev in self._blk_free[set_]:
+                self._side.wait_event(ev)
+        self._blk_prog[set_] = (b, max(j0, upto))
         with torch.cuda.stream(self._side):
-            for j in range(K):
+            for j in range(j0, upto):
                 p = self._phase_ending_at(b * K + j)
                 n = int(self._reset_ids_by_phase[p].numel())
                 if n == 0:
@@ -292,8 +301,17 @@ class VecIPPEnv:
                         continue
                 white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white[buf][:n])
                 self.engine.generate_grf(white, out=self._staged[buf][:n], stream=self._side)
-            self._blk_ready[set_].record(self._side)
-        self._blk_tag[set_] = b
+            if upto == K:
+                self._blk_ready[set_].record(self._side)
+        if upto == K:
+            self._blk_tag[set_] = b
+
+    def _prefetch_next_block(self, b: int, j: int):
+        """Behind the launches of step j of block b: field j of block b + 1 (only when an env cannot reset twice inside the two blocks,
+        2 K <= episode_steps: with shorter episodes block b + 1 would be staged before block b's resets have moved the episode
+        counters and would repeat its ground truths; it is then staged whole when its first step arrives)."""
+        if self._blk_tag[(b + 1) % 2] != b + 1 and 2 * self._blk_K <= self.episode_steps:
+            self._stage_block(b + 1, upto=j + 1)
 
     def _invalidate_staging(self):
         """A reset outside the schedule moved episode counters: staged fields may name the wrong episodes."""
@@ -304,6 +322,7 @@ class VecIPPEnv:
             self.wait()  # (the part streams' reads of the sets are in front of this point of the caller's stream)
         for set_ in range(2):
             self._blk_tag[set_] = -1
+            self._blk_prog[set_] = (-1, 0)
             for ev in self._blk_free[set_]:
                 ev.record(main)  # (everything that read the set is in front of this point of the stream)
         self._blk_waited = -1
@@ -356,6 +375,7 @@ class VecIPPEnv:
         main = torch.cuda.current_stream(self.device)
         scheduled = None
         blk = None
+        prefetch = None
         if auto_reset and self._reset_ids_by_phase is not None:
             K = self._blk_K
             b, j = divmod(self.t, K)
@@ -366,15 +386,11 @@ class VecIPPEnv:
             if self._blk_waited != b:
                 main.wait_event(self._blk_ready[set_])
                 self._blk_waited = b
-            # the next block's fields are generated while this block runs -- only when an env cannot reset twice inside the two
-            # blocks (2 K <= episode_steps): with one-step episodes block b + 1 would be staged before block b's reset has moved
-            # the episode counters and would repeat its ground truths; it is then staged when its first step arrives
-            if self._blk_tag[1 - set_] != b + 1 and 2 * K <= self.episode_steps:
-                self._stage_block(b + 1)
             p = self._phase_ending_at(self.t)
             n = int(self._reset_ids_by_phase[p].numel())
             scheduled = (p, set_ * K + j, n) if n > 0 else None
             blk = (set_, j == K - 1)
+            prefetch = (b, j)  # (the next block's fields are generated while this block runs: behind this step's launches)
         elif self._reset_ids_by_phase is not None:
             # a step outside the reset schedule (auto_reset=False): its staged fields stay unused, but when it is the LAST step of
             # its block the block's `free` event is still recorded below -- else the side stream would refill this buffer set
@@ -420,6 +436,8 @@ class VecIPPEnv:
         if scheduled is not None:
             p, k, n = scheduled
             self.reset(gt=self._staged[k][:n], _phase=p)
+        if prefetch is not None:
+            self._prefetch_next_block(*prefetch)
         if blk is not None and blk[1]:
             for ev in self._blk_free[blk[0]]:
                 ev.record(main)  # last step of the block: its buffer set may be refilled
@@ -536,6 +554,7 @@ class VecIPPEnv:
         a = actions if (torch.is_tensor(actions) and actions.dtype == torch.float64 and actions.is_cuda and actions.is_contiguous()) \
             else self.engine._dev(actions, torch.float64).reshape(-1, 3).contiguous()
         streams = self._part_streams
+        prefetch = None
         if not inputs_ready or self._main_dirty:
             self._main_dirty = False
             self._ev_inputs.record(torch.cuda.current_stream(self.device))
@@ -554,12 +573,11 @@ class VecIPPEnv:
                 for st in streams:
                     st.wait_event(self._blk_ready[set_])
                 self._blk_waited = b
-            if self._blk_tag[1 - set_] != b + 1 and 2 * K <= self.episode_steps:
-                self._stage_block(b + 1)
             p = self._phase_ending_at(self.t)
             n = int(self._reset_ids_by_phase[p].numel())
             scheduled = (p, set_ * K + j, n) if n > 0 else None
             blk = (set_, j == K - 1)
+            prefetch = (b, j)
         # (the caller's stream is looked up only when a noise ring is refilled: torch.cuda.current_stream costs ~5 us)
         nz = self._noise_plane_parts(None if self._noise_pos else torch.cuda.current_stream(self.device), streams)
         fused = {}
@@ -578,6 +596,8 @@ class VecIPPEnv:
             for q, st in enumerate(streams):
                 self._blk_free[blk[0]][q].record(st)
         self._async_pending = True
+        if prefetch is not None:
+            self._prefetch_next_block(*prefetch)
 
     def _noise_plane_parts(self, main, streams):
         """Measurement noise of this step on a partitioned batch: plane `pos` of ring (fill index % 2); the other ring is

@@ -653,6 +653,252 @@ def gen_mcts_mission():
     save("mcts_mission", **out)
 
 
+# ----------------------------------------------------------------------------- 14. call trace of the planners on the class surface
+class _Recorder:
+    """Ordered record of everything the reference's planners do to the Mapping / GridMap / sensor / simulation objects (and to the
+    planning.common reward helpers): attribute reads, assignments, calls -- arguments and results as literals or as numbered
+    arrays.  An array OBJECT keeps its number (data flow: a state a call returned and a later call receives is one number),
+    so the replay can hand its own earlier results on the way the planner does."""
+
+    def __init__(self):
+        self.events, self.arrays, self.by_id, self.keep, self.on = [], [], {}, [], False
+        self.as_arg = set()   # arrays first met as an ARGUMENT: the replay needs their values (results only need a digest)
+        self.in_args = False
+
+    @staticmethod
+    def digest(a):
+        """Large results are kept as a digest the replay recomputes on its own result: diagonal, row sums, 64 entries at fixed places."""
+        a = np.asarray(a, dtype=np.float64)
+        flat = a.ravel()
+        idx = np.random.RandomState(a.size).randint(0, a.size, 64)
+        parts = [flat[idx], a.reshape(a.shape[0], -1).sum(axis=1)]
+        if a.ndim == 2 and a.shape[0] == a.shape[1]:
+            parts.append(np.diag(a))
+        return np.concatenate(parts)
+
+    def save_into(self, out, prefix):
+        for i, a in enumerate(self.arrays):
+            if a.size > 400 and i not in self.as_arg:
+                out[f"{prefix}_d{i:04d}"] = self.digest(a)
+                out[f"{prefix}_s{i:04d}"] = np.array(a.shape, dtype=np.int64)
+            else:
+                out[f"{prefix}_a{i:04d}"] = a
+
+    def val(self, x):
+        if isinstance(x, np.ndarray):
+            i = self.by_id.get(id(x))
+            if i is not None and not (self.arrays[i].shape == x.shape and np.array_equal(self.arrays[i], x)):
+                i = None  # (the object was rewritten in place since: a new value)
+            if i is None:
+                i = len(self.arrays)
+                self.arrays.append(np.array(x, copy=True))
+                self.by_id[id(x)] = i
+                self.keep.append(x)
+                if self.in_args:
+                    self.as_arg.add(i)
+            return {"a": i}
+        if isinstance(x, (tuple, list)):
+            return {"t": [self.val(v) for v in x]}
+        if isinstance(x, dict):
+            return {"d": {str(k): self.val(v) for k, v in x.items()}}
+        if x is None or isinstance(x, (bool, str)):
+            return {"v": x}
+        if isinstance(x, (int, np.integer)):
+            return {"v": int(x)}
+        if isinstance(x, (float, np.floating)):
+            return {"v": float(x)}
+        return {"o": type(x).__name__}
+
+    def add(self, kind, obj, name, args=None, kwargs=None, result=None, rng=None):
+        if not self.on:
+            return
+        ev = {"k": kind, "o": obj, "n": name}
+        self.in_args = True
+        if args is not None:
+            ev["args"] = [self.val(a) for a in args]
+        if kwargs:
+            ev["kw"] = {k: self.val(v) for k, v in kwargs.items()}
+        self.in_args = False
+        if kind != "set":
+            ev["r"] = self.val(result)
+        if rng is not None:
+            ev["rng"] = rng
+        self.events.append(ev)
+
+
+class _Proxy:
+    """Recording stand-in for one object of the class surface; the named children come back wrapped as well."""
+    _CHILDREN = {"mapping": ("grid_map", "sensor"), "mapping.sensor": ("sensor_simulation", "sensor_model"), "mapping.grid_map": (),
+                 "mapping.sensor.sensor_simulation": (), "mapping.sensor.sensor_model": ()}
+
+    def __init__(self, target, name, rec):
+        object.__setattr__(self, "_t", target)
+        object.__setattr__(self, "_n", name)
+        object.__setattr__(self, "_r", rec)
+
+    def __getattr__(self, k):
+        t, n, r = object.__getattribute__(self, "_t"), object.__getattribute__(self, "_n"), object.__getattribute__(self, "_r")
+        v = getattr(t, k)
+        if k in _Proxy._CHILDREN.get(n, ()):
+            return _Proxy(v, n + "." + k, r)
+        if callable(v):
+            def call(*args, **kwargs):
+                rng = None
+                if k == "take_measurement" and r.on:  # the observation noise comes from NumPy's global stream: where it stood
+                    st = np.random.get_state()
+                    rng = len(r.arrays)
+                    r.arrays.append(np.array(st[1], dtype=np.uint32))
+                    r.arrays.append(np.array([st[2], st[3]], dtype=np.int64))
+                    r.arrays.append(np.array([st[4]], dtype=np.float64))
+                    r.as_arg.update((rng, rng + 1, rng + 2))  # (stored whole: the replay sets the stream to this state)
+                was = r.on
+                r.on = False  # (what the call does inside the reference is not the planner's business)
+                try:
+                    out = v(*args, **kwargs)
+                finally:
+                    r.on = was
+                r.add("call", n, k, args, kwargs, out, rng)
+                return out
+            return call
+        r.add("get", n, k, result=v)
+        return v
+
+    def __setattr__(self, k, v):
+        t, n, r = object.__getattribute__(self, "_t"), object.__getattribute__(self, "_n"), object.__getattribute__(self, "_r")
+        r.add("set", n, k, args=[v])
+        setattr(t, k, v)
+
+
+def _record_fn(rec, module, name):
+    """Wrap module.name (a planning.common helper the planner imported by name) so that its calls land in the trace."""
+    fn = getattr(module, name)
+
+    def wrapped(*args, **kwargs):
+        was = rec.on
+        rec.on = False
+        try:
+            out = fn(*args, **kwargs)
+        finally:
+            rec.on = was
+        rec.add("call", "fn", name, args, kwargs, out)
+        return out
+
+    setattr(module, name, wrapped)
+    return fn
+
+
+def gen_call_trace():
+    """What planning/mcts_mission.py and the self-play loop of planning/mcts_zero/episode_generators.py DO to the class surface: (i) one
+    MCTSMission replan (run_simulations_proxy + select_best_child, the body of replan, :352-389, in this process -- the reference
+    pickles the mission into a worker pool, where a recorder would be lost) and the executed step behind it (:404-413, with the
+    metric reads of eval, missions.py:176-197); (ii) one self-play episode step (episode_generators.py:112-155) with the
+    reference's MCTS (planning/mcts_zero/mcts.py) on stubbed inference queues.  The -m gpu test tests/test_hip_call_trace.py replays the
+    events against this repo's classes and compares every result."""
+    import json
+    import random
+
+    from planning import mcts_mission as ref_mm
+    import planning.mcts_zero.mcts as ref_mcts
+    import planning.common.optimization as ref_opt
+    from planning.common.features import EpisodeHistory
+
+    out = {}
+    uav = {"max_v": 2, "max_a": 2}
+    dim = 10
+    # ---------------------------------------------------------------- (i) classic planner
+    rec = _Recorder()
+    seed = 21
+    params = load_params(dim, dim)
+    gm, sensor, sim, mapping = build(params, seed=seed)
+    pm = _Proxy(mapping, "mapping", rec)
+    restore = [(m, n, _record_fn(rec, m, n)) for m, n in ((ref_mm, "compute_reward"), (ref_mm, "compute_adaptive_msk"), (ref_mm, "action_costs"))]
+    mis = ref_mm.MCTSMission(pm, uav, dist_to_boundaries=10, min_altitude=8, max_altitude=14, budget=40.0, altitude_spacing=6,
+                             num_simulations=6, gamma=0.95, c=2.0, episode_horizon=2, k=4.0, alpha=0.75, epsilon_expand=0.2,
+                             epsilon_rollout=0.5, max_greedy_radius=5.0, use_gcb_rollout=False, adaptive=True, value_threshold=0.4, interval_factor=0)
+    rec.on = True
+    mis.eval(run_time=0, flight_time=0)
+    previous_waypoint = mis.init_action
+    remaining_budget = mis.budget
+    for step in range(2):  # two rounds of the mission loop (mcts_mission.py:396-414): the second replans from an updated map
+        root = ref_mm.Node(state=pm.grid_map.cov_matrix, parent=None, action=previous_waypoint)
+        assert remaining_budget >= pm.grid_map.resolution
+        random.seed(70 + step)
+        merged_root = mis.run_simulations_proxy(root, remaining_budget, mis.episode_horizon, mis.num_simulations, 0)
+        waypoint = ref_mm.MCTSMission.select_best_child(merged_root).action
+        remaining_budget -= ref_mm.action_costs(waypoint, previous_waypoint, mis.uav_specifications)
+        simulated_raw_measurement = pm.sensor.take_measurement(waypoint)
+        pm.update_grid_map(waypoint, simulated_raw_measurement)
+        previous_waypoint = waypoint
+        mis.eval(run_time=0.0, flight_time=0.0)
+    rec.on = False
+    for m, n, fn in restore:
+        setattr(m, n, fn)
+    out["mission_trace"] = np.frombuffer(json.dumps(rec.events).encode(), dtype=np.uint8)
+    rec.save_into(out, "mission")
+    out["mission_seed"] = seed
+    out["mission_metrics"] = np.array([mis.root_mean_squared_errors, mis.weighted_root_mean_squared_errors, mis.mean_log_losses,
+                                       mis.weighted_mean_log_losses, mis.map_uncertainties, mis.map_uncertainty_differences], dtype=np.float64)
+    print(f"  call trace (mcts_mission): {len(rec.events)} events, {len(rec.arrays)} arrays")
+
+    # ---------------------------------------------------------------- (ii) self-play episode steps
+    rec = _Recorder()
+    seed = 33
+    params = load_params(dim, dim)
+    gm, sensor, sim, mapping = build(params, seed=seed)
+    pm = _Proxy(mapping, "mapping", rec)
+    restore = [(m, n, _record_fn(rec, m, n)) for m, n in ((ref_opt, "compute_reward"), (ref_opt, "compute_adaptive_msk"))]
+    hyper = dict(params["experiment"]["missions"][0]["hyper_params"])
+    hyper.update(num_mcts_simulations=12, non_blocking_read=False)
+    budget = 40.0
+    scenario = {"value_threshold": 0.4, "interval_factor": 0}
+    meta = {"budget": budget, "initial_budget": budget, "episode_horizon": 3, "min_altitude": 8, "max_altitude": 14, "altitude_spacing": 6,
+            "uav_specifications": uav, "scenario_info": scenario}
+    num_actions = dim * dim * 2
+    queues = _StubQueues(num_actions)
+    np.set_printoptions(threshold=sys.maxsize)  # (the node key hash(str(P)) sees the whole matrix: gen_mcts)
+    keep_planes = ref_mcts.generate_input_feature_planes
+    ref_mcts.generate_input_feature_planes = lambda *a, **k: None  # (stubbed network; features.py:98-99 would zero live states in place)
+    mcts = ref_mcts.MCTS(pm, hyper, meta, queues, queues)
+    actions_np = mcts.actions_np
+    rec.on = True
+
+    def get_adaptive_info():
+        return {"mean": pm.grid_map.mean, "value_threshold": 0.4, "interval_factor": 0}
+
+    node = ref_mcts.Node(pm.grid_map.cov_matrix)
+    previous_action = np.array([2.0, 2.0, 14.0])
+    history = EpisodeHistory(hyper["input_history_length"])
+    remaining_budget = budget
+    np.random.seed(5000 + seed)
+    chosen = []
+    for depth in range(2):  # two steps of the loop episode_generators.py:112-155
+        assert remaining_budget >= pm.grid_map.resolution
+        history.push(node.state, previous_action, remaining_budget / budget)
+        policy, valid = mcts.get_policy(node, 0, previous_action, remaining_budget, history, temperature=1)
+        action_idx = np.random.choice(len(policy), p=policy)
+        action = actions_np[action_idx, :]
+        reward, _, next_state = ref_opt.simulate_prediction_step(node.state, previous_action, action, pm, uav, get_adaptive_info())
+        rec.add("call", "fn", "simulate_prediction_step", [node.state, previous_action, action, uav, get_adaptive_info()], None, (reward, next_state))
+        simulated_raw_measurement = pm.sensor.take_measurement(action, verbose=False)
+        pm.update_grid_map(action, simulated_raw_measurement)
+        remaining_budget -= ref_actions.action_costs(action, previous_action, uav)
+        node = ref_mcts.Node(next_state)
+        previous_action = action
+        chosen.append(action_idx)
+    rec.on = False
+    np.set_printoptions(threshold=1000)
+    ref_mcts.generate_input_feature_planes = keep_planes
+    for m, n, fn in restore:
+        setattr(m, n, fn)
+    out["selfplay_trace"] = np.frombuffer(json.dumps(rec.events).encode(), dtype=np.uint8)
+    rec.save_into(out, "selfplay")
+    out["selfplay_seed"] = seed
+    out["selfplay_chosen"] = np.array(chosen)
+    print(f"  call trace (self-play): {len(rec.events)} events, {len(rec.arrays)} arrays")
+    save("call_trace", **out)
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("writing golden vectors to", OUT)
@@ -673,6 +919,7 @@ def main():
     gen_features()
     gen_mcts()
     gen_mcts_mission()
+    gen_call_trace()
     shapes = sorted(set(RESIZE_CALLS))
     print("cv2.resize stub was called with (src shape, dsize):", shapes)
 

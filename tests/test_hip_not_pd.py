@@ -121,3 +121,73 @@ def test_column_records_that_overflow_the_lds_staging(cap, monkeypatch):
         assert torch.equal(a[key], b[key]), key
     for x, y in zip(a["tree"], b["tree"]):
         assert torch.equal(x, y)
+
+
+def _revisit_actions(rs, kind, B, t, dim=50):
+    """Worst cases for S = H P H^T + R on the factor state: the SAME footprint measured again and again -- H P H^T shrinks like R / k
+    while it is evaluated as P0 - sum of squared fp32 column entries, so its rounding error is largest relative to what is left."""
+    if kind == "1x1@5m":      # one cell, R = nv(5 m) = 0.0316
+        cell = np.tile(np.array([[17, 23]]), (B, 1))
+        alt = np.full(B, 5.0)
+    elif kind == "5x5@14m":   # 5 x 5 cells -> 3 x 3 blocks of rf = 2 (partial border blocks), R = 8 nv(14 m)
+        cell = np.tile(np.array([[30, 12]]), (B, 1))
+        alt = np.full(B, 14.0)
+    elif kind == "corner@14m":  # clipped at the grid corner: 3 x 3 cells, 2 x 2 blocks
+        cell = np.tile(np.array([[0, 49]]), (B, 1))
+        alt = np.full(B, 14.0)
+    else:                      # jitter by one cell and by altitude: overlapping footprints of every shape
+        cell = np.array([[25, 25]]) + rs.randint(-1, 2, size=(B, 2))
+        alt = rs.choice(ALTS, B)
+    return np.stack([4.0 * cell[:, 0] + 2.0, 4.0 * cell[:, 1] + 2.0, alt], axis=1)
+
+
+@pytest.mark.parametrize("kind", ["1x1@5m", "5x5@14m", "corner@14m", "jitter"])
+@pytest.mark.parametrize("split", [0, 1])
+def test_S_stays_positive_definite_on_the_worst_reachable_states(kind, split, monkeypatch):
+    """mapping/mappings.py:200-215 (the inverse fallback behind a failed Cholesky) against the factor engine's refusal (status 2):
+    the refusal is UNREACHABLE on states the engine itself produces.  S = H P H^T + R with P = P0 - U U^T positive semi-definite in
+    exact arithmetic, so lambda_min(S) >= R; in the engine H P H^T comes from fp32 columns summed in fp64, whose error after 40
+    revisits of one footprint is ~1e-6 -- four orders of magnitude below R (0.03 at 5 m, 0.39 at 14 m).  Driven here: 40 steps (a
+    whole episode, the configured rank cap) on the headline configuration (fp32 patches, window 10, fixed prior), every step's S read
+    back (ipp_debug_step_item): status 0, lambda_min(S) >= R / 2 -- in fact >= R (1 - 1e-4) -- and the oracle's S within 1e-5."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+    from oracle import ipp_oracle as orc
+
+    monkeypatch.setenv("IPP_SPLIT", str(split))
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B, T = 4, 40
+    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=9 * T, window_rows=-1, fixed_prior=True)
+    monkeypatch.delenv("IPP_SPLIT")
+    assert eng.info.patch_layout == 1 and int(eng.info.window_rows) == 10 and int(eng.info.patch_split_min_items) == split
+    ocfg = orc.OracleConfig(x_dim=50, y_dim=50)
+    rs = np.random.RandomState(11)
+    white = rs.normal(size=(B, 50, 50))
+    eng.reset(white_noise=white)
+    ost = orc.env_reset(ocfg, white[0])
+    eng.debug_capture(True)
+    prev = np.tile(np.array([2.0, 2.0, 14.0]), (B, 1))
+    worst_ratio, worst_S = np.inf, 0.0
+    for t in range(T):
+        acts = _revisit_actions(rs, kind, B, t)
+        eps = rs.normal(size=(B, 9))
+        reward, status = eng.step(acts, prev, meas_noise=eps)
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0, (kind, t, status.tolist())
+        assert bool(torch.isfinite(reward).all())
+        for b in range(B):
+            it = eng.debug_item(b)
+            R = it["rf"] ** 3 * it["noise_var"]
+            lam = float(np.linalg.eigvalsh(it["S"]).min())
+            worst_ratio = min(worst_ratio, lam / R)
+            assert lam >= 0.5 * R, (kind, t, b, lam, R)
+        # env 0 against the fp64 oracle (dense P): the same S
+        m = orc.num_measurements(orc.project_fov(ocfg, acts[0]), orc.resolution_factor(acts[0]))
+        out = orc.env_step(ocfg, ost, acts[0], eps[0, :m])
+        worst_S = max(worst_S, float(np.max(np.abs(eng.debug_item(0)["S"] - out["terms"].S))))
+        assert abs(float(reward[0]) - out["reward"]) < 1e-5
+        prev = acts
+    assert worst_ratio > 1.0 - 1e-4, (kind, worst_ratio)
+    assert worst_S < 1e-5
+    assert int(eng.ranks().max()) <= 9 * T
+    eng.close()
