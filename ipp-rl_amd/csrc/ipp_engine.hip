@@ -92,6 +92,8 @@ struct Engine {
     bool profile = false;
     int step_chunks = 0;  // 0 = auto
     bool fused = false;   // k_step_factor instead of k_prepare + k_gain_factor
+    bool tree_ok = false; // ipp_tree_step available (fused engines; MC = 25: the fused tree kernel beside two-launch env steps)
+    size_t tree_fused_lds = 0;
     bool patch = false;   // k_step_patch on compact column patches (View::patch)
     int patch_waves = kPatchWavesDefault;  // waves per item of k_step_patch
     int split_min_items = 0;  // launches of at least this many items run the SPLIT step (k_step_split.h: prologue kernel + unit kernel); 0: never
@@ -473,8 +475,9 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
     }
+    if constexpr (MC == 9) {  // (MC = 25: the fused kernel would spill 431 VGPRs -- those engines run the prologue and the gain kernel as two launches)
     if (e->fused) {  // windowed factor state: prologue + gain in one kernel, one workgroup per item
-        if (MC == 9 && VEC == 2 && e->rect_ok && (e->rect_commit || (flags & IPP_PREDICT_ONLY)))
+        if (VEC == 2 && e->rect_ok && (e->rect_commit || (flags & IPP_PREDICT_ONLY)))
             timed_launch(e, 0, k_step_factor<MC, VEC, (MC == 9 && VEC == 2)>, dim3(n), dim3(kStepThreads), e->gain_lds, s, v, env_ids, n, action, prev, noise,
                      flags, e->lut_rows, status, reward, ar);
         else
@@ -482,6 +485,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                      flags, e->lut_rows, status, reward, ar);
         if (prep_done) (void)hipEventRecord(prep_done, s);
         return;
+    }
     }
     if (v.mode == IPP_FACTOR)
         timed_launch(e, 2, k_prepare<MC, IPP_FACTOR>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, env_ids, dst_ids, n, action, prev,
@@ -877,7 +881,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     e->gain_lds = gain_lds_bytes(v, e->q_chunk, e->lut_cap);
     if (v.mode == IPP_FACTOR && v.window_rows > 0) {
         const size_t MCs = v.meas_cap, LQ = (MCs * MCs + MCs + 3) & ~(size_t)3;
-        e->fused = (v.T == kStepThreads) || e->patch;
+        e->fused = ((v.T == kStepThreads) && v.meas_cap == 9) || e->patch;  // (MC = 25: two launches, see launch_chunk)
         if (const char* fu = getenv("IPP_FUSED")) e->fused = e->fused && atoi(fu) != 0;  // A/B experiments
         const int waves = v.T / 64;
         // prior table rows: a tile that holds new columns lies within window_rows of the footprint, so
@@ -890,10 +894,13 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
             e->gain_lds = e->fused ? std::max(GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, v.win_tiles * kWave),
                                               GainLds<9>::bytes(v.rank_cap, step_work_floats<9>(v.rank_cap), lutf, step_small_floats<9>(), waves, v.win_tiles, 0, 0, v.vec))
                                    : GainLds<9>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
-        else
-            e->gain_lds = e->fused ? std::max(GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave),
-                                              GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec))
-                                   : GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
+        else {
+            // MC = 25: env steps are two launches (gain_lds = the gain kernel's), tree steps stay the fused tree kernel (its LDS below)
+            e->gain_lds = GainLds<25>::bytes(v.rank_cap, 0, lutf, 0, waves, v.win_tiles, 0, 0, v.vec);
+            e->tree_ok = v.T == kStepThreads;
+            e->tree_fused_lds = std::max(GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, v.win_tiles * kWave),
+                                         GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec));
+        }
         if (e->patch) e->gain_lds = PatchLds::bytes(v.pcap, v.plw * v.plw, e->patch_waves, v.punits, v.rank_cap);
         if (e->patch && e->patch_waves == 2 && !getenv("IPP_PATCH_CAP") && !getenv("IPP_PATCH_WGS")) {
             // second configuration for large launches: LDS share of 12 workgroups per CU (10 granules of 1280 bytes)
@@ -953,7 +960,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
-    e->tree_step_lds = (e->gain_lds + (size_t)v.rank_cap * 8 + 15) & ~(size_t)15;
+    if (e->fused) e->tree_ok = true;
+    e->tree_step_lds = ((e->tree_fused_lds ? e->tree_fused_lds : e->gain_lds) + (size_t)v.rank_cap * 8 + 15) & ~(size_t)15;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
@@ -972,7 +980,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -1324,7 +1331,7 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
     Engine* e = as_engine(engine);
     if (!e || !root_ids || !path_ids || !action || !prev_action || !reward) return fail(-1, "null argument");
     if (e->tv.node_cap <= 0) return fail(-1, "ipp_tree_step needs ipp_config.node_capacity > 0");
-    if (!e->fused) return fail(-1, "ipp_tree_step needs IPP_FACTOR with window_rows > 0 and the default tile_threads");
+    if (!e->tree_ok) return fail(-1, "ipp_tree_step needs IPP_FACTOR with window_rows > 0 and the default tile_threads");
     if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
     if (n == 0) return 0;
     if (flags & ~(IPP_COV_ONLY | IPP_PREDICT_ONLY | IPP_ADAPTIVE | IPP_USE_FLIGHT_TIME)) return fail(-1, "unsupported flag bits 0x%x", flags);

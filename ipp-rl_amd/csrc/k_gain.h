@@ -23,9 +23,6 @@ namespace ipp {
 #ifndef IPP_MINWAVES
 #define IPP_MINWAVES 4
 #endif
-#ifndef IPP_ABLATE
-#define IPP_ABLATE 0  // timing experiments only: 8 = no U row appends
-#endif
 #ifndef IPP_NT_STORES
 #define IPP_NT_STORES 1  // appended rows: -2 % kernel time (A/B on MI355X)
 #endif
@@ -329,7 +326,7 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
         // append the m new columns (rows of the [k][cell] layout): coalesced row writes
 #pragma unroll
         for (int j = 0; j < MC; ++j)
-            if (j < m && !((IPP_ABLATE & 8) && acc[0][0] != 12345.f)) {
+            if (j < m) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
                 store_stream<VEC>(cov_dst + (size_t)(h.rank + j) * v.Npad + cell0, outv);

@@ -26,9 +26,6 @@
 #ifndef IPP_SF_PIPE
 #define IPP_SF_PIPE 10  // same, fused step kernel (A/B on MI355X: 6..12 within 3 %, 10 the most consistent)
 #endif
-#ifndef IPP_GF_ABLATE
-#define IPP_GF_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no row stream, 8 = no compaction, 16 = no mean / diag atomics, 32 = no new-row stores
-#endif
 // Rows requested per group by VEC: a row of a 64 * VEC-cell tile is 256 VEC bytes per wave, so the VEC = 2 kernels keep
 // more of them in flight for the same bytes (A/B at 4096 envs of 50x50, VEC = 2: 10 / 16 / 20 rows 13.65 / 13.85 / 13.85 M)
 #ifndef IPP_PIPE2
@@ -325,7 +322,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         int nact = 0;
         bool partial = false;  // (rect: some active column covers only a part of the unit: its loads are predicated per lane)
         bool span_part = false;  // (rm: ... already by its tile span -- columns written on band tiles; else the rectangle test suffices)
-        for (int k0 = 0; k0 < ((IPP_GF_ABLATE & 8) ? 0 : r); k0 += kWave) {
+        for (int k0 = 0; k0 < r; k0 += kWave) {
             const int k = k0 + lane;
             bool on = false;
             bool part_k = false, part_sp = false;
@@ -421,7 +418,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 if (PRE) {
 #pragma unroll
                     for (int b = 0; b < MC; ++b) {  // unrolled: acc[.][b] must be a static register index
-                        if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                        if (b < m) {
                             float cb[VEC];
                             block_term(b, cb);
 #pragma unroll
@@ -434,7 +431,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                     // the FMAs through the DPP row broadcast (45 dependent broadcast LDS reads per tile before)
                     static_for<0, MC>([&](auto bc) {
                         constexpr int B = decltype(bc)::value;
-                        if (B < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                        if (B < m) {
                             float cb[VEC];
                             block_term(B, cb);
                             static_for<B, MC>([&](auto jc) {
@@ -447,7 +444,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 } else {
 #pragma unroll
                     for (int b = 0; b < MC; ++b) {
-                        if (b < ((IPP_GF_ABLATE & 1) ? 0 : m)) {
+                        if (b < m) {
                             float cb[VEC];
                             block_term(b, cb);
 #pragma unroll
@@ -478,7 +475,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         }
 
         // ---- stream the stored rows: acc += row_k[cells] * Q[k,:]  (Q carries the sign of the downdate)
-        if (nact > 0 && !(IPP_GF_ABLATE & 4)) {
+        if (nact > 0) {
             typedef float rowv __attribute__((ext_vector_type(VEC)));
             auto col_of = [&](int a) -> int { return __builtin_amdgcn_readfirstlane((int)ridx[min(a, nact + 7)]); };
             const int safe_k = col_of(0);  // nact > 0: the first column stored on this tile
@@ -651,7 +648,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
         }
         units += (unsigned long long)(nact + (commit ? m + 4 : 2)) * in_cells + (unsigned long long)(commit ? m : 0) * (valid_cells - in_cells);
         if (LMASK && commit) extra += 2ull * in_cells;
-        if (commit && !((IPP_GF_ABLATE & 2) && acc[0][0] != 12345.f)) {
+        if (commit) {
             float outv[VEC];
             if (LMASK) {
                 // in place (dst == env): diag -= |Wc_i|^2, mean += Wc_i y as read-modify-writes at L2.
@@ -662,7 +659,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
                 // value (ds_bpermute, no LDS memory) make instruction c cover cells 64 c .. 64 c + 63 of the tile.
                 float* dg = (CHAIN ? diag_rw : v.diag + (size_t)h.dst * npad) + (size_t)tile * kWaveTile;
                 float* mu = v.mean + (size_t)h.dst * npad + (size_t)tile * kWaveTile;
-                const bool no_atomics = (IPP_GF_ABLATE & 16) && acc[0][0] != 12345.f;
+                const bool no_atomics = false;
                 const int comp = lane & (VEC - 1);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
@@ -691,7 +688,7 @@ __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, cons
             }
 #pragma unroll
             for (int j = 0; j < MC; ++j)
-                if (j < m && lane_valid && !((IPP_GF_ABLATE & 32) && acc[0][0] != 12345.f)) {
+                if (j < m && lane_valid) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) outv[c] = acc[c][j];
                     store_stream<VEC>((CHAIN ? new_cols + (size_t)j * cc->nstride : cov_dst + (size_t)(r + j) * npad) + cell0, outv);

@@ -21,9 +21,6 @@
 #ifndef IPP_GW_PIPE
 #define IPP_GW_PIPE 12  // rows of U requested per group (A/B on MI355X: 4: 0.46 ms, 8: 0.42, 12: 0.40; ping-pong 2 x 4: 0.44)
 #endif
-#ifndef IPP_GW_ABLATE
-#define IPP_GW_ABLATE 0  // timing experiments only: 1 = no prior table / base term, 2 = no stores, 4 = no Q loads
-#endif
 
 namespace ipp {
 
@@ -106,7 +103,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
         const int dmax = max(abs(trow0 - h.yu), max(abs(trow0 - h.yd), max(abs(trow1 - h.yu), abs(trow1 - h.yd))));
         const int nlut = (dmax - dmin + 1) * v.W;
         const bool use_lut = nlut <= kTileLut;
-        if (use_lut && !(IPP_GW_ABLATE & 1)) {
+        if (use_lut) {
             for (int i = lane; i < nlut; i += kWave) {
                 const int dr = i / v.W, dc = i - dr * v.W;
                 lut[i] = matern_f(dmin + dr, dc, s3, h.sv);
@@ -130,7 +127,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
             }
             // per block: 4 (padded, weight 0) footprint cells x VEC grid cells = 4*VEC independent table lookups in
             // flight, so the LDS latency is paid once per block instead of once per lookup
-            for (int b = 0; b < ((IPP_GW_ABLATE & 1) ? 0 : m); ++b) {
+            for (int b = 0; b < m; ++b) {
                 float cb[VEC];
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) cb[c] = 0.f;
@@ -173,7 +170,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
                     const float* __restrict__ qr = qrows + (size_t)kq[i] * QS;
                     float qv[MC];
 #pragma unroll
-                    for (int j = 0; j < MC; ++j) qv[j] = (IPP_GW_ABLATE & 4) ? (float)(kq[i] + j) : qr[j];
+                    for (int j = 0; j < MC; ++j) qv[j] = qr[j];
 #pragma unroll
                     for (int j = 0; j < MC; ++j)
 #pragma unroll
@@ -222,7 +219,7 @@ __global__ __launch_bounds__(kWave, 4) void k_gain_wave(View v, const float* __r
         item_part += wave_sum(part);
         const int valid_cells = max(0, min(kWaveTile, v.N - tile * kWaveTile));
         units += (unsigned long long)(nact + (h.commit ? m + 4 : 2)) * valid_cells;
-        if (h.commit && !((IPP_GW_ABLATE & 2) && acc[0][0] != 12345.f)) {
+        if (h.commit) {
             float outv[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) outv[c] = diag_in[c] - dred[c];

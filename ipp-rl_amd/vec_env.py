@@ -311,7 +311,10 @@ class VecIPPEnv:
         2 K <= episode_steps: with shorter episodes block b + 1 would be staged before block b's resets have moved the episode
         counters and would repeat its ground truths; it is then staged whole when its first step arrives)."""
         if self._blk_tag[(b + 1) % 2] != b + 1 and 2 * self._blk_K <= self.episode_steps:
-            self._stage_block(b + 1, upto=j + 1)
+            if os.environ.get("IPP_STAGE_SPREAD", "1") == "0":  # A/B: the whole block at once, behind the first step's launches
+                self._stage_block(b + 1)
+            else:
+                self._stage_block(b + 1, upto=j + 1)
 
     def _invalidate_staging(self):
         """A reset outside the schedule moved episode counters: staged fields may name the wrong episodes."""
