@@ -368,6 +368,14 @@ int ipp_generate_grf(void* engine, int32_t n, const float* white_noise /*[dev]*/
  */
 int ipp_generate_grf_rows(void* engine, int32_t n, const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence,
                           float* gt_out /*[dev]*/, void* stream);
+/* ... for fields of SEVERAL episodes in one launch (the batched driver stages the ground truths of a block of steps at once):
+ * field i belongs to group i / group_rows and draws from subsequence + group_subsequence[group] ([host] int64, at most 16 groups,
+ * passed by value: nothing is uploaded in front of the launch); a negative row_ids[i] skips field i (its gt_out row stays as it is).
+ * group_rows = 0: one group (= ipp_generate_grf_rows).
+ * simulations/ground_truths.py:14-33 (the field), mapping/mappings.py:217-261 (the reset that installs it). */
+int ipp_generate_grf_groups(void* engine, int32_t n, int32_t group_rows, const int64_t* group_subsequence /*[host] or NULL*/,
+                            const int32_t* row_ids /*[dev] or NULL*/, int64_t row_offset, uint64_t seed, uint64_t subsequence,
+                            float* gt_out /*[dev]*/, void* stream);
 
 /*
  * One fused environment step for `n` items.  Replaces, per item:

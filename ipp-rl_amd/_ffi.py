@@ -104,6 +104,7 @@ PROTOTYPES = {
     "ipp_tree_score_actions": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_generate_grf_rows": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
+    "ipp_generate_grf_groups": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
     "ipp_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_step_autoreset": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "ipp_step_parts": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),

@@ -648,7 +648,7 @@ int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* 
                const GrfNoise* noise = nullptr) {
     const View& v = e->v;
     if (!white && !(noise && e->grf_tt > 0 && e->grf_fft)) return fail(-1, "in-kernel ground-truth noise needs the fast Hartley path (50x50 / 100x100 grids)");
-    const GrfNoise gn = noise ? *noise : GrfNoise{nullptr, 0, 0, 0};
+    const GrfNoise gn = noise ? *noise : GrfNoise{nullptr, 0, 0, 0, 0, {0}};
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
     if (e->grf_tt > 0 && e->grf_fft) {  // n = 50 / 100: fast Hartley transforms in LDS (k_grf_fft.h), same amplitude table
         const int np = 16 * e->grf_tt;
@@ -1223,13 +1223,21 @@ int ipp_generate_grf(void* engine, int32_t n, const float* white_noise, float* g
 
 int ipp_generate_grf_rows(void* engine, int32_t n, const int32_t* row_ids, int64_t row_offset, uint64_t seed, uint64_t subsequence,
                           float* gt_out, void* stream) {
+    return ipp_generate_grf_groups(engine, n, 0, nullptr, row_ids, row_offset, seed, subsequence, gt_out, stream);
+}
+
+int ipp_generate_grf_groups(void* engine, int32_t n, int32_t group_rows, const int64_t* group_subsequence, const int32_t* row_ids,
+                            int64_t row_offset, uint64_t seed, uint64_t subsequence, float* gt_out, void* stream) {
     Engine* e = as_engine(engine);
     if (!e || !gt_out) return fail(-1, "null argument");
     if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
     if (n == 0) return 0;
+    if (group_rows < 0 || (group_rows > 0 && (!group_subsequence || (n + group_rows - 1) / group_rows > 16)))
+        return fail(-1, "ipp_generate_grf_groups: at most 16 groups of group_rows fields, with their subsequence offsets");
     if (!(e->grf_tt > 0 && e->grf_fft)) return fail(-3, "ipp_generate_grf_rows: this grid has no generator that draws its own noise (ipp_fill_normal_rows + ipp_generate_grf)");
     HIP_TRY(hipSetDevice(e->device));
-    const GrfNoise gn = {row_ids, (long long)row_offset, seed, subsequence};
+    GrfNoise gn = {row_ids, (long long)row_offset, seed, subsequence, group_rows, {0}};
+    for (int g = 0; group_rows > 0 && g < (n + group_rows - 1) / group_rows; ++g) gn.group_subseq[g] = (long long)group_subsequence[g];
     return launch_grf(e, n, nullptr, e->v.grf_raw2, nullptr, gt_out, reinterpret_cast<hipStream_t>(stream), &gn);
 }
 

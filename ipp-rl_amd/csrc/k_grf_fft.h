@@ -133,6 +133,10 @@ struct GrfNoise {
     const int* row_ids;
     long long row_offset;
     uint64_t seed, subseq;
+    // fields of several episodes in one launch (ipp_generate_grf_groups): field i belongs to group i / group_rows and draws from
+    // subseq + group_subseq[group] (by value: no upload in front of the launch); group_rows == 0: one group.  A NEGATIVE row id skips the field.
+    int group_rows;
+    long long group_subseq[16];
 };
 
 // One workgroup per field.  white [n_items][N] float standard normals (or nullptr: GrfNoise); amp [n][amp_ld] doubles (the table of
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gf[];
     const int item = blockIdx.x;
     if (item >= n_items) return;
+    if (!white && gn.row_ids && gn.row_ids[item] < 0) return;  // (padding row of a staged block)
     const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
     if (env < 0 || env >= v.cap) return;
     T* X = reinterpret_cast<T*>(smem_gf);
@@ -167,10 +172,11 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
             }
         } else {
             const uint64_t rid = (uint64_t)((gn.row_ids ? (long long)gn.row_ids[item] : (long long)item) + gn.row_offset);
+            const uint64_t subseq = gn.subseq + (gn.group_rows > 0 ? (uint64_t)gn.group_subseq[min(item / gn.group_rows, 15)] : 0ull);
             constexpr int qpr = (N + 3) / 4;  // counters per row: element e of the row is normal e & 3 of counter rid * qpr + (e >> 2)
             for (int qc = tid; qc < qpr; qc += NT) {
                 float nrm[4];
-                philox_normal4(rid * (uint64_t)qpr + (uint64_t)qc, gn.subseq, gn.seed, nrm);
+                philox_normal4(rid * (uint64_t)qpr + (uint64_t)qc, subseq, gn.seed, nrm);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int e = 4 * qc + h;

@@ -317,14 +317,20 @@ class IPPEngine:
         self._keep_grf = w
         return out
 
-    def generate_grf_rows(self, n: int, seed: int, subsequence: int, out, row_ids=None, row_offset: int = 0, stream=None) -> bool:
+    def generate_grf_rows(self, n: int, seed: int, subsequence: int, out, row_ids=None, row_offset: int = 0, stream=None,
+                          group_rows: int = 0, group_subsequence=None) -> bool:
         """generate_grf with the white noise drawn inside the generator (the numbers normal_rows(.., n_cells, seed, subsequence, row_ids,
-        row_offset) would have written).  Returns False when this grid has no such generator (caller: normal_rows + generate_grf)."""
+        row_offset) would have written).  group_rows / group_subsequence (host ints, <= 16 groups): fields of several episodes in one
+        launch -- field i draws from subsequence + group_subsequence[i // group_rows]; a negative row id skips its field.  Returns False
+        when this grid has no such generator (caller: normal_rows + generate_grf)."""
         torch = _torch()
         ids = self._dev(row_ids, torch.int32)
         st = self.stream if stream is None else C.c_void_p(stream.cuda_stream)
-        rc = self._lib.ipp_generate_grf_rows(self._h, int(n), self._ptr(ids), int(row_offset), int(seed) & (2 ** 64 - 1),
-                                             int(subsequence) & (2 ** 64 - 1), self._ptr(out), st)
+        gs = None
+        if group_rows:
+            gs = (C.c_int64 * len(group_subsequence))(*[int(x) for x in group_subsequence])
+        rc = self._lib.ipp_generate_grf_groups(self._h, int(n), int(group_rows), gs, self._ptr(ids), int(row_offset), int(seed) & (2 ** 64 - 1),
+                                               int(subsequence) & (2 ** 64 - 1), self._ptr(out), st)
         if rc == -3:
             return False
         _ffi.check(rc)
