@@ -356,8 +356,12 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     run_steps(warmup)
     # `regions` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + device sync on both sides; the
     # reported region is the MEDIAN one (by the max-over-ranks time), the spread goes into the record
+    def sync_all():  # join the part streams into the caller's, then the device (the env learns that nothing of it is in flight any more)
+        env.wait()
+        torch.cuda.synchronize()
+
     issue_s = []  # host time to issue a region's steps (the launches queue up behind the device: issue time < region time = device-bound)
-    timed_regions = [timed_region(run_steps, steps, torch.cuda.synchronize, ranks, issue_s) for _ in range(max(1, regions))]
+    timed_regions = [timed_region(run_steps, steps, sync_all, ranks, issue_s) for _ in range(max(1, regions))]
     per_rank, elapsed_max = median_region(timed_regions)
     sync_regions = None
     if use_parts:
