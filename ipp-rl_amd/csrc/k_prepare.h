@@ -910,7 +910,12 @@ __device__ __forceinline__ void observe_wave(const View& v, const ItemHdr& h, un
             val = fmin(fmax(val + h.nv_d * eps, 0.0), 1.0);
         zz[lane] = val;
         double hx = 0.0;
-        for (int a = 0; a < myb.count(); ++a) hx += myb.weight * (double)o.mean[a];
+        // (fixed trip count: with the block's cell count as the bound, o.mean[] was indexed dynamically and ObsRegs lived in scratch --
+        // the only scratch object of the patch kernels; same additions in the same order)
+        const int cnt_b = myb.count();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < cnt_b) hx += myb.weight * (double)o.mean[a];
         vv[lane] = val - hx;
     } else if (lane < MC) {
         zz[lane] = 0.0;
