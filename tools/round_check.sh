@@ -35,6 +35,10 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_mct
 # PMC passes (separate runs, counters only)
 bash tools/pmc_run.sh $O/pmc --parts 1 > $O/pmc_run.log 2>&1
 python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json
+# the split step's kernels (unit kernel: waves' wait share, traffic; prologue kernel) -- its summary is NOT named *pmc_summary*: bench.py
+# replays traffic from those, and the split run has the same command line
+IPP_SPLIT=1 PMC_CUSTOM="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES;FETCH_SIZE;WRITE_SIZE TCC_HIT_sum TCC_MISS_sum;SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" bash tools/pmc_run.sh $O/pmc_split --parts 1 > $O/pmc_run_split.log 2>&1
+python tools/pmc_summary.py $O/pmc_split 40 > $O/split_pmc.json 2>>$O/pmc_summary.err
 PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_w12 --parts 1 --shuffle-prior > $O/pmc_run_w12.log 2>&1
 python tools/pmc_summary.py $O/pmc_w12 40 > $O/pmc_summary_w12.json 2>>$O/pmc_summary.err
 PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --parts 1 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
