@@ -188,7 +188,8 @@ int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const dou
  *   prev_action [dev] double[..][3]: read per ITEM by the step (and written with IPP_UPDATE_PREV), written per ENV by
  *               the reset: use it with env_ids == NULL (item == env) unless the two index spaces agree
  *   reset_src   [dev] int32[n]: index into reset_gt, or -1 (no reset); NULL: plain ipp_step
- *   reset_gt    [dev] float[..][H][W] ground-truth fields (e.g. from ipp_generate_grf)
+ *   reset_gt    [dev] float[..][H][W] ground-truth fields (e.g. from ipp_generate_grf); NULL: every resetting env takes the field staged
+ *               in its alternate plane (ipp_generate_grf_groups with gt_out == NULL) -- a flip, no copy
  *   init_action [host] double[3]
  */
 int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const double* action, double* prev_action,
@@ -372,6 +373,10 @@ int ipp_generate_grf_rows(void* engine, int32_t n, const int32_t* row_ids, int64
  * field i belongs to group i / group_rows and draws from subsequence + group_subsequence[group] ([host] int64, at most 16 groups,
  * passed by value: nothing is uploaded in front of the launch); a negative row_ids[i] skips field i (its gt_out row stays as it is).
  * group_rows = 0: one group (= ipp_generate_grf_rows).
+ * gt_out == NULL: field i is written into the ALTERNATE ground-truth plane of env slot row_ids[i] -- every env owns two planes, the
+ * current one and the one for its next episode; a reset folded into a step launch with reset_gt == NULL (ipp_step_autoreset,
+ * ipp_step_parts) then only flips the env to it instead of copying H * W floats in and out (at 100x100 and 2048 resets per step the
+ * copies were 164 MB of a step's traffic).  ipp_read_gt / ipp_write_gt / ipp_reset always address the CURRENT plane.
  * simulations/ground_truths.py:14-33 (the field), mapping/mappings.py:217-261 (the reset that installs it). */
 int ipp_generate_grf_groups(void* engine, int32_t n, int32_t group_rows, const int64_t* group_subsequence /*[host] or NULL*/,
                             const int32_t* row_ids /*[dev] or NULL*/, int64_t row_offset, uint64_t seed, uint64_t subsequence,

@@ -129,7 +129,9 @@ struct View {
     // state slabs
     float* mean;     // [cap][Npad]
     float* diag;     // [cap][Npad]
-    float* gt;       // [cap][Npad]
+    float* gt;       // [2 cap][Npad] ground-truth planes: env e reads plane gt_slot[e] (e or cap + e); the OTHER one receives the next
+                     // episode's field ahead of time (ipp_generate_grf_groups with gt_out == NULL) and a folded reset only flips the slot
+    int* gt_slot;    // [cap]
     double* prior;   // [cap][2]  (sigma^2, l)
     int* rank;       // [cap]
     int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
@@ -175,11 +177,15 @@ struct View {
     float* grf_raw2; // [max_batch][Npad] un-normalised field (ipp_generate_grf, may run on a side stream)
 };
 
+// The plane that holds env's ground truth / the one that is staged for its next episode.
+__device__ __forceinline__ float* gt_plane(const View& v, int env) { return v.gt + (size_t)v.gt_slot[env] * v.Npad; }
+__device__ __forceinline__ int gt_alt_slot(const View& v, int env) { const int s = v.gt_slot[env]; return s >= v.cap ? s - v.cap : s + v.cap; }
+
 // Episode reset folded into a step launch (ipp_step_autoreset): item i resets its env after its step when
 // src[i] >= 0, taking ground truth gt[src[i]] ([N] floats).  Mission.init_action by value.
 struct AutoReset {
     const int* src;     // [n] or NULL (no resets in this launch)
-    const float* gt;    // [..][N]
+    const float* gt;    // [..][N], or NULL: the new ground truth already sits in the env's alternate plane -- the reset flips gt_slot
     const double* prior; // [..][2] prior (sigma^2, l) of the new episode that takes ground truth k, or NULL: the config's (ipp_set_reset_prior)
     double* prev;       // [capacity][3] indexed by env id, or NULL
     double init[3];
@@ -197,7 +203,32 @@ __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& a
     const float m0 = isnan(sv_d) ? NAN : 0.5f;
     float* mean = v.mean + (size_t)env * v.Npad;
     float* diag = v.diag + (size_t)env * v.Npad;
-    float* gt = v.gt + (size_t)env * v.Npad;
+    if (!ar.gt) {
+        // the ground truth of the new episode was generated into the env's alternate plane: no 2 x 4 N bytes of copy (at 100x100 and
+        // 2048 resets per step the copies were 164 MB of a step's traffic) -- mean and variance planes, then the flip
+        const int alt = gt_alt_slot(v, env);
+        float4* mean4 = reinterpret_cast<float4*>(mean);
+        float4* diag4 = reinterpret_cast<float4*>(diag);
+        const int n4 = v.N / 4, np4 = v.Npad / 4;
+        if ((v.N & 3) == 0) {
+            for (int c = lane; c < np4; c += kWave) {
+                const bool valid = c < n4;
+                mean4[c] = valid ? make_float4(m0, m0, m0, m0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                diag4[c] = valid ? make_float4(sv, sv, sv, sv) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (int c = lane; c < v.Npad; c += kWave) { mean[c] = c < v.N ? m0 : 0.f; diag[c] = c < v.N ? sv : 0.f; }
+        }
+        if (lane == 0) {
+            v.gt_slot[env] = alt;
+            v.rank[env] = 0;
+            v.prior[2 * env + 0] = sv_d;
+            v.prior[2 * env + 1] = ls_d;
+        }
+        if (ar.prev && lane < 3) ar.prev[3 * env + lane] = ar.init[lane];
+        return;
+    }
+    float* gt = gt_plane(v, env);
     const float* src = ar.gt + (size_t)k * v.N;
     if ((v.N & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15ull) == 0ull) {
         // four cells per lane and instruction, the ground-truth loads of a pass all in flight before the first store: written one

@@ -124,7 +124,7 @@ struct Layout {
     bool patch;
     int patch_waves;
     PatchGeo pg;
-    uint64_t off_mean, off_diag, off_gt, off_prior, off_rank, off_span, off_cnt, off_icnt, off_cov, off_blk, off_hdr, off_linv, off_yv, off_q, off_wc,
+    uint64_t off_mean, off_diag, off_gt, off_gtslot, off_prior, off_rank, off_span, off_cnt, off_icnt, off_cov, off_blk, off_hdr, off_linv, off_yv, off_q, off_wc,
         off_partial, off_dbg, off_grfh, off_grfcs, off_grfg, off_grfhp, off_grfamp, off_grfraw, off_grfraw2, off_sc_hdr, off_sc_ext, off_sc_mask, off_sc_G, off_sc_P, off_tr_cov, off_tr_diag, off_tr_meta, off_sc_ndiag, total, cov_slot_floats;
 };
 
@@ -265,7 +265,8 @@ int plan(const ipp_config& c, Layout& L, bool allow_patch = true) {
     const uint64_t cap = c.capacity, mb = c.max_batch, np = L.Npad;
     L.off_mean = o; o += up(cap * np * 4);
     L.off_diag = o; o += up(cap * np * 4);
-    L.off_gt = o; o += up(cap * np * 4);
+    L.off_gt = o; o += up(2 * cap * np * 4);  // two ground-truth planes per env: the current one and the one staged for its next episode
+    L.off_gtslot = o; o += up(cap * 4);
     L.off_prior = o; o += up(cap * 2 * 8);
     L.off_rank = o; o += up(cap * 4);
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(2 * cap * (uint64_t)c.rank_cap * 4) : 0;  // tile spans, then rectangles
@@ -648,7 +649,7 @@ int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* 
                const GrfNoise* noise = nullptr) {
     const View& v = e->v;
     if (!white && !(noise && e->grf_tt > 0 && e->grf_fft)) return fail(-1, "in-kernel ground-truth noise needs the fast Hartley path (50x50 / 100x100 grids)");
-    const GrfNoise gn = noise ? *noise : GrfNoise{nullptr, 0, 0, 0, 0, {0}};
+    const GrfNoise gn = noise ? *noise : GrfNoise{nullptr, 0, 0, 0, 0, {0}, 0};
     if (v.W != v.H) return fail(-1, "device GRF needs a square grid (the reference transposes its dims, simulations/simulations.py:45-47)");
     if (e->grf_tt > 0 && e->grf_fft) {  // n = 50 / 100: fast Hartley transforms in LDS (k_grf_fft.h), same amplitude table
         const int np = 16 * e->grf_tt;
@@ -768,6 +769,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     v.mean = reinterpret_cast<float*>(base + L.off_mean);
     v.diag = reinterpret_cast<float*>(base + L.off_diag);
     v.gt = reinterpret_cast<float*>(base + L.off_gt);
+    v.gt_slot = reinterpret_cast<int*>(base + L.off_gtslot);
     v.prior = reinterpret_cast<double*>(base + L.off_prior);
     v.rank = reinterpret_cast<int*>(base + L.off_rank);
     v.colspan = reinterpret_cast<int*>(base + L.off_span);
@@ -986,6 +988,9 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipGetLastError();
     // state starts zeroed (rank 0, padding 0); envs must still be ipp_reset before use
     HIP_TRY(hipMemset(base, 0, L.off_cov));
+    hipLaunchKernelGGL(k_init_gt_slots, dim3((cfg->capacity + 255) / 256), dim3(256), 0, nullptr, v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(base + L.off_hdr, 0, L.total - L.off_hdr));
     if (cfg->x_dim == cfg->y_dim) {
         std::vector<double> h;
@@ -1172,7 +1177,7 @@ int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const do
     if (!e) return fail(-1, "null engine");
     if (e->v.mode != IPP_FACTOR) return fail(-1, "ipp_step_autoreset: factor state only (dense engines: ipp_step + ipp_reset_episode)");
     if (flags & IPP_PREDICT_ONLY) return fail(-1, "ipp_step_autoreset: not with IPP_PREDICT_ONLY");
-    if (reset_src && (!reset_gt || !init_action)) return fail(-1, "reset_src needs reset_gt and init_action");
+    if (reset_src && !init_action) return fail(-1, "reset_src needs init_action");  // (reset_gt == NULL: the ground truths were staged into the alternate planes)
     AutoReset ar = {reset_src, reset_gt, reset_src ? e->reset_prior : nullptr, reset_src ? prev_action : nullptr, {0.0, 0.0, 0.0}};
     if (init_action) for (int k = 0; k < 3; ++k) ar.init[k] = init_action[k];
     return step_impl(engine, env_ids, nullptr, n, action, prev_action, meas_noise, flags, reward, status, stream, ar);
@@ -1195,7 +1200,7 @@ int ipp_step_parts(void* engine, int32_t n, const double* action, double* prev_a
     if (part_begin[0] != 0 || part_begin[n_parts] != n) return fail(-1, "part_begin has to run from 0 to n");
     for (int p = 0; p < n_parts; ++p)
         if (part_begin[p + 1] <= part_begin[p]) return fail(-1, "part %d is empty", p);
-    if (reset_src && (!reset_gt || !init_action)) return fail(-1, "reset_src needs reset_gt and init_action");
+    if (reset_src && !init_action) return fail(-1, "reset_src needs init_action");
     AutoReset ar = {reset_src, reset_gt, reset_src ? e->reset_prior : nullptr, reset_src ? prev_action : nullptr, {0.0, 0.0, 0.0}};
     if (init_action) for (int k = 0; k < 3; ++k) ar.init[k] = init_action[k];
     HIP_TRY(hipSetDevice(e->device));
@@ -1229,14 +1234,15 @@ int ipp_generate_grf_rows(void* engine, int32_t n, const int32_t* row_ids, int64
 int ipp_generate_grf_groups(void* engine, int32_t n, int32_t group_rows, const int64_t* group_subsequence, const int32_t* row_ids,
                             int64_t row_offset, uint64_t seed, uint64_t subsequence, float* gt_out, void* stream) {
     Engine* e = as_engine(engine);
-    if (!e || !gt_out) return fail(-1, "null argument");
+    if (!e) return fail(-1, "null engine");
+    if (!gt_out && !row_ids) return fail(-1, "ipp_generate_grf_groups: gt_out == NULL writes the alternate plane of env row_ids[i]: row_ids needed");
     if (n < 0 || n > e->v.max_batch) return fail(-1, "n = %d outside [0, max_batch = %d]", n, e->v.max_batch);
     if (n == 0) return 0;
     if (group_rows < 0 || (group_rows > 0 && (!group_subsequence || (n + group_rows - 1) / group_rows > 16)))
         return fail(-1, "ipp_generate_grf_groups: at most 16 groups of group_rows fields, with their subsequence offsets");
     if (!(e->grf_tt > 0 && e->grf_fft)) return fail(-3, "ipp_generate_grf_rows: this grid has no generator that draws its own noise (ipp_fill_normal_rows + ipp_generate_grf)");
     HIP_TRY(hipSetDevice(e->device));
-    GrfNoise gn = {row_ids, (long long)row_offset, seed, subsequence, group_rows, {0}};
+    GrfNoise gn = {row_ids, (long long)row_offset, seed, subsequence, group_rows, {0}, gt_out ? 0 : 1};
     for (int g = 0; group_rows > 0 && g < (n + group_rows - 1) / group_rows; ++g) gn.group_subseq[g] = (long long)group_subsequence[g];
     return launch_grf(e, n, nullptr, e->v.grf_raw2, nullptr, gt_out, reinterpret_cast<hipStream_t>(stream), &gn);
 }
@@ -1566,7 +1572,15 @@ static int read_row(Engine* e, const float* slab, int env, float* out, void* str
 }
 int ipp_read_mean(void* engine, int32_t env_id, float* out, void* stream) { Engine* e = as_engine(engine); return read_row(e, e ? e->v.mean : nullptr, env_id, out, stream); }
 int ipp_read_diag(void* engine, int32_t env_id, float* out, void* stream) { Engine* e = as_engine(engine); return read_row(e, e ? e->v.diag : nullptr, env_id, out, stream); }
-int ipp_read_gt(void* engine, int32_t env_id, float* out, void* stream) { Engine* e = as_engine(engine); return read_row(e, e ? e->v.gt : nullptr, env_id, out, stream); }
+static int copy_gt(Engine* e, int env, float* out, const float* in, void* stream) {
+    if (!e || (!out && !in)) return fail(-1, "null argument");
+    if (int rc = check_env(e, env)) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_copy_gt, dim3((e->v.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->v, env, out, in);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ipp_read_gt(void* engine, int32_t env_id, float* out, void* stream) { return copy_gt(as_engine(engine), env_id, out, nullptr, stream); }
 
 int ipp_read_cov_dense(void* engine, int32_t env_id, float* out, void* stream) {
     Engine* e = as_engine(engine);
@@ -1614,7 +1628,7 @@ static int write_row(Engine* e, float* slab, int env, const float* in, void* str
     return 0;
 }
 int ipp_write_mean(void* engine, int32_t env_id, const float* mean, void* stream) { Engine* e = as_engine(engine); return write_row(e, e ? e->v.mean : nullptr, env_id, mean, stream); }
-int ipp_write_gt(void* engine, int32_t env_id, const float* gt, void* stream) { Engine* e = as_engine(engine); return write_row(e, e ? e->v.gt : nullptr, env_id, gt, stream); }
+int ipp_write_gt(void* engine, int32_t env_id, const float* gt, void* stream) { return copy_gt(as_engine(engine), env_id, nullptr, gt, stream); }
 
 int ipp_write_cov_dense(void* engine, int32_t env_id, const float* P, void* stream) {
     Engine* e = as_engine(engine);

@@ -315,8 +315,8 @@ __global__ __launch_bounds__(kMaxTileThreads, IPP_MINWAVES) void k_gain(View v, 
     }
     if (h.dst != h.env) {
         float g[VEC];
-        load_vec<VEC>(v.gt + (size_t)h.env * v.Npad + cell0, g);
-        store_vec<VEC>(v.gt + (size_t)h.dst * v.Npad + cell0, g);
+        load_vec<VEC>(gt_plane(v, h.env) + cell0, g);
+        store_vec<VEC>(gt_plane(v, h.dst) + cell0, g);
         if (tile == 0 && tid == 0) {
             v.prior[2 * h.dst + 0] = v.prior[2 * h.env + 0];
             v.prior[2 * h.dst + 1] = v.prior[2 * h.env + 1];

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NT) void k_grf_dft(View v, const int* __restrict__ 
     for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[NW + w]); }
     const double span = dhi - dlo;
     typedef float outv __attribute__((ext_vector_type(XB3)));
-    float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
+    float* gt = gt_out ? gt_out + (size_t)item * N : gt_plane(v, env);
     if (own) {
 #pragma unroll
         for (int j = 0; j < OPT; ++j) {

@@ -137,6 +137,7 @@ struct GrfNoise {
     // subseq + group_subseq[group] (by value: no upload in front of the launch); group_rows == 0: one group.  A NEGATIVE row id skips the field.
     int group_rows;
     long long group_subseq[16];
+    int to_alt;  // gt_out == NULL: field i goes to the ALTERNATE ground-truth plane of env row_ids[i] (staged for its next episode; the reset flips)
 };
 
 // One workgroup per field.  white [n_items][N] float standard normals (or nullptr: GrfNoise); amp [n][amp_ld] doubles (the table of
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
     const int item = blockIdx.x;
     if (item >= n_items) return;
     if (!white && gn.row_ids && gn.row_ids[item] < 0) return;  // (padding row of a staged block)
-    const int env = gt_out ? 0 : (env_ids ? env_ids[item] : item);
+    const int env = gt_out ? 0 : (gn.to_alt ? gn.row_ids[item] : (env_ids ? env_ids[item] : item));
     if (env < 0 || env >= v.cap) return;
     T* X = reinterpret_cast<T*>(smem_gf);
     // min / max per wave: behind the array (n = 50) or, at n = 100 where the array fills the workgroup's 80 KB, in its first row once the
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
 #pragma unroll
     for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, (double)red[w]); dhi = fmax(dhi, (double)red[16 + w]); }
     const double span = dhi - dlo;
-    float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
+    float* gt = gt_out ? gt_out + (size_t)item * N : (gn.to_alt ? v.gt + (size_t)gt_alt_slot(v, env) * v.Npad : gt_plane(v, env));
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int i = tid + q * NT;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
 #pragma unroll
     for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, red[w]); dhi = fmax(dhi, red[8 + w]); }
     const double span = dhi - dlo;
-    float* gt = gt_out ? gt_out + (size_t)item * N : v.gt + (size_t)env * v.Npad;
+    float* gt = gt_out ? gt_out + (size_t)item * N : gt_plane(v, env);
 #pragma unroll
     for (int o = 0; o < OW; ++o) {
         if (wave + NW * o >= TT) break;

@@ -31,7 +31,7 @@ __global__ void k_reset_small(View v, const int* __restrict__ env_ids, int n_ite
     const bool valid = cell < v.N;
     v.mean[(size_t)env * v.Npad + cell] = valid ? (isnan(sv) ? NAN : 0.5f) : 0.f;
     v.diag[(size_t)env * v.Npad + cell] = valid ? (float)sv : 0.f;
-    if (gt_in) v.gt[(size_t)env * v.Npad + cell] = valid ? gt_in[(size_t)item * v.N + cell] : 0.f;
+    if (gt_in) gt_plane(v, env)[cell] = valid ? gt_in[(size_t)item * v.N + cell] : 0.f;
 }
 
 // ipp_step_autoreset behind the step kernels that do not reset in-kernel: item i resets its env when ar.src[i] >= 0.
@@ -51,12 +51,26 @@ __global__ void k_reset_flagged(View v, const int* __restrict__ env_ids, int n_i
         v.prior[2 * env + 1] = ls;
         if (ar.prev)
             for (int j = 0; j < 3; ++j) ar.prev[3 * env + j] = ar.init[j];
+        if (!ar.gt) v.gt_slot[env] = gt_alt_slot(v, env);  // (the new ground truth was staged into the alternate plane: no other thread reads the slot here)
     }
     if (cell >= v.Npad) return;
     const bool valid = cell < v.N;
     v.mean[(size_t)env * v.Npad + cell] = valid ? (isnan(sv) ? NAN : 0.5f) : 0.f;
     v.diag[(size_t)env * v.Npad + cell] = valid ? (float)sv : 0.f;
-    v.gt[(size_t)env * v.Npad + cell] = valid ? ar.gt[(size_t)k * v.N + cell] : 0.f;
+    if (ar.gt) gt_plane(v, env)[cell] = valid ? ar.gt[(size_t)k * v.N + cell] : 0.f;
+}
+
+// ipp_read_gt / ipp_write_gt: the env's CURRENT ground-truth plane (the slot lives on the device)
+__global__ void k_copy_gt(View v, int env, float* __restrict__ out, const float* __restrict__ in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.N) return;
+    if (out) out[i] = gt_plane(v, env)[i];
+    else gt_plane(v, env)[i] = in[i];
+}
+
+__global__ void k_init_gt_slots(View v) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < v.cap) v.gt_slot[e] = e;
 }
 
 // Dense state: P <- Matern prior (mapping/mappings.py:242-261).  Workgroup = kBandRows rows x 1024 columns.
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void k_grf_norm(View v, const int* __restrict_
         for (int i = threadIdx.x; i < v.N; i += blockDim.x) gt[i] = (float)(((double)raw[i] - dlo) / span);
         return;
     }
-    float* gt = v.gt + (size_t)env * v.Npad;
+    float* gt = gt_plane(v, env);
     for (int i = threadIdx.x; i < v.Npad; i += blockDim.x) gt[i] = (i < v.N) ? (float)(((double)raw[i] - dlo) / span) : 0.f;
 }
 
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256) void k_fork(View v, const int* __restrict__ sr
         for (int i = threadIdx.x; i < v.Npad; i += blockDim.x) {
             v.mean[(size_t)d * v.Npad + i] = v.mean[(size_t)s * v.Npad + i];
             v.diag[(size_t)d * v.Npad + i] = v.diag[(size_t)s * v.Npad + i];
-            v.gt[(size_t)d * v.Npad + i] = v.gt[(size_t)s * v.Npad + i];
+            gt_plane(v, d)[i] = gt_plane(v, s)[i];
         }
         if (threadIdx.x == 0) {
             v.prior[2 * d + 0] = v.prior[2 * s + 0];
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(256) void k_metrics(View v, const int* __restrict__
     const int item = blockIdx.x;
     const int env = env_ids ? env_ids[item] : item;
     if (env < 0 || env >= v.cap) return;
-    const float* gt = v.gt + (size_t)env * v.Npad;
+    const float* gt = gt_plane(v, env);
     const float* est = v.mean + (size_t)env * v.Npad;
     const float* dg = v.diag + (size_t)env * v.Npad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -275,7 +275,7 @@ __device__ __forceinline__ ItemHdr* prepare_item_ex(const View& v, const int ite
     }
 
     const float* mean_env = v.mean + (size_t)h.env * v.Npad;
-    const float* gt_env = v.gt + (size_t)h.env * v.Npad;
+    const float* gt_env = gt_plane(v, h.env);
     const float* cov_env = v.cov + (size_t)h.env * v.cov_slot;
     const double R = (double)(h.rf * h.rf * h.rf) * h.nv_d;  // sensor_models.py:36
     const bool cov_only = (flags & IPP_COV_ONLY) != 0;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     if (tid == 0) IPP_MARK(item, 3);
     const bool cov_only = (flags & IPP_COV_ONLY) != 0;
     const float* mean_env = v.mean + (size_t)h.env * v.Npad;
-    const float* gt_env = v.gt + (size_t)h.env * v.Npad;
+    const float* gt_env = gt_plane(v, h.env);
     float* slot = v.cov + (size_t)h.env * v.cov_slot;
     // records that do not fit the LDS staging: the item's global scratch block (split step: the record area of the item's block, which
     // receives EVERY record -- record a at blk_rec + a * 16 -- the first pcap of them are staged in LDS as well, for the m x m algebra)

@@ -321,8 +321,9 @@ class IPPEngine:
                           group_rows: int = 0, group_subsequence=None) -> bool:
         """generate_grf with the white noise drawn inside the generator (the numbers normal_rows(.., n_cells, seed, subsequence, row_ids,
         row_offset) would have written).  group_rows / group_subsequence (host ints, <= 16 groups): fields of several episodes in one
-        launch -- field i draws from subsequence + group_subsequence[i // group_rows]; a negative row id skips its field.  Returns False
-        when this grid has no such generator (caller: normal_rows + generate_grf)."""
+        launch -- field i draws from subsequence + group_subsequence[i // group_rows]; a negative row id skips its field.  out=None:
+        field i goes to the ALTERNATE ground-truth plane of env slot row_ids[i] (staged for its next episode; a folded reset with
+        reset_gt=None flips the env to it).  Returns False when this grid has no such generator (caller: normal_rows + generate_grf)."""
         torch = _torch()
         ids = self._dev(row_ids, torch.int32)
         st = self.stream if stream is None else C.c_void_p(stream.cuda_stream)
@@ -371,9 +372,9 @@ class IPPEngine:
             if not isinstance(prev_actions, torch.Tensor) or p.data_ptr() != prev_actions.data_ptr():
                 raise ValueError("reset_src needs prev_actions as a contiguous float64 device tensor (the reset writes it)")
             src = self._dev(reset_src, torch.int32)
-            g = self._dev(reset_gt, torch.float32)
-            if src.numel() != n or g is None:
-                raise ValueError("reset_src must have one entry per item and needs reset_gt")
+            g = self._dev(reset_gt, torch.float32)  # (None: the fields were staged into the envs' alternate planes -- the reset flips)
+            if src.numel() != n:
+                raise ValueError("reset_src must have one entry per item")
             init = (C.c_double * 3)(*[float(x) for x in init_action])
             _ffi.check(self._lib.ipp_step_autoreset(self._h, self._ptr(ids), n, self._ptr(a), self._ptr(p), self._ptr(nz), flags,
                                                     self._ptr(reward), self._ptr(status), self._ptr(src), self._ptr(g), init,

@@ -145,6 +145,8 @@ class VecIPPEnv:
         if stagger:
             self._side = self._side_pick if self._part_streams is not None else self._pick_streams(dev, 1)[1]
         self._grf_rows = None if os.environ.get("IPP_GRF_ROWS", "1") != "0" else False  # (False: the engine has no in-generator noise / A/B)
+        self._gt_flip_ok = os.environ.get("IPP_GT_FLIP", "1") != "0"  # (A/B: 0 = staged buffers + copies at the resets)
+        self.alt_blocks = 0
         # Staging in BLOCKS of K steps: the fields of all resets of block b + 1 are generated while block b runs, into one of
         # two buffer sets, and the streams meet ONCE per block (main waits for the block's `ready` event before its first step
         # and records `free` behind its last; the side stream waits for `free` before it refills the set).  With an event
@@ -169,6 +171,7 @@ class VecIPPEnv:
                     ev.record(torch.cuda.current_stream(dev))
             self._blk_tag = [-1, -1]   # block index staged in each buffer set
             self._blk_prog = [(-1, 0), (-1, 0)]  # (block, fields staged so far) of a block that is being staged field by field
+            self._blk_alt = [False, False]       # the set's block went straight into the envs' ALTERNATE ground-truth planes (resets flip)
             self._blk_waited = -1      # block whose `ready` event the main stream has waited for
         # measurement noise for NOISE_RING steps per generator launch
         self._noise_ring = torch.empty((self.NOISE_RING, B, self.engine.meas_cap), dtype=torch.float32, device=dev)
@@ -286,6 +289,8 @@ class VecIPPEnv:
         if j0 == 0:
             for ev in self._blk_free[set_]:
                 self._side.wait_event(ev)
+        if j0 == 0:
+            self._blk_alt[set_] = False
         if j0 == 0 and self._grf_rows is not False and self._stage_block_once(b):
             upto = K  # (the whole block went out as ONE generator launch)
             j0 = K
@@ -339,12 +344,17 @@ class VecIPPEnv:
             if len(e_p) and not np.all(e_p == e_p[0]):
                 return False
             epi.append(int(e_p[0]) if len(e_p) else 0)
-        ok = self.engine.generate_grf_rows(K * nm, self.seed, self.GT_STREAM, self._staged_sets[set_], row_ids=ids,
+        # where the resets are folded into the step launches the fields go straight into the envs' alternate planes and a reset is a
+        # flip (no copy of H W floats in and out per reset); else into the set's buffer, which the separate reset launch copies
+        alt = bool(self._fused_reset) and self._gt_flip_ok
+        ok = self.engine.generate_grf_rows(K * nm, self.seed, self.GT_STREAM, None if alt else self._staged_sets[set_], row_ids=ids,
                                            row_offset=self.env_id_offset, stream=self._side, group_rows=nm, group_subsequence=epi)
         if not ok:
             self._grf_rows = False
             return False
         self._grf_rows = True
+        self._blk_alt[set_] = alt
+        self.alt_blocks += int(alt)  # (blocks of ground truths generated straight into the alternate planes: tests, reports)
         return True
 
     def _prefetch_next_block(self, b: int, j: int):
@@ -367,6 +377,7 @@ class VecIPPEnv:
         for set_ in range(2):
             self._blk_tag[set_] = -1
             self._blk_prog[set_] = (-1, 0)
+            self._blk_alt[set_] = False
             for ev in self._blk_free[set_]:
                 ev.record(main)  # (everything that read the set is in front of this point of the stream)
         self._blk_waited = -1
@@ -458,7 +469,7 @@ class VecIPPEnv:
         fused = None
         if self._fused_reset and env_ids is None and scheduled is not None:
             p, k, n = scheduled
-            fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
+            fused = dict(reset_src=self._reset_src(p), reset_gt=None if self._blk_alt[k // self._blk_K] else self._staged[k][:n], init_action=INIT_ACTION)
             if self.shuffle_prior_cov:  # priors of the episodes this launch starts, row i for staged field i
                 self.engine.set_reset_prior(self._prior_scale_scheduled(p))
         if self._orders is not None and env_ids is None:
@@ -479,7 +490,8 @@ class VecIPPEnv:
             after_step_hook()
         if scheduled is not None:
             p, k, n = scheduled
-            self.reset(gt=self._staged[k][:n], _phase=p)
+            # (a block that went into the alternate planes has no buffer to copy from: the separate reset draws the same field again)
+            self.reset(gt=None if self._blk_alt[k // self._blk_K] else self._staged[k][:n], _phase=p)
         if prefetch is not None:
             self._prefetch_next_block(*prefetch)
         if blk is not None and blk[1]:
@@ -627,7 +639,7 @@ class VecIPPEnv:
         fused = {}
         if scheduled is not None:
             p, k, n = scheduled
-            fused = dict(reset_src=self._reset_src(p), reset_gt=self._staged[k][:n], init_action=INIT_ACTION)
+            fused = dict(reset_src=self._reset_src(p), reset_gt=None if self._blk_alt[k // self._blk_K] else self._staged[k][:n], init_action=INIT_ACTION)
             if self.shuffle_prior_cov:
                 self.engine.set_reset_prior(self._prior_scale_scheduled(p))
         self.engine.set_item_order(self._orders_parts[self.t % self.episode_steps])

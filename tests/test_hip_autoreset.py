@@ -98,3 +98,46 @@ def test_vec_env_fused_resets_equal_separate_resets(shuffle):
         assert torch.equal(envs[0].mean(e), envs[1].mean(e))
         assert torch.equal(envs[0].diag(e), envs[1].diag(e))
         assert torch.equal(envs[0].ground_truth(e), envs[1].ground_truth(e))
+
+
+@pytest.mark.parametrize("dim,B,T,parts", [(50, 2048, 8, 2), (100, 512, 6, 1)])
+def test_flipped_ground_truth_planes_equal_copied_ones(monkeypatch, dim, B, T, parts):
+    """Resets folded into the step launches take their ground truth from the env's ALTERNATE plane (generated there ahead of time,
+    ipp_generate_grf_groups with gt_out == NULL) and flip to it; with IPP_GT_FLIP=0 the fields go through staged buffers and are
+    copied in at the reset (mapping/mappings.py:217-261, simulations/ground_truths.py:14-33: the same episode either way).
+    Rewards, planes, ground truths and ranks bit for bit over several episodes; hand-made resets and reads in between."""
+    import torch
+    from ipp_rl_amd import EngineConfig
+    from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
+
+    cfg = EngineConfig(x_dim=dim, y_dim=dim)
+    monkeypatch.setenv("IPP_GT_FLIP", "0")
+    copy = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=5, parts=parts)
+    monkeypatch.setenv("IPP_GT_FLIP", "1")
+    flip = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=5, parts=parts)
+    monkeypatch.delenv("IPP_GT_FLIP")
+    assert copy._gt_flip_ok is False and flip._gt_flip_ok is True and bool(flip._fused_reset)
+    for env in (copy, flip):
+        env.reset()
+    alts = [float(a) for a in range(5, 15)]
+    for t in range(4 * T + 3):
+        a = cell_centre_actions(cfg, t, 0, B, B, alts)
+        r1, s1 = copy.step(a)
+        r1 = r1.clone()
+        r2, s2 = flip.step(a)
+        assert torch.equal(r1, r2), t
+        assert int(s2.abs().sum()) == 0
+        if t == 2 * T + 1:  # a hand-made reset of a few envs in between (their staged fields are thrown away and made again)
+            ids = np.array([1, 7, B // 2, B - 1], dtype=np.int32)
+            copy.reset(env_ids=ids)
+            flip.reset(env_ids=ids)
+    assert flip.alt_blocks >= 3 and copy.alt_blocks == 0  # (after the hand-made reset the phases' episode counters differ: per-phase staging again)
+    assert torch.equal(copy.engine.ranks(), flip.engine.ranks()) and np.array_equal(copy.episode, flip.episode)
+    for e in (0, 1, 7, T - 1, T, B // 2, B - 1):
+        assert torch.equal(copy.ground_truth(e), flip.ground_truth(e)), e
+        assert torch.equal(copy.mean(e), flip.mean(e)) and torch.equal(copy.diag(e), flip.diag(e)), e
+    # the flipped envs really changed planes: an env that has been reset an odd number of times reads the upper half
+    slots = flip.engine.arena  # (the slot table lives in the arena; read through the public read-back instead)
+    w = torch.empty((1, cfg.n_cells), dtype=torch.float32, device="cuda")
+    flip.engine.write_gt(3, w.fill_(0.25)[0])
+    assert float(flip.ground_truth(3).min()) == 0.25 and float(flip.ground_truth(3).max()) == 0.25
