@@ -4,10 +4,10 @@
 // of dependent round trips (inputs -> header -> contributing columns -> gather -> m x m algebra) during which its three 80-register
 // waves stream nothing (profiles/r04_experiments.txt 13, 16).  Here the two phases are two launches on the same stream:
 //
-//   P  k_step_patch<1, KP, MINW, SPLIT = true>   ITEM-parallel, one wave per item: the prologue of the fused kernel, word for word (same
-//      template, same device functions: header, compaction, gather, observation, S / Cholesky / L^-1 / y), which leaves the item's BLOCK
-//      in View::blk (SplitBlk, k_step_patch.h): header words, footprint tables, L^-1 | y, the prior table, one 64-byte record per
-//      contributing column.  Latency-bound, a few MB of traffic per launch.
+//   P  k_step_patch<NW, KP, MINW, SPLIT = true>  ITEM-parallel, NW = 1 .. 3 waves per item (default 3: 14 us per item instead of 20-22 with
+//      one): the prologue of the fused kernel, word for word (same template, same device functions: header, compaction, gather,
+//      observation, S / Cholesky / L^-1 / y), which leaves the item's BLOCK in View::blk (SplitBlk, k_step_patch.h): header words,
+//      footprint tables, L^-1 | y, the prior table, one 64-byte record per contributing column.  Latency-bound, ~30 MB per launch.
 //   U  k_step_units                              UNIT-parallel, one wave per (item, unit): grid = 8 ceil(n / 8) x punits workgroups of 64
 //      threads, workgroup b -> dispatch position and unit through the XCD-aware map below (the units of an item sit on consecutive
 //      slots of one XCD, heaviest items first); copies the block's tables to LDS, reads the records' offset / rectangle words into the
@@ -21,6 +21,10 @@
 // arriver reads the reductions with agent-scope loads.  No fence: nothing else travels between the units -- except, for an item
 // whose env is reset by this launch, the units' mean / variance stores, which are then write-through as well so that the reset's
 // plain stores to the same lines are the last word whatever XCDs the units ran on.
+// MEASURED (profiles/r05_experiments.txt 2): U alone streams at 0.40 of 8 TB/s (fused kernel: 0.30 as one launch) with a slot duty of
+// 0.88, but the step loses on every schedule (42.5 against 55.7 M env-steps/s on two groups): P is a 28-38 us latency chain per launch
+// in each group's dependency chain, and it cannot be placed while the other group's U holds every wave slot.  Selected by
+// IPP_SPLIT=<min items> (ipp_info.patch_split_min_items); never by default.
 // mapping/mappings.py:178-197, planning/common/rewards.py:8-31.
 #pragma once
 #include "k_step_patch.h"
@@ -28,7 +32,7 @@
 namespace ipp {
 
 constexpr int kSplitMinWP = 6;  // waves per SIMD the prologue kernel aims at (three waves per item: 8 items per CU, 20 KB of LDS each)
-constexpr int kSplitMinWU = 6;  // ... the unit kernel (80 VGPRs as the fused kernel's unit loop)
+constexpr int kSplitMinWU = 6;  // ... the unit kernel (it needs 64 VGPRs: the hardware then runs 8 waves per SIMD)
 
 // LDS of a unit wave: the block's tables (fb_yx | fb_w | L^-1 | y | prior table, in the block's order) and the list area of the
 // records beyond the register pages.
