@@ -179,5 +179,12 @@ def test_part_and_staging_streams_sit_on_different_hardware_queues():
         a, b, s = env.part_stream(0), env.part_stream(1), env._side
         for x, y in ((a, b), (a, s), (b, s), (a, torch.cuda.current_stream()), (b, torch.cuda.current_stream())):
             assert min(eng.probe_stream_pair(x, y, launches) for _ in range(2)) < shared, "two of the env's streams share a queue"
+        # the placement as plain numbers (bench.py puts them on its line: config.queues_*)
+        rep = env.queue_report
+        assert rep["n_queues"] >= 4 and rep["parts_distinct"] is True and rep["staging_shares_a_part_queue"] is False
+    # one launch per step: the staging stream is only kept off the caller's queue (one probe per candidate, no classification)
+    single = VecIPPEnv(cfg, 64, episode_steps=8, stagger=True, window_rows=-1, seed=5, parts=1)
+    assert single.queue_report is None and single._side is not None
+    assert eng.probe_stream_pair(single._side, torch.cuda.current_stream(), launches) < 0.9 * serial
     with pytest.raises(Exception):
         eng.probe_stream_pair(st, st, 0)
