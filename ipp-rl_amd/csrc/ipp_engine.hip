@@ -85,7 +85,6 @@ struct Engine {
     bool grf_dft = false;  // even square grids up to 256: k_grf_dft instead of k_grf_conv + k_grf_norm
     int grf_tt = 0;        // > 0: even square grids up to 128: k_grf_hartley<grf_tt> (fp64 MFMA GEMMs)
     bool grf_fft = false;  // ... and n = 50 / 100: k_grf_fft (fast Hartley transforms) on the same amplitude table
-    bool grf_fp64 = false; // ... in fp64 (IPP_GRF_FP64=1) instead of fp32
     int grf_kc = 1;        // spectrum rows per LDS chunk
     int lut_cap;
     int lut_rows = 0;  // workgroup-per-item factor kernels: rows |drow| of the prior table kept in LDS
@@ -145,7 +144,6 @@ bool patch_layout(const ipp_config& c, int MC) {
         // tree nodes on patches (k_tree_patch.h): the records address column patches by 32-bit offsets in 8-byte units from
         // View::cov: root slots + node blocks must lie within 32 GB of it
         // (plan() checks the reach of the 32-bit record offsets on the finished layout)
-        if (const char* tp = getenv("IPP_TREE_PATCH")) { if (atoi(tp) == 0) return false; }  // A/B: band-tile tree kernels
     }
     if (c.x_dim % 2 != 0 || c.x_dim > 256 || c.y_dim > 256) return false;
     if (!(c.x_dim > 2 * c.window_rows + 13)) return false;
@@ -155,7 +153,7 @@ bool patch_layout(const ipp_config& c, int MC) {
         const PatchGeo g = patch_geometry(c.x_dim, c.y_dim, c.window_rows);
         if (!patch_units_exact(g.pw, g.ph)) return false;
     }
-    for (const char* name : {"IPP_RECT_META", "IPP_RECT", "IPP_CLIP_COLS", "IPP_FUSED", "IPP_VEC", "IPP_STEP_CHUNKS"})
+    for (const char* name : {"IPP_RECT_META", "IPP_RECT", "IPP_FUSED", "IPP_STEP_CHUNKS"})
         if (getenv(name)) return false;
     if (const char* p = getenv("IPP_PATCH")) return atoi(p) != 0;
     return true;
@@ -200,7 +198,6 @@ int plan(const ipp_config& c, Layout& L, bool allow_patch = true) {
     const bool windowed = c.state_repr == IPP_FACTOR && c.window_rows > 0;
     const long window_cells = std::min<long>(c.y_dim, 2L * c.window_rows + 5) * c.x_dim;
     L.VEC = (L.MC == 9 && !(windowed && window_cells < 16 * 256)) ? 4 : 2;
-    if (const char* ve = getenv("IPP_VEC")) { if (L.MC == 9 && (atoi(ve) == 2 || atoi(ve) == 4)) L.VEC = atoi(ve); }  // A/B experiments
     L.patch = allow_patch && patch_layout(c, L.MC);
     L.patch_waves = patch_waves_wanted();
     if (L.patch) {
@@ -292,7 +289,7 @@ int plan(const ipp_config& c, Layout& L, bool allow_patch = true) {
     }
     {   // un-normalised fields of the convolution path (k_grf_conv + k_grf_norm): even square grids up to 256 run the Hartley /
         // DFT kernels, which normalise in place (2 x 1.3 GB of the configs[2] arena)
-        const bool conv = !(c.x_dim == c.y_dim && c.x_dim % 2 == 0 && c.x_dim >= 4 && c.x_dim <= 256) || getenv("IPP_GRF_CONV") != nullptr;
+        const bool conv = !(c.x_dim == c.y_dim && c.x_dim % 2 == 0 && c.x_dim >= 4 && c.x_dim <= 256);
         L.off_grfraw = o; o += conv ? up(mb * np * 4) : 0;
         L.off_grfraw2 = o; o += conv ? up(mb * np * 4) : 0;
     }
@@ -655,13 +652,8 @@ int launch_grf(Engine* e, int n, const float* white, float* raw, const int32_t* 
         const int np = 16 * e->grf_tt;
         const double* ampt = (const double*)v.grf_amp;
         const double2* twt = (const double2*)v.grf_cs;
-        if (e->grf_fp64) {
-            if (v.W == 100) hipLaunchKernelGGL((k_grf_fft<10, double>), dim3(n), dim3(512), grf_fft_lds_bytes(100, 8), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
-            else hipLaunchKernelGGL((k_grf_fft<5, double>), dim3(n), dim3(256), grf_fft_lds_bytes(50, 8), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
-        } else {
-            if (v.W == 100) hipLaunchKernelGGL((k_grf_fft<10, float>), dim3(n), dim3(512), grf_fft_lds_bytes(100, 4), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
-            else hipLaunchKernelGGL((k_grf_fft<5, float>), dim3(n), dim3(256), grf_fft_lds_bytes(50, 4), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
-        }
+        if (v.W == 100) hipLaunchKernelGGL((k_grf_fft<10, float>), dim3(n), dim3(512), grf_fft_lds_bytes(100, 4), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
+        else hipLaunchKernelGGL((k_grf_fft<5, float>), dim3(n), dim3(256), grf_fft_lds_bytes(50, 4), s, v, env_ids, n, white, ampt, np, gt_out, gn, twt);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -784,7 +776,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     // two-dimensional windows (k_gain_factor.h): every kernel that appends columns of a windowed state clips them (the
     // one-wave-per-item kernel of tile_threads = 64 and the pipelined kernel do not: off for those engines)
     v.clip_cols = (cfg->state_repr == IPP_FACTOR && cfg->window_rows > 0 && L.T != 64 && cfg->x_dim > 2 * cfg->window_rows + 13) ? 1 : 0;
-    if (const char* cl = getenv("IPP_CLIP_COLS")) v.clip_cols = v.clip_cols && atoi(cl) != 0;  // A/B experiments
     // rectangle tiles for committed steps where a rectangle (<= 2 R + 5 + 2 cells of alignment wide) is at most 0.4 grid rows
     // (the rectangle-tile kernels carry no sqrt / exp form of the prior term: the table P0(|drow|, |dcol|) must be complete,
     // i.e. not cut at 48 KiB -- same arithmetic as for lut_rows below)
@@ -816,7 +807,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         // column records in LDS: what fits the share of a workgroup when kPatchWavesPerCu waves of the kernel are resident per CU
         // (the LDS of a workgroup is allocated in granules of 1280 bytes on gfx950: 16 KB would take 13 of the 128)
         int wgs = kPatchWavesPerCu / L.patch_waves;
-        if (const char* wg = getenv("IPP_PATCH_WGS")) { if (atoi(wg) > 0) wgs = atoi(wg); }  // A/B: workgroups per CU to leave room for
         // (at most 13 granules: 170 records are more than the two register pages of the unit loop hold, and the 8 workgroups of the
         // default configuration then leave 30 KB of the CU's LDS to the ground-truth kernel that runs beside the steps)
         const size_t budget = std::min<size_t>((size_t)160 * 1024 / wgs / 1280 * 1280, (size_t)13 * 1280);
@@ -904,7 +894,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                                          GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec));
         }
         if (e->patch) e->gain_lds = PatchLds::bytes(v.pcap, v.plw * v.plw, e->patch_waves, v.punits, v.rank_cap);
-        if (e->patch && e->patch_waves == 2 && !getenv("IPP_PATCH_CAP") && !getenv("IPP_PATCH_WGS")) {
+        if (e->patch && e->patch_waves == 2 && !getenv("IPP_PATCH_CAP")) {
             // second configuration for large launches: LDS share of 12 workgroups per CU (10 granules of 1280 bytes)
             const size_t budget = (size_t)160 * 1024 / 12 / 1280 * 1280;
             const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, 2, v.punits, v.rank_cap);
@@ -937,7 +927,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<9, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_FACTOR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare<25, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    {  // patch kernels: IPP_PATCH_WGS <= 2 asks for more than the default 64 KB of dynamic LDS
+    {  // patch kernels: opt in to more than the default 64 KB of dynamic LDS
         const int pl = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
@@ -971,7 +961,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
     if (e->fused && e->tv.node_cap > 0 && v.meas_cap == 9) {
         // Split tree steps: worth it once the launch fills the device several times over (below that the second launch
         // and the scratch round trip of L^-1 | Q cost more than the occupancy gains); IPP_TREE_SPLIT=<min items> / 0
-        if (const char* tt = getenv("IPP_TREE_T")) e->tree_T = (atoi(tt) == 128) ? 128 : kStepThreads;
         e->tree_gain_lds = (GainLds<9>::bytes(v.rank_cap, 0, e->lut_rows * v.W, 0, e->tree_T / kWave, v.win_tiles, 0, v.rank_cap, v.vec) + 15) & ~(size_t)15;
         e->tree_split_min = 2048;
         if (const char* ts = getenv("IPP_TREE_SPLIT")) e->tree_split_min = atoi(ts);
@@ -998,12 +987,10 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         HIP_TRY(hipMemcpy(v.grf_h, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
         const int n = cfg->x_dim;
         e->grf_dft = (n % 2 == 0) && n >= 4 && n <= 256;  // odd n: the reference's amp is not even (ground_truths.py:8-11)
-        if (const char* gc = getenv("IPP_GRF_CONV")) e->grf_dft = e->grf_dft && atoi(gc) == 0;  // A/B experiments
         if (e->grf_dft && n <= 128) {
             const int tt = (n + 15) / 16;
             std::vector<double> hp, amp;
             bool ok = grf_hartley_tables_host(n, 16 * tt, cfg->cluster_radius, hp, amp);
-            if (const char* gh = getenv("IPP_GRF_HARTLEY")) ok = ok && atoi(gh) != 0;  // A/B experiments
             if (ok) {
                 HIP_TRY(hipMemcpy(v.grf_hp, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
                 HIP_TRY(hipMemcpy(v.grf_amp, amp.data(), amp.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1016,9 +1003,6 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                 if (n == 100) (void)hipFuncSetAttribute((const void*)&k_grf_hartley<7, 8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
                 e->grf_fft = (n == 50 || n == 100);
                 if (const char* gf = getenv("IPP_GRF_FFT")) e->grf_fft = e->grf_fft && atoi(gf) != 0;  // A/B: the GEMM form
-                if (const char* g64 = getenv("IPP_GRF_FP64")) e->grf_fp64 = atoi(g64) != 0;
-                (void)hipFuncSetAttribute((const void*)&k_grf_fft<10, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(100, 8));
-                (void)hipFuncSetAttribute((const void*)&k_grf_fft<5, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)grf_fft_lds_bytes(50, 8));
             }
         }
         if (e->grf_dft) {

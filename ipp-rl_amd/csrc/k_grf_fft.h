@@ -144,7 +144,7 @@ struct GrfNoise {
 // k_grf_hartley.h: zero padded, leading dimension amp_ld); result into the env slots (gt_out == nullptr) or gt_out [n_items][N].
 // T = float (default): the transforms in fp32 -- inputs and output are fp32 anyway and the field is min-max normalised: 6e-7 of the
 // normalised field against numpy's fp64 path (bar 1e-5, tests/test_hip_big_grids.py), half the LDS (four 100x100 fields per CU) and
-// plain-rate arithmetic; T = double (IPP_GRF_FP64=1) keeps the reference's precision end to end.
+// plain-rate arithmetic (T = double -- the reference's precision end to end -- measured no closer to the bar and is not instantiated).
 template <int N1, typename T>
 __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const int* __restrict__ env_ids, int n_items, const float* __restrict__ white,
                                                                   const double* __restrict__ amp, int amp_ld, float* __restrict__ gt_out, GrfNoise gn,
