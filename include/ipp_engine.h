@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 12
+#define IPP_ABI_VERSION 13
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -341,6 +341,13 @@ int ipp_mcts_expand(const ipp_mcts_tables* t, const double* prior, const double*
                     double alpha, double eps, uint64_t seed, void* stream);
 /* Values back along the `wave` recorded descents of every root. */
 int ipp_mcts_backup(const ipp_mcts_tables* t, int32_t wave, void* stream);
+/* The search policies of all roots from their visit counts (get_policy's read-out, planning/mcts_zero/mcts.py:83-143, for
+ * temperature > 0): deploy_time = 0 takes the forced playouts back (:109-131; tie_uniform [dev] R numbers in [0, 1) pick the kept
+ * action among the most visited ones like the reference's rng.choice, NULL = the first), then visits^(1/temperature) normalised.
+ * policy [dev] R x kmax float64 on the roots' valid sets (0 on the padding), valid_idx [dev] R x kmax int32 = those sets (-1 padded;
+ * may be NULL), ok [dev] R = 0 where the reference returns None (root not expanded / no visits kept). */
+int ipp_mcts_policy(const ipp_mcts_tables* t, const double* tie_uniform, double temperature, int32_t deploy_time, double* policy,
+                    int32_t* valid_idx, int32_t* ok, void* stream);
 
 /*
  * NN input state plane of one env slot: the N x N covariance with the rows / columns outside the adaptive mask

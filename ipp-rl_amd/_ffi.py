@@ -14,7 +14,7 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class IppConfig(C.Structure):
@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ipp_mcts_level_steps": (C.c_int, [_P, C.POINTER(IppMctsTables), C.c_int32, C.c_int32, C.c_uint32, _P]),
     "ipp_mcts_expand": (C.c_int, [C.POINTER(IppMctsTables), _P, _P, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint64, _P]),
     "ipp_mcts_backup": (C.c_int, [C.POINTER(IppMctsTables), C.c_int32, _P]),
+    "ipp_mcts_policy": (C.c_int, [C.POINTER(IppMctsTables), _P, C.c_double, C.c_int32, _P, _P, _P, _P]),
     "ipp_tree_score_actions": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, C.c_uint32, _P, _P, _P]),
     "ipp_generate_grf": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "ipp_generate_grf_rows": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),

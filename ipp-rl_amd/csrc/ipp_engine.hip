@@ -1464,6 +1464,18 @@ int ipp_mcts_backup(const ipp_mcts_tables* t, int32_t wave, void* stream) {
     return 0;
 }
 
+int ipp_mcts_policy(const ipp_mcts_tables* t, const double* tie_uniform, double temperature, int32_t deploy_time, double* policy,
+                    int32_t* valid_idx, int32_t* ok, void* stream) {
+    if (int rc = mcts_check(t)) return rc;
+    if (!policy || !ok) return fail(-1, "null argument");
+    if (!(temperature > 0)) return fail(-1, "temperature = %g: the read-out on the device is the one for temperature > 0 (mcts.py:133-143)", temperature);
+    HIP_TRY(hipSetDevice(t->device));
+    hipLaunchKernelGGL(k_mcts_policy, dim3((t->roots * kWave + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *t, tie_uniform,
+                       1.0 / temperature, (int)(deploy_time != 0), policy, valid_idx, ok);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ipp_tree_read_diag(void* engine, int32_t node_id, float* out, void* stream) {
     Engine* e = as_engine(engine);
     if (!e || !out) return fail(-1, "null argument");

@@ -481,4 +481,110 @@ __global__ void k_mcts_backup(ipp_mcts_tables m, int W) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- policy read-out
+// One wave per root: the search policy from the root's visit counts (mcts.py:83-143 for temperature > 0).  Training time
+// (deploy_time == 0): forced playouts taken back (:109-131) -- among the most visited actions one is kept (tie_u[j] picks it
+// like rng.choice picks among the ties; NULL: the first), every other action gives back one forced playout at a time while its
+// PUCT score with the reduced count stays below the kept action's, and single remaining visits are dropped; then
+// visits^(1/T) / sum.  Same arithmetic and operand order as the NumPy read-out (device_mcts.py::_policies_rows); every action's
+// take-back loop is independent of the others', so the lanes run theirs side by side.
+// policy [R][kmax] (0 on the padding), idx_out [R][kmax] = the root's valid action indices (optional), ok [R] = 1 where the root
+// was expanded and kept visits (the reference returns None otherwise).
+__global__ __launch_bounds__(256) void k_mcts_policy(ipp_mcts_tables m, const double* __restrict__ tie_u, double inv_temperature, int deploy_time,
+                                                     double* __restrict__ policy, int32_t* __restrict__ idx_out, int32_t* __restrict__ ok) {
+#pragma clang fp contract(off)
+    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (j >= m.roots) return;
+    const int node = j * m.nodes_per_root, kmax = m.kmax;
+    const size_t row = (size_t)node * kmax;
+    double* pj = policy + (size_t)j * kmax;
+    const int K = m.n_k[node];
+    const double ns = m.n_ns[node];
+    const bool ok_root = (m.n_flags[node] & kNodeExpanded) && K > 0;
+    if (idx_out)
+        for (int k = lane; k < kmax; k += 64) idx_out[(size_t)j * kmax + k] = m.t_idx[row + k];
+    if (!ok_root) {
+        for (int k = lane; k < kmax; k += 64) pj[k] = 0.0;
+        if (lane == 0) ok[j] = 0;
+        return;
+    }
+    auto visits_of = [&](int k) { return (m.t_idx[row + k] >= 0) ? m.t_nsa[row + k] : 0.0; };
+    double max_puct = -INFINITY, lo = INFINITY, hi = -INFINITY, pc = 0.0;
+    const double sq = sqrt(ns + 1);
+    bool allzero = true;
+    int best = -1;
+    if (!deploy_time) {
+        double vmax = -INFINITY;
+        int nz = 0;
+        for (int k = lane; k < kmax; k += 64) {
+            vmax = fmax(vmax, visits_of(k));
+            if (m.t_idx[row + k] >= 0) {
+                const double q = m.t_qsa[row + k];
+                lo = fmin(lo, q); hi = fmax(hi, q); nz |= (q != 0.0) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            vmax = fmax(vmax, mc_shfl_xor(vmax, o));
+            lo = fmin(lo, mc_shfl_xor(lo, o));
+            hi = fmax(hi, mc_shfl_xor(hi, o));
+            nz |= __shfl_xor(nz, o, 64);
+        }
+        if (K < m.num_actions) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); }  // (mcts.py:267-278, as in k_mcts_select)
+        allzero = nz == 0;
+        pc = m.puct_init + log((ns + m.puct_base + 1) / m.puct_base);
+        // the kept action: the pick-th (ascending action order) of the most visited
+        int n_ties = 0;
+        for (int k0 = 0; k0 < kmax; k0 += 64) {
+            const int k = k0 + lane;
+            n_ties += __popcll(__ballot(k < kmax && k < K && visits_of(k) == vmax));
+        }
+        if (n_ties > 0 && (vmax > 0 || m.num_actions == K)) {
+            long long pick = tie_u ? (long long)(tie_u[j] * (double)n_ties) : 0;
+            pick = pick < n_ties - 1 ? pick : n_ties - 1;
+            int seen = 0;
+            for (int k0 = 0; k0 < kmax && best < 0; k0 += 64) {
+                const int k = k0 + lane;
+                unsigned long long b = __ballot(k < kmax && k < K && visits_of(k) == vmax);
+                const int c = __popcll(b);
+                if (pick < seen + c) {
+                    for (int r = (int)pick - seen; r > 0; --r) b &= b - 1;  // drop the r lowest ties
+                    best = k0 + (int)__ffsll((long long)b) - 1;
+                }
+                seen += c;
+            }
+            const double q = m.t_qsa[row + best], nsa = m.t_nsa[row + best], ps = m.t_ps[row + best];
+            const double qn = allzero ? q : ((lo == hi) ? q / hi : (q - lo) / (hi - lo));
+            max_puct = (m.t_idx[row + best] >= 0) ? qn + pc * (ps * (sq / (1 + nsa))) : -INFINITY;
+        }
+    }
+    double sum_vt = 0.0, tot = 0.0;
+    for (int k = lane; k < kmax; k += 64) {
+        const bool valid = m.t_idx[row + k] >= 0;
+        double visits = valid ? m.t_nsa[row + k] : 0.0;
+        if (!deploy_time) {
+            if (valid && k != best) {
+                const double ps = m.t_ps[row + k], q = m.t_qsa[row + k];
+                double left = (visits == 0) ? 0.0 : ceil(sqrt(m.fpf * ps * ns));
+                const double qn = allzero ? q : ((lo == hi) ? q / hi : (q - lo) / (hi - lo));
+                while (left > 0) {
+                    const double prior = pc * (ps * (sq / (1 + (visits - 1))));
+                    if (qn + prior >= max_puct) break;  // (the playout is not taken back: the action leaves the loop)
+                    visits -= 1;
+                    left -= 1;
+                }
+            }
+            if (visits == 1) visits = 0;
+        }
+        const double vt = (inv_temperature == 1.0) ? visits : pow(visits, inv_temperature);
+        pj[k] = vt;
+        sum_vt += vt;
+        tot += visits;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum_vt += mc_shfl_xor(sum_vt, o); tot += mc_shfl_xor(tot, o); }
+    for (int k = lane; k < kmax; k += 64) pj[k] = (tot > 0) ? pj[k] / sum_vt : 0.0;  // (each lane re-reads what it wrote)
+    if (lane == 0) ok[j] = tot > 0 ? 1 : 0;
+}
+
 }  // namespace ipp

@@ -122,12 +122,22 @@ class DeviceMCTS(VectorMCTS):
         tab.pend_count = b["counts"].data_ptr()
         tab.rq_count = b["counts"].data_ptr() + 4 * R
         self._tab, self._buf, self._tab_roots, self._tab_depth = tab, b, R, D
+        # read-out (ipp_mcts_policy): results on the device and their pinned host copies
+        self._out = dict(policy=e((R, K), torch.float64), valid_idx=e((R, K), torch.int32), ok=e((R,), torch.int32), u=e((R,), torch.float64))
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)  # noqa: E731
+        self._out_host = dict(policy=pin((R, K), torch.float64), valid_idx=pin((R, K), torch.int32), ok=pin((R,), torch.int32),
+                              K=pin((R,), torch.int32), nodes=pin((), torch.int64))
         return tab, b
 
     # ------------------------------------------------------------------ search
     def get_policy(self, roots: Sequence[int], previous_actions, budgets, depth: int = 0, temperature: float = 1.0,
-                   deploy_time: bool = False, rngs=None):
-        """Like VectorMCTS.get_policy: one search of num_mcts_simulations per root, policies from the roots' visit counts."""
+                   deploy_time: bool = False, rngs=None, as_arrays: bool = False):
+        """Like VectorMCTS.get_policy: one search of num_mcts_simulations per root, policies from the roots' visit counts.
+
+        The read-out (mcts.py:83-143) runs on the device too (ipp_mcts_policy) when temperature > 0, the action set is a large one and
+        the roots share one generator (rngs=None); the reference's per-root (dict, valid indices) pairs are then built from two
+        arrays.  as_arrays=True skips that: returns {"policy": [R, kmax] float64, "valid_idx": [R, kmax] int32 (-1 padded),
+        "K": [R], "ok": [R] (0 where the reference returns None)} as DEVICE tensors (valid until the next search)."""
         import torch
 
         eng, lib = self.engine, self.engine._lib
@@ -205,7 +215,7 @@ class DeviceMCTS(VectorMCTS):
                                f"raise nodes_per_root / the engine's node_capacity")
         if err[2]:
             raise RuntimeError(f"ipp_tree_step reported status {int(err[2])} (rank_cap / footprint)")
-        return self._policies(b, R, npr, prev0.cpu().numpy(), budget0.cpu().numpy(), temperature, deploy_time, rngs, roots)
+        return self._policies(b, R, npr, prev0, budget0, temperature, deploy_time, rngs, roots, as_arrays)
 
     def _expand(self, lib, tp, b, R, W, root_env, stream):
         import torch
@@ -239,20 +249,21 @@ class DeviceMCTS(VectorMCTS):
                                        seed, stream))
         self._keep_infer = (pr_all, v_all)
 
-    def _policies(self, b, R, npr, prev0, budget0, temperature, deploy_time, rngs, roots):
-        """get_policy (mcts.py:83-143) from the root rows, through VectorMCTS._policy_sparse on a table of the R roots."""
-        import torch
-
-        idx = torch.arange(R, device=b["n_k"].device, dtype=torch.int64) * npr
-        host = lambda t: t[idx].cpu().numpy()  # noqa: E731
-        self.t_idx = host(b["t_idx"]).astype(np.int64)
-        self.t_Ps, self.t_Nsa, self.t_Qsa = host(b["t_ps"]), host(b["t_nsa"]), host(b["t_qsa"])
-        self.n_K = host(b["n_k"]).astype(np.int64)
-        self.n_Ns = host(b["n_ns"])
-        self.n_expanded = (host(b["n_flags"]) & 1).astype(bool)
+    def _policies(self, b, R, npr, prev0, budget0, temperature, deploy_time, rngs, roots, as_arrays=False):
+        """get_policy (mcts.py:83-143) from the root rows: on the device (ipp_mcts_policy), or through VectorMCTS._policy_sparse /
+        _policies_rows on host copies of the R root rows (small action sets, temperature 0, per-root generators)."""
+        self._host_rows = {}  # (the root rows come to the host when somebody asks for them: t_idx, t_Nsa, ... below)
+        self._rows_src = (b, R, npr)
         self.root_ids = np.arange(R)
-        self.stats["nodes"] = int((b["n_flags"] & 1).sum().item())
         self._shared_rng = None
+        on_device = (rngs is None and temperature > 0 and self.num_actions > self.DENSE_ACTIONS
+                     and os.environ.get("IPP_MCTS_HOST_READOUT", "0") != "1")
+        if on_device:
+            return self._policies_device(b, R, npr, temperature, deploy_time, as_arrays)
+        if as_arrays:
+            raise ValueError("as_arrays needs the read-out on the device: temperature > 0, rngs=None and more than DENSE_ACTIONS actions")
+        self.stats["nodes"] = int((b["n_flags"] & 1).sum().item())
+        prev0, budget0 = prev0.cpu().numpy(), budget0.cpu().numpy()
         if rngs is None:  # one generator for the read-out draws of all roots (1024 seeded RandomStates cost 50 ms)
             shared = np.random.RandomState(self.seed & 0x7fffffff)
             rngs = [shared] * R
@@ -262,6 +273,49 @@ class DeviceMCTS(VectorMCTS):
         if self.num_actions <= self.DENSE_ACTIONS or temperature == 0:
             return [self._policy_sparse(j, prev0[j], float(budget0[j]), temperature, deploy_time, rngs[j]) for j in range(R)]
         return self._policies_rows(R, temperature, deploy_time, rngs)
+
+    def _policies_device(self, b, R, npr, temperature, deploy_time, as_arrays):
+        """ipp_mcts_policy on the root rows; the kept action among equally visited ones is picked by the same draw of the shared
+        generator as in _policies_rows (one uniform per root)."""
+        import torch
+
+        eng, o = self.engine, self._out
+        u_ptr = None
+        if not deploy_time:
+            shared = np.random.RandomState(self.seed & 0x7fffffff)
+            self._shared_rng = shared
+            o["u"].copy_(torch.from_numpy(shared.random_sample(R)))
+            u_ptr = o["u"].data_ptr()
+        _ffi.check(eng._lib.ipp_mcts_policy(C.byref(self._tab), u_ptr, float(temperature), int(bool(deploy_time)), o["policy"].data_ptr(),
+                                            o["valid_idx"].data_ptr(), o["ok"].data_ptr(), eng.stream))
+        nodes = (b["n_flags"] & 1).sum()
+        root_nodes = torch.arange(R, device=o["ok"].device, dtype=torch.int64) * npr
+        K_dev = b["n_k"][root_nodes]
+        if as_arrays:
+            self.stats["nodes"] = int(nodes.item())
+            return dict(policy=o["policy"], valid_idx=o["valid_idx"], K=K_dev, ok=o["ok"])
+        h = self._out_host
+        h["policy"].copy_(o["policy"], non_blocking=True)
+        h["valid_idx"].copy_(o["valid_idx"], non_blocking=True)
+        h["ok"].copy_(o["ok"], non_blocking=True)
+        h["K"].copy_(K_dev, non_blocking=True)
+        h["nodes"].copy_(nodes, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.stats["nodes"] = int(h["nodes"].item())
+        p, ok, K = h["policy"].numpy(), h["ok"].numpy(), h["K"].numpy()
+        t_idx = h["valid_idx"].numpy().astype(np.int64)
+        self._host_rows["t_idx"] = t_idx
+        self._host_rows["n_K"] = K.astype(np.int64)
+        out = []
+        for j in range(R):
+            if not ok[j]:
+                out.append(None)
+                continue
+            idx = t_idx[j, :K[j]]
+            pj = p[j, :K[j]]
+            nz = pj > 0
+            out.append((dict(zip(idx[nz].tolist(), pj[nz].tolist())), idx))
+        return out
 
     def _policies_rows(self, R, temperature, deploy_time, rngs):
         """VectorMCTS._policy_sparse for all roots at once (large action sets, temperature > 0): the same arithmetic on
@@ -330,6 +384,34 @@ class DeviceMCTS(VectorMCTS):
             nz = pj > 0
             out.append((dict(zip(idx[nz].tolist(), pj[nz].tolist())), idx))
         return out
+
+    # The root rows on the host (what VectorMCTS keeps as NumPy tables): copied from the device when first asked for after a search.
+    _ROOT_ROWS = {"t_idx": ("t_idx", lambda a: a.astype(np.int64)), "t_Ps": ("t_ps", None), "t_Nsa": ("t_nsa", None), "t_Qsa": ("t_qsa", None),
+                  "n_K": ("n_k", lambda a: a.astype(np.int64)), "n_Ns": ("n_ns", None), "n_expanded": ("n_flags", lambda a: (a & 1).astype(bool))}
+
+    def _root_rows(name):  # noqa: N805 (builds the properties below)
+        def get(self):
+            rows = self.__dict__.setdefault("_host_rows", {})
+            if name not in rows:
+                src = self.__dict__.get("_rows_src")
+                if src is None:
+                    raise AttributeError(f"{name}: no search yet")
+                import torch
+
+                b, R, npr = src
+                key, conv = DeviceMCTS._ROOT_ROWS[name]
+                a = b[key][torch.arange(R, device=b[key].device, dtype=torch.int64) * npr].cpu().numpy()
+                rows[name] = conv(a) if conv else a
+            return rows[name]
+
+        def put(self, value):
+            self.__dict__.setdefault("_host_rows", {})[name] = value
+
+        return property(get, put)
+
+    t_idx, t_Ps, t_Nsa, t_Qsa = _root_rows("t_idx"), _root_rows("t_Ps"), _root_rows("t_Nsa"), _root_rows("t_Qsa")
+    n_K, n_Ns, n_expanded = _root_rows("n_K"), _root_rows("n_Ns"), _root_rows("n_expanded")
+    del _root_rows
 
     def root_statistics(self):
         """(valid action indices, visit counts, Q) of every root after get_policy: arrays [R, kmax], padding idx -1."""

@@ -361,6 +361,46 @@ def test_device_search_policies_of_a_large_action_set():
     assert pruned > 0  # forced playouts were actually taken back somewhere
 
 
+@pytest.mark.parametrize("temperature,deploy_time", [(1.0, False), (0.5, False), (1.0, True)])
+def test_device_read_out_equals_the_host_read_out(monkeypatch, temperature, deploy_time):
+    """ipp_mcts_policy (forced playouts taken back, ties among the most visited actions, temperature) against the NumPy read-out of the
+    same root rows with the same draws (DeviceMCTS._policies_rows, mcts.py:83-143): 50x50 x 2 levels, the shared generator.  The two
+    searches are the same search (deterministic): equal visit counts, then equal policies -- bit for bit at temperature 1 (sums of
+    integers), to 1e-15 otherwise; as_arrays=True returns the same numbers as device tensors."""
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+
+    dim, R, sims, horizon = 50, 48, 96, 4
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.25)
+    roots = list(range(R))
+    make = lambda: DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="random", seed=5, leaf_value=0.3)  # noqa: E731
+    monkeypatch.setenv("IPP_MCTS_HOST_READOUT", "1")
+    a = make()
+    out_a = a.get_policy(roots, prev, [60.0] * R, temperature=temperature, deploy_time=deploy_time)
+    nsa_a = a.t_Nsa.copy()
+    monkeypatch.setenv("IPP_MCTS_HOST_READOUT", "0")
+    b = make()
+    out_b = b.get_policy(roots, prev, [60.0] * R, temperature=temperature, deploy_time=deploy_time)
+    assert np.array_equal(nsa_a, b.t_Nsa)
+    pruned = 0
+    for j in roots:
+        assert (out_a[j] is None) == (out_b[j] is None)
+        (pa, ia), (pb, ib) = out_a[j], out_b[j]
+        assert np.array_equal(ia, ib) and ib.dtype == np.int64 and set(pa) == set(pb)
+        if temperature == 1.0:
+            assert pa == pb
+        else:
+            assert max(abs(pa[k] - pb[k]) for k in pa) < 1e-15
+        assert abs(sum(pb.values()) - 1.0) < 1e-12
+        pruned += int((nsa_a[j, :int(b.n_K[j])] > 0).sum()) - len(pb)
+    assert (pruned > 0) == (not deploy_time)  # forced playouts were taken back somewhere / none at deploy time
+    arr = b.get_policy(roots, prev, [60.0] * R, temperature=temperature, deploy_time=deploy_time, as_arrays=True)
+    pol, vidx, K, ok = (arr[k].cpu().numpy() for k in ("policy", "valid_idx", "K", "ok"))
+    for j in roots:
+        assert ok[j] == 1 and np.array_equal(vidx[j, :K[j]], out_b[j][1]) and np.all(vidx[j, K[j]:] == -1) and np.all(pol[j, K[j]:] == 0)
+        nz = pol[j, :K[j]] > 0
+        assert dict(zip(vidx[j, :K[j]][nz].tolist(), pol[j, :K[j]][nz].tolist())) == out_b[j][0]
+
+
 def test_device_search_without_read_backs_equals_the_synchronised_loop(monkeypatch):
     """Tree nodes as patches (40x40: k_tree_patch) and a stub network: with IPP_MCTS_NOSYNC=1 the driver queues select, every level
     (ipp_mcts_level_steps with n = -1: launches sized for roots x wave items, the kernels read the request counts on the device),
