@@ -325,11 +325,12 @@ typedef struct ipp_mcts_tables {
 } ipp_mcts_tables;
 
 /* W descents per root (virtual visits between them), from waypoint prev0[j] with budget0[j] at tree depth `depth`;
- * sim0 = index of the first of these simulations in the search.  Fills p_*, leaf, pend_*, rq_*. */
+ * sim0 = index of the first of these simulations in the search.  Fills p_*, leaf, pend_*, rq_*, the path arguments ts_paths of the
+ * requested steps and the device paths (n_devpath) of the children that get a device node. */
 int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env /*[dev] R env slots*/, const double* prev0 /*[dev] R x 3*/,
                     const double* budget0 /*[dev] R*/, int32_t depth, int32_t sim0, int32_t wave, uint64_t seed, void* stream);
-/* The n covariance steps requested at `level` (= tree depth - depth of the select call): parents' device paths,
- * ipp_tree_step, edge numerators and the new nodes' device paths.  flags as for ipp_tree_step.
+/* The n covariance steps requested at `level` (= tree depth - depth of the select call): ipp_tree_step on the request list and
+ * the edge numerators t_num = reward (cost + 1).  flags as for ipp_tree_step.
  * n < 0 (engines with ipp_info.patch_layout = 1): the count stays on the device (t->rq_count[level], written by
  * ipp_mcts_select); the launches are sized for roots x wave items, so that the driver queues select, all levels, expand and
  * backup of a wave of simulations without a read-back in between. */
@@ -339,7 +340,8 @@ int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, 
  * Dirichlet(alpha) noise of weight eps on the root of simulation 0. */
 int ipp_mcts_expand(const ipp_mcts_tables* t, const double* prior, const double* value, double value_const, int32_t sets_only,
                     double alpha, double eps, uint64_t seed, void* stream);
-/* Values back along the `wave` recorded descents of every root. */
+/* Values back along the `wave` recorded descents of every root; clears pend_count and rq_count for the next ipp_mcts_select
+ * (the caller clears them once before the first). */
 int ipp_mcts_backup(const ipp_mcts_tables* t, int32_t wave, void* stream);
 /* The search policies of all roots from their visit counts (get_policy's read-out, planning/mcts_zero/mcts.py:83-143, for
  * temperature > 0): deploy_time = 0 takes the forced playouts back (:109-131; tie_uniform [dev] R numbers in [0, 1) pick the kept

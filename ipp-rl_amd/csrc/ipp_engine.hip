@@ -1325,7 +1325,7 @@ static int score_actions_impl(void* engine, int32_t env_id, const ScorePath& pat
 
 static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* path_ids, const int32_t* new_ids, int32_t n,
                           const double* action, const double* prev_action, uint32_t flags, float* reward, int32_t* status,
-                          void* stream, const int32_t* n_dev) {
+                          void* stream, const int32_t* n_dev, const TreeEdgeOut* edge_out = nullptr) {
     Engine* e = as_engine(engine);
     if (!e || !root_ids || !path_ids || !action || !prev_action || !reward) return fail(-1, "null argument");
     if (e->tv.node_cap <= 0) return fail(-1, "ipp_tree_step needs ipp_config.node_capacity > 0");
@@ -1341,12 +1341,13 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
         // (LDS sized for the waves this kernel really has: the step kernel may run 1 wave per item -- IPP_PATCH_WAVES --, the tree kernel 2 to 4)
         const int nw = e->patch_waves >= 2 ? e->patch_waves : 2;
         const size_t tlds = PatchLds::bytes(v.pcap, v.plw * v.plw, nw, v.punits, v.rank_cap);
+        const TreeEdgeOut eo = edge_out ? *edge_out : TreeEdgeOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         if (nw == 3)
-            timed_launch(e, 0, k_tree_patch<3>, dim3(n), dim3(192), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
+            timed_launch(e, 0, k_tree_patch<3>, dim3(n), dim3(192), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);
         else if (nw == 4)
-            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
+            timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);
         else
-            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev);
+            timed_launch(e, 0, k_tree_patch<2>, dim3(n), dim3(128), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1434,11 +1435,12 @@ int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
     const size_t o = (size_t)level * rw;
-    hipLaunchKernelGGL(k_mcts_level_paths, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)level, n_arg);
+    // (the path arguments ts_paths were written by ipp_mcts_select; the patch kernel writes the edge numerators itself)
+    const TreeEdgeOut eo{t->rq_parent + o, t->rq_k + o, t->rq_cost + o, t->t_num, t->err, t->kmax};
     if (int rc = tree_step_impl(engine, t->rq_root + o, t->ts_paths + kMctsPath * o, t->rq_newdev + o, n_grid, t->rq_action + 3 * o, t->rq_prev + 3 * o,
-                                flags, t->ts_reward + o, t->ts_status + o, stream, dev_count ? t->rq_count + level : nullptr))
+                                flags, t->ts_reward + o, t->ts_status + o, stream, dev_count ? t->rq_count + level : nullptr, e->patch ? &eo : nullptr))
         return rc;
-    hipLaunchKernelGGL(k_mcts_apply, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)level, n_arg);
+    if (!e->patch) hipLaunchKernelGGL(k_mcts_apply, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)level, n_arg);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1459,7 +1461,10 @@ int ipp_mcts_backup(const ipp_mcts_tables* t, int32_t wave, void* stream) {
     if (int rc = mcts_check(t)) return rc;
     if (wave <= 0 || wave > t->wave) return fail(-1, "wave = %d outside [1, %d]", wave, t->wave);
     HIP_TRY(hipSetDevice(t->device));
-    hipLaunchKernelGGL(k_mcts_backup, dim3((t->roots + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *t, (int)wave);
+    if (t->wave * t->max_depth <= kWave)  // one wave per root, one lane per recorded step
+        hipLaunchKernelGGL(k_mcts_backup, dim3(t->roots), dim3(kWave), 0, reinterpret_cast<hipStream_t>(stream), *t, (int)wave);
+    else
+        hipLaunchKernelGGL(k_mcts_backup_serial, dim3((std::max(t->roots, t->max_depth) + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *t, (int)wave);
     HIP_TRY(hipGetLastError());
     return 0;
 }

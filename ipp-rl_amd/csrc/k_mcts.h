@@ -11,8 +11,8 @@
 //   k_mcts_select   all roots: W descents each (virtual visits keep them apart), recording paths, pending leaves and,
 //                   per tree level, the covariance steps of edges traversed for the first time (request lists that ARE
 //                   the argument arrays of ipp_tree_step)
-//   per level:      k_mcts_level_paths, ipp_tree_step (k_tree.h), k_mcts_apply (edge numerators, device paths of the
-//                   new nodes)
+//   per level:      ipp_tree_step on the request list (path arguments and the new nodes' device paths were written by the
+//                   selection; k_tree_patch writes the edge numerators itself, band-tile engines through k_mcts_apply)
 //   k_mcts_expand   valid-action sets and priors of the pending leaves (network replies optional)
 //   k_mcts_backup   values back along the recorded paths
 // Arithmetic is fp64 with contraction off and in the operand order of the NumPy driver (vector_mcts.py), which builds the
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             const unsigned char cfl = m.n_flags[child];
             const int cK = m.n_k[child];
             const double cns = m.n_ns[child];
+            const int pv = lane < kMctsPath ? m.n_devpath[(size_t)kMctsPath * cur + lane] : -1;  // (this node's device path: lanes 0..5)
+            int pth[kMctsPath];
+#pragma unroll
+            for (int s = 0; s < kMctsPath; ++s) pth[s] = __shfl(pv, s, 64);
             MC_STAMP(5);
             if (lane == 0) {
                 if (isnan(num)) {  // first traversal of the edge: one device step
@@ -249,6 +253,18 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     m.rq_cost[r] = cost;
                     m.rq_prev[3 * r] = prev[0]; m.rq_prev[3 * r + 1] = prev[1]; m.rq_prev[3 * r + 2] = prev[2];
                     m.rq_action[3 * r] = action[0]; m.rq_action[3 * r + 1] = action[1]; m.rq_action[3 * r + 2] = action[2];
+                    // the step's path argument = this node's device path; a stored child's = that + its new device node (the node was
+                    // expanded in an earlier wave of simulations, so its path is final; nobody reads the child's before the next wave)
+                    int depth = 0;
+#pragma unroll
+                    for (int s = 0; s < kMctsPath; ++s) {
+                        m.ts_paths[kMctsPath * r + s] = pth[s];
+                        depth += pth[s] >= 0 ? 1 : 0;
+                    }
+                    if (newdev >= 0) {
+#pragma unroll
+                        for (int s = 0; s < kMctsPath; ++s) m.n_devpath[(size_t)kMctsPath * child + s] = (s == depth) ? newdev : pth[s];
+                    }
                 }
                 const size_t ps = ((size_t)w * m.roots + j) * m.max_depth + plen;
                 m.p_node[ps] = cur;
@@ -291,40 +307,16 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
 #endif
 }
 
-// Inputs of the level's ipp_tree_step that depend on the previous level's results: the parents' device paths.
-__global__ void k_mcts_level_paths(ipp_mcts_tables m, int level, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < 0) n = m.rq_count[level];  // (the count stays on the device: ipp_mcts_level_steps with n < 0)
-    if (i >= n) return;
-    const size_t r = (size_t)level * m.roots * m.wave + i;
-    const int parent = m.rq_parent[r];
-#pragma unroll
-    for (int s = 0; s < kMctsPath; ++s) m.ts_paths[kMctsPath * r + s] = m.n_devpath[(size_t)kMctsPath * parent + s];
-}
-
-// Results of the level's ipp_tree_step: the edge's masked trace reduction (reward (cost + 1), rewards.py:31 undone: the
-// cost depends on the path that led to the node, the reduction does not) and the device path of a stored child.
+// Results of a level's ipp_tree_step for engines whose tree kernels do not write them themselves (band-tile nodes; k_tree_patch
+// does: TreeEdgeOut): the edge's masked trace reduction (reward (cost + 1), rewards.py:31 undone: the cost depends on the path that
+// led to the node, the reduction does not).
 __global__ void k_mcts_apply(ipp_mcts_tables m, int level, int n) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < 0) n = m.rq_count[level];
     if (i >= n) return;
     const size_t r = (size_t)level * m.roots * m.wave + i;
     if (m.ts_status[r] != 0) m.err[2] = m.ts_status[r];
-    const int parent = m.rq_parent[r], k = m.rq_k[r];
-    m.t_num[(size_t)parent * m.kmax + k] = (double)m.ts_reward[r] * (m.rq_cost[r] + 1.0);
-    const int newdev = m.rq_newdev[r];
-    if (newdev >= 0) {
-        const int c = m.rq_child[r];
-        int depth = 0;
-#pragma unroll
-        for (int s = 0; s < kMctsPath; ++s) {
-            const int p = m.n_devpath[(size_t)kMctsPath * parent + s];
-            m.n_devpath[(size_t)kMctsPath * c + s] = p;
-            depth += p >= 0 ? 1 : 0;
-        }
-        if (depth < kMctsPath) m.n_devpath[(size_t)kMctsPath * c + depth] = newdev;
-    }
+    m.t_num[(size_t)m.rq_parent[r] * m.kmax + m.rq_k[r]] = (double)m.ts_reward[r] * (m.rq_cost[r] + 1.0);
 }
 
 // ---------------------------------------------------------------------------------------------------- expansion
@@ -451,11 +443,20 @@ __global__ __launch_bounds__(256) void k_mcts_expand(ipp_mcts_tables m, const do
 }
 
 // ---------------------------------------------------------------------------------------------------- backup
-// One thread per root: the W recorded descents, deepest step first (mcts.py:255-265; virtual visits taken back first).
-__global__ void k_mcts_backup(ipp_mcts_tables m, int W) {
+// The W recorded descents of a root, deepest step first (mcts.py:255-265; virtual visits taken back first).
+// k_mcts_backup_serial: one thread per root walks them one after the other -- every step a chain of dependent round trips (66 us
+// per wave of 8 simulations at configs[4]).  k_mcts_backup (W x max_depth <= 64): one WAVE per root, one lane per recorded step in
+// processing order (lane = w D + pos, step = plen_w - 1 - pos): every lane loads its step and its edge at once; the values
+// val = reward + gamma value' are a suffix scan along each descent (they do not depend on the tables); the updates of an edge that
+// several descents went through are applied descent by descent on a copy in LDS held at the edge's first lane -- the same operations
+// on the same operands in the same order as the serial walk, so the tables come out bit-identical (tests/test_hip_mcts.py).
+// Both clear the per-wave counters (pending leaves, requests per level) for the next wave of simulations.
+__global__ void k_mcts_backup_serial(ipp_mcts_tables m, int W) {
 #pragma clang fp contract(off)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m.max_depth) m.rq_count[j] = 0;
     if (j >= m.roots) return;
+    m.pend_count[j] = 0;
     const bool virt = W > 1;
     for (int w = 0; w < W; ++w) {
         const int lf = m.leaf[w * m.roots + j];
@@ -479,6 +480,69 @@ __global__ void k_mcts_backup(ipp_mcts_tables m, int W) {
             value = val;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_mcts_backup(ipp_mcts_tables m, int W) {
+#pragma clang fp contract(off)
+    __shared__ double st_nsa[64], st_q[64];
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int D = m.max_depth;
+    if (j == 0 && lane < D) m.rq_count[lane] = 0;
+    if (lane == 0) m.pend_count[j] = 0;
+    const bool virt = W > 1;
+    const int w = lane / D, pos = lane - w * D;
+    const bool in_w = w < W;
+    const int plen = in_w ? m.p_len[w * m.roots + j] : 0;
+    const int lf = in_w ? m.leaf[w * m.roots + j] : -1;
+    const bool valid = pos < plen;
+    const int stp = plen - 1 - pos;
+    int node = -1, k = -1;
+    double cost = 0.0;
+    if (valid) {
+        const size_t ps = ((size_t)w * m.roots + j) * D + stp;
+        node = m.p_node[ps]; k = m.p_k[ps]; cost = m.p_cost[ps];
+    }
+    double carry = lf >= 0 ? m.n_value[lf] : 0.0;  // (the leaf's value, on every lane of the descent)
+    const size_t e = valid ? (size_t)node * m.kmax + k : 0;
+    double nsa0 = 0.0, q0 = 0.0, num = 0.0, nns = 0.0;
+    if (valid) { nsa0 = m.t_nsa[e]; q0 = m.t_qsa[e]; num = m.t_num[e]; if (!virt) nns = m.n_ns[node]; }
+    // ---- values along each descent: position 0 is the deepest step
+    const double reward = num / (cost + 1.0);  // rewards.py:31
+    double val = 0.0;
+    for (int p = 0; p < D; ++p) {
+        if (pos == p) val = reward + m.gamma * carry;
+        const int src = min(w * D + p, 63);
+        const double vp = __shfl(val, src, 64);
+        const int okp = __shfl((int)valid, src, 64);
+        if (okp) carry = vp;
+    }
+    // ---- the first lane (in processing order) that holds the same edge: edges sit at one depth of the tree, so only the lanes of
+    // the same step index in the earlier descents can match
+    int first = lane;
+    for (int wp = 0; wp < W; ++wp) {
+        const int plen_p = __shfl(plen, min(wp * D, 63), 64);
+        const int src = wp * D + (plen_p - 1 - stp);
+        const bool cand = valid && wp < w && stp < plen_p && stp >= 0;
+        const int s2 = cand ? src : lane;
+        const int node_p = __shfl(node, s2, 64), k_p = __shfl(k, s2, 64);
+        if (cand && first == lane && node_p == node && k_p == k) first = src;
+    }
+    st_nsa[lane] = nsa0;
+    st_q[lane] = q0;
+    __syncthreads();
+    // ---- the updates, descent by descent (no two steps of one descent share an edge)
+    for (int wp = 0; wp < W; ++wp) {
+        if (valid && w == wp) {
+            double nsa = st_nsa[first];
+            const double q = st_q[first];
+            if (virt) nsa -= 1;
+            st_q[first] = (nsa > 0) ? (nsa * q + val) / (nsa + 1) : val;
+            st_nsa[first] = nsa + 1;
+        }
+        __syncthreads();
+    }
+    if (valid && first == lane) { m.t_qsa[e] = st_q[lane]; m.t_nsa[e] = st_nsa[lane]; }
+    if (valid && !virt) m.n_ns[node] = nns + 1;  // (W == 1: one descent, every node once; with virtual visits: - 1 + 1, unchanged)
 }
 
 // ---------------------------------------------------------------------------------------------------- policy read-out

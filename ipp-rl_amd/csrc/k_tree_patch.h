@@ -69,11 +69,19 @@ struct TreeIo {
     }
 };
 
+// The search driver's use of an item's reward (ipp_mcts_level_steps): the numerator of the tree edge that asked for the step,
+// t_num[parent][k] = reward (cost + 1) (rewards.py:31 undone: the cost depends on the path that led to the node, the masked trace
+// reduction does not), and a non-zero status into err[2] -- written by the kernel itself instead of by a launch behind it.
+struct TreeEdgeOut {
+    const int* parent; const int* k; const double* cost;  // [n_items] the edge (node, slot) and the cost the reward was divided by
+    double* t_num; int* err; int kmax;                    // t_num == nullptr: off
+};
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
     int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
-    int* __restrict__ status_out, float* __restrict__ reward_out, const int* __restrict__ n_dev) {
+    int* __restrict__ status_out, float* __restrict__ reward_out, const int* __restrict__ n_dev, TreeEdgeOut eo) {
     // n_dev: the item count lives on the device (ipp_mcts_level_steps with n < 0: the search driver queues the levels of a
     // wave of simulations without reading their request counts back); the grid then has n_items >= *n_dev workgroups
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
@@ -161,6 +169,10 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
             v.hdr[item] = h;
             if (status_out) status_out[item] = h.status;
             reward_out[item] = 0.f;
+            if (eo.t_num) {
+                if (h.status != 0) eo.err[2] = h.status;
+                eo.t_num[(size_t)eo.parent[item] * eo.kmax + eo.k[item]] = 0.0;
+            }
         }
         return;
     }
@@ -341,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
                                                nullptr, n_lds, n_ovf > 0 ? ovf : nullptr, n_ovf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(solve_flag, status == IPP_STATUS_NOT_PD ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0 && eo.t_num && status != 0) eo.err[2] = status;
         if (lane == 0) IPP_MARK(item, 7);
     }
     const int n_fast = min(n_lds, 2 * kWave);
@@ -394,7 +407,9 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
         IPP_MARK(item, 2);
         double tot = 0.0;
         for (int t = 0; t < n_units; ++t) tot += lds.unit_red[t];
-        reward_out[item] = dead ? NAN : (float)(tot / (pl.hs->cost_d + 1.0));  // rewards.py:31
+        const float rew = dead ? NAN : (float)(tot / (pl.hs->cost_d + 1.0));  // rewards.py:31
+        reward_out[item] = rew;
+        if (eo.t_num) eo.t_num[(size_t)eo.parent[item] * eo.kmax + eo.k[item]] = (double)rew * (eo.cost[item] + 1.0);
         if (commit_u && !dead) {
             int* meta = tv.node_meta + kNodeMeta * new_id;
             meta[0] = m;

@@ -125,6 +125,7 @@ class DeviceMCTS(VectorMCTS):
         # read-out (ipp_mcts_policy): results on the device and their pinned host copies
         self._out = dict(policy=e((R, K), torch.float64), valid_idx=e((R, K), torch.int32), ok=e((R,), torch.int32), u=e((R,), torch.float64))
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)  # noqa: E731
+        self._counts_host, self._counts_ev = pin((R + D,), torch.int32), torch.cuda.Event()
         self._out_host = dict(policy=pin((R, K), torch.float64), valid_idx=pin((R, K), torch.int32), ok=pin((R,), torch.int32),
                               K=pin((R,), torch.int32), nodes=pin((), torch.int64))
         return tab, b
@@ -163,6 +164,7 @@ class DeviceMCTS(VectorMCTS):
         b["dev_count"].zero_()
         b["h_keys"].zero_()
         b["err"].zero_()
+        b["counts"].zero_()  # (pending leaves / requests per level of a wave of simulations: ipp_mcts_backup clears them again)
         flags = (_ffi.IPP_ADAPTIVE if self.adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if self.uav is not None else 0)
         stream = eng.stream
         tp = C.byref(tab)
@@ -178,30 +180,40 @@ class DeviceMCTS(VectorMCTS):
             acc = torch.zeros_like(b["counts"], dtype=torch.int64)
             while sim < self.num_simulations:
                 w = min(W, self.num_simulations - sim)
-                b["counts"].zero_()
                 _ffi.check(lib.ipp_mcts_select(tp, root_env.data_ptr(), prev0.data_ptr(), budget0.data_ptr(), int(depth), int(sim), int(w),
                                                C.c_uint64(self.seed & (2 ** 64 - 1)), stream))
                 for level in range(D):
                     _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, -1, flags, stream))
                 self._expand(lib, tp, b, R, W, root_env, stream)
-                _ffi.check(lib.ipp_mcts_backup(tp, int(w), stream))
                 acc += b["counts"]
+                _ffi.check(lib.ipp_mcts_backup(tp, int(w), stream))
                 sim += w
             tot = acc.cpu().numpy()
             self.stats["device_steps"] += int(tot[R:].sum())
             self.stats["launches"] += int(D * ((self.num_simulations + W - 1) // W))
             self.stats["inferences"] += int(tot[:R].sum())
+        # The synchronised loop reads the request counts of a wave back (one small copy into pinned memory).  With tree nodes as
+        # patches the first levels are queued BEHIND the copy with their counts left on the device (n = -1), so the read-back's
+        # round trip (~40 us) passes under their kernels; the deeper levels are launched with exact sizes (or skipped when empty).
+        ahead = min(D, 2) if (bool(int(eng.info.patch_layout)) and eng.max_batch >= R * W  # (those launches are sized for R x W items)
+                              and os.environ.get("IPP_MCTS_AHEAD", "1") != "0") else 0
+        counts_h, ev = self._counts_host, self._counts_ev
         while not nosync and sim < self.num_simulations:
             w = min(W, self.num_simulations - sim)
-            b["counts"].zero_()
             _ffi.check(lib.ipp_mcts_select(tp, root_env.data_ptr(), prev0.data_ptr(), budget0.data_ptr(), int(depth), int(sim), int(w),
                                            C.c_uint64(self.seed & (2 ** 64 - 1)), stream))
-            counts = b["counts"].cpu().numpy()  # the one synchronisation of the wave
+            counts_h.copy_(b["counts"], non_blocking=True)
+            ev.record()
+            for level in range(ahead):
+                _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, -1, flags, stream))
+            ev.synchronize()  # the one synchronisation of the wave
+            counts = counts_h.numpy()
             level_n, n_pending = counts[R:], int(counts[:R].sum())
             for level in range(D):
                 n = int(level_n[level])
-                if n:
+                if level >= ahead and n:
                     _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, n, flags, stream))
+                if n:
                     self.stats["device_steps"] += n
                     self.stats["launches"] += 1
             if n_pending:
