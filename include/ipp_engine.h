@@ -317,9 +317,10 @@ typedef struct ipp_mcts_tables {
     /* per wave: recorded descents [W][R][max_depth] / [W][R], pending leaves [R][W] */
     int32_t* p_node; int32_t* p_k; double* p_cost; int32_t* p_len; int32_t* leaf;
     int32_t* pend_node; int32_t* pend_depth; int32_t* pend_sim; double* pend_prev; double* pend_budget; int32_t* pend_count;
-    /* covariance steps requested per tree level [max_depth][R W]: these are the argument arrays of ipp_tree_step */
+    /* covariance steps requested by a wave of simulations [max_depth R W] (one list; a descent asks for at most max_depth): these
+     * are the argument arrays of ipp_tree_step */
     int32_t* rq_root; int32_t* rq_parent; int32_t* rq_k; int32_t* rq_child; int32_t* rq_newdev;
-    double* rq_cost; double* rq_prev; double* rq_action; int32_t* rq_count;  /* rq_count [max_depth] */
+    double* rq_cost; double* rq_prev; double* rq_action; int32_t* rq_count;  /* rq_count [1] */
     int32_t* ts_paths; float* ts_reward; int32_t* ts_status;
     int32_t* err;                /* [4] node range / device-node range exhausted, tree-step status, kmax too small */
 } ipp_mcts_tables;
@@ -329,12 +330,13 @@ typedef struct ipp_mcts_tables {
  * requested steps and the device paths (n_devpath) of the children that get a device node. */
 int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env /*[dev] R env slots*/, const double* prev0 /*[dev] R x 3*/,
                     const double* budget0 /*[dev] R*/, int32_t depth, int32_t sim0, int32_t wave, uint64_t seed, void* stream);
-/* The n covariance steps requested at `level` (= tree depth - depth of the select call): ipp_tree_step on the request list and
- * the edge numerators t_num = reward (cost + 1).  flags as for ipp_tree_step.
- * n < 0 (engines with ipp_info.patch_layout = 1): the count stays on the device (t->rq_count[level], written by
- * ipp_mcts_select); the launches are sized for roots x wave items, so that the driver queues select, all levels, expand and
- * backup of a wave of simulations without a read-back in between. */
-int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, int32_t n, uint32_t flags, void* stream);
+/* The covariance steps [first, first + n) of the wave's request list: ipp_tree_step on them and the edge numerators
+ * t_num = reward (cost + 1).  The requests of a wave of simulations do not depend on each other (a node that gets its device
+ * state in this wave is a leaf until ipp_mcts_expand), so one launch takes them all; n <= ipp_config.max_batch per call.
+ * flags as for ipp_tree_step.  n < 0 (first = 0, engines with ipp_info.patch_layout = 1): the count stays on the device
+ * (t->rq_count[0], written by ipp_mcts_select) and the launch is sized for min(max_batch, roots x wave) items -- the driver queues it
+ * behind the selection without a read-back and launches requests beyond that size, if any, when it has read the count. */
+int ipp_mcts_steps(void* engine, const ipp_mcts_tables* t, int32_t first, int32_t n, uint32_t flags, void* stream);
 /* Pending leaves: valid-action sets (sets_only = 1: only those, so that the caller can ask its network with them) and
  * priors / value: prior [dev] [R W][kmax] on the valid sets or NULL = uniform; value [dev] [R W] or NULL = value_const;
  * Dirichlet(alpha) noise of weight eps on the root of simulation 0. */

@@ -98,7 +98,7 @@ PROTOTYPES = {
     "ipp_tree_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P]),
     "ipp_tree_read_diag": (C.c_int, [_P, C.c_int32, _P, _P]),
     "ipp_mcts_select": (C.c_int, [C.POINTER(IppMctsTables), _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, _P]),
-    "ipp_mcts_level_steps": (C.c_int, [_P, C.POINTER(IppMctsTables), C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "ipp_mcts_steps": (C.c_int, [_P, C.POINTER(IppMctsTables), C.c_int32, C.c_int32, C.c_uint32, _P]),
     "ipp_mcts_expand": (C.c_int, [C.POINTER(IppMctsTables), _P, _P, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint64, _P]),
     "ipp_mcts_backup": (C.c_int, [C.POINTER(IppMctsTables), C.c_int32, _P]),
     "ipp_mcts_policy": (C.c_int, [C.POINTER(IppMctsTables), _P, C.c_double, C.c_int32, _P, _P, _P, _P]),

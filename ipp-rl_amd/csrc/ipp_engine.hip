@@ -1417,30 +1417,30 @@ int ipp_mcts_select(const ipp_mcts_tables* t, const int32_t* root_env, const dou
     return 0;
 }
 
-int ipp_mcts_level_steps(void* engine, const ipp_mcts_tables* t, int32_t level, int32_t n, uint32_t flags, void* stream) {
+int ipp_mcts_steps(void* engine, const ipp_mcts_tables* t, int32_t first, int32_t n, uint32_t flags, void* stream) {
     if (int rc = mcts_check(t)) return rc;
     Engine* e = as_engine(engine);
     if (!e) return fail(-1, "null engine");
-    if (level < 0 || level >= t->max_depth) return fail(-1, "level %d outside [0, %d)", level, t->max_depth);
-    const int rw = t->roots * t->wave;
-    // n < 0: the level's request count stays on the device (t->rq_count[level]); the launches are sized for roots x wave items
-    // (patch engines: k_tree_patch reads the count) -- a search wave needs no read-back between select and backup
+    const int64_t cap = (int64_t)t->max_depth * t->roots * t->wave;
+    // n < 0: the request count stays on the device (t->rq_count[0]); the launch is sized for roots x wave items (patch engines:
+    // k_tree_patch reads the count) -- a search wave needs no read-back between select and the steps
     const bool dev_count = n < 0;
-    if (dev_count && !e->patch) return fail(-1, "n < 0 (device-side counts) needs the patch layout");
-    if (!dev_count && n > rw) return fail(-1, "n = %d outside [0, roots x wave = %d]", n, rw);
+    if (dev_count && !e->patch) return fail(-1, "n < 0 (device-side count) needs the patch layout");
+    if (dev_count && first != 0) return fail(-1, "n < 0 (device-side count) goes with first = 0");
+    if (first < 0 || (!dev_count && (int64_t)first + n > cap)) return fail(-1, "requests [%d, %d) outside the list of %lld", first, first + n, (long long)cap);
     if (n == 0) return 0;
-    const int n_grid = dev_count ? rw : n, n_arg = dev_count ? -1 : n;
+    const int n_grid = dev_count ? (int)std::min<int64_t>(e->v.max_batch, (int64_t)t->roots * t->wave) : n;
     if ((int64_t)t->roots * t->dev_per_root > e->tv.node_cap)
         return fail(-1, "roots x dev_per_root = %lld device nodes exceed ipp_config.node_capacity = %d", (long long)t->roots * t->dev_per_root, e->tv.node_cap);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
-    const size_t o = (size_t)level * rw;
+    const size_t o = (size_t)first;
     // (the path arguments ts_paths were written by ipp_mcts_select; the patch kernel writes the edge numerators itself)
     const TreeEdgeOut eo{t->rq_parent + o, t->rq_k + o, t->rq_cost + o, t->t_num, t->err, t->kmax};
     if (int rc = tree_step_impl(engine, t->rq_root + o, t->ts_paths + kMctsPath * o, t->rq_newdev + o, n_grid, t->rq_action + 3 * o, t->rq_prev + 3 * o,
-                                flags, t->ts_reward + o, t->ts_status + o, stream, dev_count ? t->rq_count + level : nullptr, e->patch ? &eo : nullptr))
+                                flags, t->ts_reward + o, t->ts_status + o, stream, dev_count ? t->rq_count : nullptr, e->patch ? &eo : nullptr))
         return rc;
-    if (!e->patch) hipLaunchKernelGGL(k_mcts_apply, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)level, n_arg);
+    if (!e->patch) hipLaunchKernelGGL(k_mcts_apply, dim3((n_grid + 255) / 256), dim3(256), 0, s, *t, (int)first, (int)n);
     HIP_TRY(hipGetLastError());
     return 0;
 }

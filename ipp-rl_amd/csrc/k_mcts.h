@@ -8,11 +8,12 @@
 // root: everything of a root (its node range, its hash table, its device-node range, the simulations in flight) is
 // touched by that wave only and in program order, so there are no atomics except the per-level request counters, and
 // the search is deterministic.  Per wave of W simulations in flight per root:
-//   k_mcts_select   all roots: W descents each (virtual visits keep them apart), recording paths, pending leaves and,
-//                   per tree level, the covariance steps of edges traversed for the first time (request lists that ARE
-//                   the argument arrays of ipp_tree_step)
-//   per level:      ipp_tree_step on the request list (path arguments and the new nodes' device paths were written by the
-//                   selection; k_tree_patch writes the edge numerators itself, band-tile engines through k_mcts_apply)
+//   k_mcts_select   all roots: W descents each (virtual visits keep them apart), recording paths, pending leaves and the
+//                   covariance steps of edges traversed for the first time (ONE request list per wave of simulations that IS
+//                   the argument arrays of ipp_tree_step: the steps are independent of each other -- a node created in this
+//                   wave stays a leaf until the wave's expansion -- so one launch takes them all), their path arguments and
+//                   the device paths of the new nodes
+//   ipp_tree_step   on the request list (k_tree_patch writes the edge numerators itself, band-tile engines through k_mcts_apply)
 //   k_mcts_expand   valid-action sets and priors of the pending leaves (network replies optional)
 //   k_mcts_backup   values back along the recorded paths
 // Arithmetic is fp64 with contraction off and in the operand order of the NumPy driver (vector_mcts.py), which builds the
@@ -84,7 +85,6 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
     const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (j >= m.roots) return;
     const int base = j * m.nodes_per_root;
-    const int RW = m.roots * m.wave;
     const bool virt = W > 1;
     uint64_t* hk = m.h_keys + (size_t)j * m.table_size;
     int32_t* hv = m.h_vals + (size_t)j * m.table_size;
@@ -124,14 +124,16 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             // ---- PUCT over the node's K valid actions (mcts.py:280-296)
             const size_t row = (size_t)cur * m.kmax;
             double rq[NR], rn[NR], rp[NR];
-            int ri[NR];
+            int ri[NR], rc[NR];
             if (NE > 0) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const int k = min(lane + 64 * i, m.kmax - 1);
                     rq[i] = m.t_qsa[row + k]; rn[i] = m.t_nsa[row + k]; rp[i] = m.t_ps[row + k]; ri[i] = m.t_idx[row + k];
+                    rc[i] = m.t_child[row + k];  // (with the rows: the chosen edge's child is known one round trip earlier)
                 }
             }
+            const int pv = lane < kMctsPath ? m.n_devpath[(size_t)kMctsPath * cur + lane] : -1;  // (this node's device path: lanes 0..5)
             double lo = INFINITY, hi = -INFINITY;
             int nz = 0;
             if (NE > 0) {
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             const double sq = sqrt(ns + 1);
             const bool force = d == 0;
             double best = -INFINITY, best_u = -1.0, best_nsa = 0.0;
-            int best_k = 0x7fffffff, best_a = -1;
-            auto consider = [&](int k, double q, double nsa, double ps, int ai) {
+            int best_k = 0x7fffffff, best_a = -1, best_c = -2;  // (best_c = -2: not loaded with the rows)
+            auto consider = [&](int k, double q, double nsa, double ps, int ai, int ci) {
                 const double qn = allzero ? q : ((lo == hi) ? q / hi : (q - lo) / (hi - lo));
                 double uct = qn + pc * (ps * (sq / (1 + nsa)));
                 if (force) {
@@ -169,30 +171,36 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     if (nsa < nfp) uct = INFINITY;
                 }
                 const double u = m.tie_break ? mc_u01(mc_mix(seed ^ mc_mix(((uint64_t)(uint32_t)cur << 32) | (uint32_t)(k + 1)) ^ ((uint64_t)(sim0 + w) << 20))) : 0.0;
-                if (uct > best || (uct == best && (m.tie_break ? u > best_u : k < best_k))) { best = uct; best_k = k; best_u = u; best_nsa = nsa; best_a = ai; }
+                if (uct > best || (uct == best && (m.tie_break ? u > best_u : k < best_k))) { best = uct; best_k = k; best_u = u; best_nsa = nsa; best_a = ai; best_c = ci; }
             };
             if (NE > 0) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i)
-                    if (lane + 64 * i < K) consider(lane + 64 * i, rq[i], rn[i], rp[i], ri[i]);
+                    if (lane + 64 * i < K) consider(lane + 64 * i, rq[i], rn[i], rp[i], ri[i], rc[i]);
             } else {
-                for (int k = lane; k < K; k += 64) consider(k, m.t_qsa[row + k], m.t_nsa[row + k], m.t_ps[row + k], m.t_idx[row + k]);
+                for (int k = lane; k < K; k += 64) consider(k, m.t_qsa[row + k], m.t_nsa[row + k], m.t_ps[row + k], m.t_idx[row + k], -2);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const double ob = mc_shfl_xor(best, o), ou = mc_shfl_xor(best_u, o), on = mc_shfl_xor(best_nsa, o);
-                const int ok = __shfl_xor(best_k, o, 64), oa = __shfl_xor(best_a, o, 64);
+                const int ok = __shfl_xor(best_k, o, 64), oa = __shfl_xor(best_a, o, 64), oc = __shfl_xor(best_c, o, 64);
                 if (ob > best || (ob == best && (m.tie_break ? (ou > best_u || (ou == best_u && ok < best_k)) : ok < best_k))) {
-                    best = ob; best_k = ok; best_u = ou; best_nsa = on; best_a = oa;
+                    best = ob; best_k = ok; best_u = ou; best_nsa = on; best_a = oa; best_c = oc;
                 }
             }
             MC_STAMP(2);
             const int k = best_k, a_idx = best_a;  // (K >= 1 for an expanded node)
             // ---- the chosen edge: everything it needs in one round trip
             const double action[3] = {m.actions[3 * (size_t)a_idx], m.actions[3 * (size_t)a_idx + 1], m.actions[3 * (size_t)a_idx + 2]};
-            int child = m.t_child[row + k];
+            int child = (NE > 0) ? best_c : m.t_child[row + k];
             const double num = m.t_num[row + k];
             const uint64_t zk = m.zkey[a_idx], hcur = m.n_hash[cur];
+            // (an existing child's record in the same round trip as the edge's fields)
+            const bool child_known = child >= 0;
+            const int cpre = child_known ? child : cur;
+            const unsigned char cfl_pre = m.n_flags[cpre];
+            const int cK_pre = m.n_k[cpre];
+            const double cns_pre = m.n_ns[cpre];
             const double cost = mc_cost(m, action, prev);
             MC_STAMP(3);
             if (child < 0) {  // (wave-uniform) transposition lookup: the same measurements in any order are one node
@@ -221,10 +229,9 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             }
             MC_STAMP(4);
             // ---- the child's record (the next level's node) next to this level's bookkeeping
-            const unsigned char cfl = m.n_flags[child];
-            const int cK = m.n_k[child];
-            const double cns = m.n_ns[child];
-            const int pv = lane < kMctsPath ? m.n_devpath[(size_t)kMctsPath * cur + lane] : -1;  // (this node's device path: lanes 0..5)
+            const unsigned char cfl = child_known ? cfl_pre : m.n_flags[child];
+            const int cK = child_known ? cK_pre : m.n_k[child];
+            const double cns = child_known ? cns_pre : m.n_ns[child];
             int pth[kMctsPath];
 #pragma unroll
             for (int s = 0; s < kMctsPath; ++s) pth[s] = __shfl(pv, s, 64);
@@ -242,9 +249,9 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                             m.n_flags[child] = cfl | kNodeStored;
                         }
                     }
-                    const int lvl = d - depth0;
-                    const int slot = atomicAdd(&m.rq_count[lvl], 1);
-                    const size_t r = (size_t)lvl * RW + slot;
+                    // ONE request list per wave of simulations: the requested steps do not depend on each other (a node that gets its
+                    // device state in this wave is a leaf until the wave's expansion, so no descent of the wave goes below it)
+                    const size_t r = (size_t)atomicAdd(m.rq_count, 1);
                     m.rq_root[r] = root_env[j];
                     m.rq_parent[r] = cur;
                     m.rq_k[r] = k;
@@ -310,11 +317,11 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
 // Results of a level's ipp_tree_step for engines whose tree kernels do not write them themselves (band-tile nodes; k_tree_patch
 // does: TreeEdgeOut): the edge's masked trace reduction (reward (cost + 1), rewards.py:31 undone: the cost depends on the path that
 // led to the node, the reduction does not).
-__global__ void k_mcts_apply(ipp_mcts_tables m, int level, int n) {
+__global__ void k_mcts_apply(ipp_mcts_tables m, int first, int n) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const size_t r = (size_t)level * m.roots * m.wave + i;
+    const size_t r = (size_t)first + i;
     if (m.ts_status[r] != 0) m.err[2] = m.ts_status[r];
     m.t_num[(size_t)m.rq_parent[r] * m.kmax + m.rq_k[r]] = (double)m.ts_reward[r] * (m.rq_cost[r] + 1.0);
 }
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256) void k_mcts_expand(ipp_mcts_tables m, const do
 __global__ void k_mcts_backup_serial(ipp_mcts_tables m, int W) {
 #pragma clang fp contract(off)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m.max_depth) m.rq_count[j] = 0;
+    if (j == 0) m.rq_count[0] = 0;
     if (j >= m.roots) return;
     m.pend_count[j] = 0;
     const bool virt = W > 1;
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(64) void k_mcts_backup(ipp_mcts_tables m, int W) {
     __shared__ double st_nsa[64], st_q[64];
     const int j = blockIdx.x, lane = threadIdx.x;
     const int D = m.max_depth;
-    if (j == 0 && lane < D) m.rq_count[lane] = 0;
+    if (j == 0 && lane == 0) m.rq_count[0] = 0;
     if (lane == 0) m.pend_count[j] = 0;
     const bool virt = W > 1;
     const int w = lane / D, pos = lane - w * D;

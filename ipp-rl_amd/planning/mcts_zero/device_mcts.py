@@ -6,8 +6,8 @@ of device work.  Here the node tables live in HBM (torch tensors handed to the C
 owns one root, and the host only sequences the launches of a wave of simulations:
 
     ipp_mcts_select            W descents per root (PUCT, forced playouts, virtual visits, transposition lookup)
-    (one small read-back: the number of covariance steps requested per tree level and whether any leaf is pending)
-    ipp_mcts_level_steps       per tree level: ipp_tree_step for all roots + edge numerators + new nodes' device paths
+    (one small read-back, under the step launch: the number of covariance steps requested and whether any leaf is pending)
+    ipp_mcts_steps             ipp_tree_step on the wave's request list (ONE launch: the requests are independent) + edge numerators
     ipp_mcts_expand            valid-action sets, priors (uniform or the network's), Dirichlet noise at the root
     ipp_mcts_backup            values back along the recorded descents
 
@@ -38,9 +38,10 @@ from .vector_mcts import VectorMCTS
 class DeviceMCTS(VectorMCTS):
     def __init__(self, engine, hyper_params: Dict, meta_data: Dict, infer: Optional[Callable] = None, sims_in_flight: int = 4,
                  tie_break: str = "first", seed: int = 0, leaf_value: float = 0.0, nodes_per_root: Optional[int] = None,
-                 dev_per_root: Optional[int] = None):
+                 dev_per_root: Optional[int] = None, queue_ahead: bool = True):
         super().__init__(engine, hyper_params, meta_data, infer, None, sims_in_flight, tie_break, seed)
         self.leaf_value = float(leaf_value)
+        self.queue_ahead = bool(queue_ahead)  # (False: every step launch waits for the wave's request count -- tests, A/B)
         self.seed = int(seed)
         S, W = self.num_simulations, self.sims_in_flight
         # a descent passes through at most horizon + 1 edges and only its first traversal of an edge creates a node; more
@@ -98,12 +99,13 @@ class DeviceMCTS(VectorMCTS):
             p_len=e((W, R), torch.int32), leaf=e((W, R), torch.int32),
             pend_node=e((R, W), torch.int32), pend_depth=e((R, W), torch.int32), pend_sim=e((R, W), torch.int32),
             pend_prev=e((R, W, 3), torch.float64), pend_budget=e((R, W), torch.float64),
-            # pend_count [R] and rq_count [D] share one buffer: cleared and read back together
-            counts=e((R + D,), torch.int32),
-            rq_root=e((D, R * W), torch.int32), rq_parent=e((D, R * W), torch.int32), rq_k=e((D, R * W), torch.int32),
-            rq_child=e((D, R * W), torch.int32), rq_newdev=e((D, R * W), torch.int32), rq_cost=e((D, R * W), torch.float64),
-            rq_prev=e((D, R * W, 3), torch.float64), rq_action=e((D, R * W, 3), torch.float64),
-            ts_paths=e((D, R * W, 6), torch.int32), ts_reward=e((D, R * W), torch.float32), ts_status=e((D, R * W), torch.int32),
+            # pend_count [R] and rq_count [1] share one buffer: cleared and read back together
+            counts=e((R + 1,), torch.int32),
+            # (one request list per wave of simulations; a descent asks for at most D steps, typically one)
+            rq_root=e((D * R * W,), torch.int32), rq_parent=e((D * R * W,), torch.int32), rq_k=e((D * R * W,), torch.int32),
+            rq_child=e((D * R * W,), torch.int32), rq_newdev=e((D * R * W,), torch.int32), rq_cost=e((D * R * W,), torch.float64),
+            rq_prev=e((D * R * W, 3), torch.float64), rq_action=e((D * R * W, 3), torch.float64),
+            ts_paths=e((D * R * W, 6), torch.int32), ts_reward=e((D * R * W,), torch.float32), ts_status=e((D * R * W,), torch.int32),
             err=e((4,), torch.int32),
         )
         uav = self.uav
@@ -125,7 +127,7 @@ class DeviceMCTS(VectorMCTS):
         # read-out (ipp_mcts_policy): results on the device and their pinned host copies
         self._out = dict(policy=e((R, K), torch.float64), valid_idx=e((R, K), torch.int32), ok=e((R,), torch.int32), u=e((R,), torch.float64))
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)  # noqa: E731
-        self._counts_host, self._counts_ev = pin((R + D,), torch.int32), torch.cuda.Event()
+        self._counts_host, self._counts_ev = pin((R + 1,), torch.int32), torch.cuda.Event()
         self._out_host = dict(policy=pin((R, K), torch.float64), valid_idx=pin((R, K), torch.int32), ok=pin((R,), torch.int32),
                               K=pin((R,), torch.int32), nodes=pin((), torch.int64))
         return tab, b
@@ -164,58 +166,37 @@ class DeviceMCTS(VectorMCTS):
         b["dev_count"].zero_()
         b["h_keys"].zero_()
         b["err"].zero_()
-        b["counts"].zero_()  # (pending leaves / requests per level of a wave of simulations: ipp_mcts_backup clears them again)
+        b["counts"].zero_()  # (pending leaves / requests of a wave of simulations: ipp_mcts_backup clears them again)
         flags = (_ffi.IPP_ADAPTIVE if self.adaptive else 0) | (_ffi.IPP_USE_FLIGHT_TIME if self.uav is not None else 0)
         stream = eng.stream
         tp = C.byref(tab)
         sim = 0
-        # Without a network in the loop (stub leaf values) and with tree nodes stored as patches (ipp_info.patch_layout: the
-        # tree-step kernel reads its item count on the device), a wave of simulations is queued without ANY read-back: select,
-        # every level (launches sized for roots x wave items, ipp_mcts_level_steps with n = -1), expand, backup.  The request
-        # counts are summed on the device for the statistics.
-        # (opt-in, IPP_MCTS_NOSYNC=1: measured equal to the synchronised loop -- 44.9 vs 44.4 ms per configs[4] search: the search is
-        # bound by the GPU time of select + tree steps (35 ms) and the host read-out of the policies, not by the 64 read-backs)
-        nosync = self.infer is None and bool(int(eng.info.patch_layout)) and os.environ.get("IPP_MCTS_NOSYNC", "0") == "1"
-        if nosync:
-            acc = torch.zeros_like(b["counts"], dtype=torch.int64)
-            while sim < self.num_simulations:
-                w = min(W, self.num_simulations - sim)
-                _ffi.check(lib.ipp_mcts_select(tp, root_env.data_ptr(), prev0.data_ptr(), budget0.data_ptr(), int(depth), int(sim), int(w),
-                                               C.c_uint64(self.seed & (2 ** 64 - 1)), stream))
-                for level in range(D):
-                    _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, -1, flags, stream))
-                self._expand(lib, tp, b, R, W, root_env, stream)
-                acc += b["counts"]
-                _ffi.check(lib.ipp_mcts_backup(tp, int(w), stream))
-                sim += w
-            tot = acc.cpu().numpy()
-            self.stats["device_steps"] += int(tot[R:].sum())
-            self.stats["launches"] += int(D * ((self.num_simulations + W - 1) // W))
-            self.stats["inferences"] += int(tot[:R].sum())
-        # The synchronised loop reads the request counts of a wave back (one small copy into pinned memory).  With tree nodes as
-        # patches the first levels are queued BEHIND the copy with their counts left on the device (n = -1), so the read-back's
-        # round trip (~40 us) passes under their kernels; the deeper levels are launched with exact sizes (or skipped when empty).
-        ahead = min(D, 2) if (bool(int(eng.info.patch_layout)) and eng.max_batch >= R * W  # (those launches are sized for R x W items)
-                              and os.environ.get("IPP_MCTS_AHEAD", "1") != "0") else 0
+        # A wave of simulations: select, the covariance steps it asked for (ONE list: they do not depend on each other), expand,
+        # backup.  With tree nodes stored as patches (ipp_info.patch_layout: the tree-step kernel reads its item count on the device)
+        # the step launch is queued right behind the selection, sized for roots x wave items (n = -1); the host reads the counts
+        # (pending leaves, requests) into pinned memory meanwhile and only launches what the list holds beyond that size (descents
+        # that pass several new edges through transpositions: a few dozen of 8192 at configs[4]).  Band-tile engines (and
+        # queue_ahead=False) launch the exact count after the read-back.
+        ahead = self.queue_ahead and bool(int(eng.info.patch_layout)) and eng.max_batch >= R * W
         counts_h, ev = self._counts_host, self._counts_ev
-        while not nosync and sim < self.num_simulations:
+        while sim < self.num_simulations:
             w = min(W, self.num_simulations - sim)
             _ffi.check(lib.ipp_mcts_select(tp, root_env.data_ptr(), prev0.data_ptr(), budget0.data_ptr(), int(depth), int(sim), int(w),
                                            C.c_uint64(self.seed & (2 ** 64 - 1)), stream))
             counts_h.copy_(b["counts"], non_blocking=True)
             ev.record()
-            for level in range(ahead):
-                _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, -1, flags, stream))
+            if ahead:
+                _ffi.check(lib.ipp_mcts_steps(eng._h, tp, 0, -1, flags, stream))
             ev.synchronize()  # the one synchronisation of the wave
-            counts = counts_h.numpy()
-            level_n, n_pending = counts[R:], int(counts[:R].sum())
-            for level in range(D):
-                n = int(level_n[level])
-                if level >= ahead and n:
-                    _ffi.check(lib.ipp_mcts_level_steps(eng._h, tp, level, n, flags, stream))
-                if n:
-                    self.stats["device_steps"] += n
-                    self.stats["launches"] += 1
+            n, n_pending = int(counts_h[R]), int(counts_h[:R].sum())
+            first = R * W if ahead else 0
+            while first < n:
+                chunk = min(n - first, eng.max_batch)
+                _ffi.check(lib.ipp_mcts_steps(eng._h, tp, first, chunk, flags, stream))
+                first += chunk
+                self.stats["launches"] += 1
+            self.stats["device_steps"] += n
+            self.stats["launches"] += 1 if ahead else 0
             if n_pending:
                 self._expand(lib, tp, b, R, W, root_env, stream)
                 self.stats["inferences"] += n_pending

@@ -401,20 +401,19 @@ def test_device_read_out_equals_the_host_read_out(monkeypatch, temperature, depl
         assert dict(zip(vidx[j, :K[j]][nz].tolist(), pol[j, :K[j]][nz].tolist())) == out_b[j][0]
 
 
-def test_device_search_without_read_backs_equals_the_synchronised_loop(monkeypatch):
-    """Tree nodes as patches (40x40: k_tree_patch) and a stub network: with IPP_MCTS_NOSYNC=1 the driver queues select, every level
-    (ipp_mcts_level_steps with n = -1: launches sized for roots x wave items, the kernels read the request counts on the device),
-    expand and backup of each wave of simulations without a read-back; trees and statistics must equal the synchronised loop's."""
+def test_device_search_step_launch_behind_the_selection_equals_exact_launches():
+    """Tree nodes as patches (40x40: k_tree_patch) and a stub network: by default the driver queues the wave's covariance steps right
+    behind the selection (ipp_mcts_steps with n = -1: a launch sized for roots x wave items, the kernel reads the request count on the
+    device) and reads the counts meanwhile; trees and statistics must equal those of launches sized after the read-back."""
     from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
 
     dim, R, sims, horizon = 40, 8, 32, 4
     eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.25)
-    assert eng.info.patch_layout == 1
+    assert eng.info.patch_layout == 1 and eng.max_batch >= 4 * R
     roots = list(range(R))
     results = []
-    for nosync in ("0", "1"):
-        monkeypatch.setenv("IPP_MCTS_NOSYNC", nosync)
-        s = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="first", leaf_value=0.3)
+    for ahead in (False, True):
+        s = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=4, tie_break="first", leaf_value=0.3, queue_ahead=ahead)
         out = s.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(3 + r) for r in roots])
         idx, nsa, q = s.root_statistics()
         results.append((out, idx.copy(), nsa.copy(), q.copy(), dict(s.stats)))

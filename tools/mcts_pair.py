@@ -67,7 +67,7 @@ class Search:
             b["n_flags"].zero_(); b["n_flags"][root_nodes] = 2
             b["n_value"].zero_(); b["n_devpath"].fill_(-1)
             b["n_hash"][root_nodes] = (torch.arange(R, device=self.eng.device, dtype=torch.int64) + 1) * (-7046029254386353131)
-            b["root_count"].fill_(1); b["dev_count"].zero_(); b["h_keys"].zero_(); b["err"].zero_()
+            b["root_count"].fill_(1); b["dev_count"].zero_(); b["h_keys"].zero_(); b["err"].zero_(); b["counts"].zero_()
         self.sim = 0
 
     def wave(self):
@@ -75,11 +75,9 @@ class Search:
         w = min(W, sims - self.sim)
         flags = _ffi.IPP_ADAPTIVE | _ffi.IPP_USE_FLIGHT_TIME
         with torch.cuda.stream(self.stream):
-            self.b["counts"].zero_()
             _ffi.check(lib.ipp_mcts_select(tp, self.root_env.data_ptr(), self.prev0.data_ptr(), self.budget0.data_ptr(), 0, int(self.sim), int(w),
                                            C.c_uint64(m.seed & (2 ** 64 - 1)), self.cs))
-            for level in range(self.D):
-                _ffi.check(lib.ipp_mcts_level_steps(self.eng._h, tp, level, -1, flags, self.cs))
+            _ffi.check(lib.ipp_mcts_steps(self.eng._h, tp, 0, -1, flags, self.cs))
             m._expand(lib, tp, self.b, self.R, W, self.root_env, self.cs)
             _ffi.check(lib.ipp_mcts_backup(tp, int(w), self.cs))
         self.sim += w
