@@ -349,21 +349,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     for (int j = 0; j < RJ; ++j)
         if (con[j]) { klist[pos[j]] = (unsigned short)(tid + j * NT); rclist[pos[j]] = rc_pre[j]; }
     patch_sync<ONE>();
-    int ck[RJ];
-    unsigned crc[RJ];
-#pragma unroll
-    for (int j = 0; j < RJ; ++j) {
-        const int t = tid + j * NT;
-        ck[j] = (t < n_c) ? (int)klist[t] : 0;
-        crc[j] = (t < n_c) ? rclist[t] : 0u;
-    }
     // (no barrier behind the reads: nothing below writes the two lists' areas before the barrier that ends the gather -- the
     // records go to lds.rec, the prior tables to lds.lut and pl.ktab, which starts behind the rectangle list)
     static_assert(4 * kPatchMaxRank <= (3 * MC * (MC + 1) + 3 * MC + 4 * MC) * 8, "rectangle list reaches pl.ktab");
 
     // ------------------------------------------------------------------ gather HT = H_F U[F,:]^T for the contributing columns
-    // The OWNER of a column gathers it: lanes <-> columns, the footprint's blocks and cells are wave-uniform loop counters,
-    // every request is an unconditional buffer load whose offset is pushed out of range where the column is not stored.
+    // Lanes <-> columns (rounds of 64), the footprint's blocks and cells are wave-uniform loop counters, every request is an
+    // unconditional buffer load whose offset is pushed out of range where the column is not stored.  The waves of the item SHARE
+    // a round: wave w takes the measurement blocks i = w (mod NW) of all its columns and writes those entries of the records -- with
+    // the usual 30-60 contributing columns one wave issued all 9 .. 36 requests per column while the others waited at the barrier.
+    const int wave_u = ONE ? 0 : __builtin_amdgcn_readfirstlane(wave);
+    auto mine = [&](int i) { return ONE || (i % NW) == wave_u; };
     const auto slot_rs = __builtin_amdgcn_make_buffer_rsrc(slot, 0, 0x7ffffff0, 0x00020000);
     const auto row_rs = __builtin_amdgcn_make_buffer_rsrc(slot - v.pstride, 0, 0x7ffffff0, 0x00020000);  // (records hold offsets from here)
     // (cells and weights of the measurement blocks from the LDS tables filled in front of the barrier above: evaluating
@@ -380,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         for (int i = 0; i < MC; ++i) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) l[i][a] = 0.f;
-            if (i < m) {  // wave-uniform
+            if (i < m && mine(i)) {  // wave-uniform
                 const int cnt = uni(pl.bcnt[i]);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -399,40 +395,44 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     };
     auto gather_store = [&](unsigned rc, int k, bool on, int a_pos, const float (&l)[MC][4]) {
         if (!on) return;
-        float rec[kPatchRec];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) rec[i] = 0.f;
+        float* dst = (a_pos < cap) ? lds.rec + (size_t)a_pos * kPatchRec : nullptr;
+        float* gdst = (SPLIT || a_pos >= cap) ? (SPLIT ? blk_rec + (size_t)a_pos * kPatchRec : ovf + (size_t)(a_pos - cap) * kPatchRec) : nullptr;
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
-            if (i < m) {
+            if (i < m && mine(i)) {
                 const int cnt = uni(pl.bcnt[i]);
                 float t = l[i][0];
                 if (cnt > 1) t += l[i][1];
                 if (cnt > 2) t += l[i][2] + l[i][3];
-                rec[i] = -(t * lds.fb_w[4 * i]);  // block weight; sign of the downdate folded in
+                const float val = -(t * lds.fb_w[4 * i]);  // block weight; sign of the downdate folded in
+                if (dst) dst[i] = val;
+                if (gdst) gdst[i] = val;
             }
         }
+        if (wave_u != 0) return;
+        // wave 0: the entries no block fills and the column's address / rectangle
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (i >= m) {
+                if (dst) dst[i] = 0.f;
+                if (gdst) gdst[i] = 0.f;
+            }
         const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
         const int shift = (r0n - r0k) * pw + (c0n - c0k);
-        rec[12] = __int_as_float((k * v.pstride + shift + v.pstride) * 4);                // byte offset of the shifted patch from one patch in front of the slot (>= 0: the scalar offset of the row requests)
-        rec[13] = __int_as_float(r0k | (c0k << 16));                                      // rectangle: first row | first column << 16
-        rec[14] = __int_as_float((r1k - r0k) | ((c1k - c0k) << 16));                      //            rows - 1 | columns - 1 << 16
-        rec[15] = __int_as_float(k);
-        if (a_pos < cap) {
-            float4* dst = reinterpret_cast<float4*>(lds.rec + (size_t)a_pos * kPatchRec);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-        }
-        if (SPLIT || a_pos >= cap) {
-            float4* dst = reinterpret_cast<float4*>(SPLIT ? blk_rec + (size_t)a_pos * kPatchRec : ovf + (size_t)(a_pos - cap) * kPatchRec);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-        }
+        const float4 meta = make_float4(__int_as_float((k * v.pstride + shift + v.pstride) * 4),  // byte offset of the shifted patch from one patch in front of the slot (>= 0: the scalar offset of the row requests)
+                                        __int_as_float(r0k | (c0k << 16)),                           // rectangle: first row | first column << 16
+                                        __int_as_float((r1k - r0k) | ((c1k - c0k) << 16)),          //            rows - 1 | columns - 1 << 16
+                                        __int_as_float(k));
+        if (dst) reinterpret_cast<float4*>(dst)[3] = meta;
+        if (gdst) reinterpret_cast<float4*>(gdst)[3] = meta;
     };
     {
         float l0[MC][4];
-        const bool any0 = wave * kWave < n_c;  // (wave-uniform)
-        if (any0) gather_issue(crc[0], ck[0], tid < n_c, l0);
+        const bool any0 = n_c > 0;  // (wave-uniform)
+        const bool on0 = lane < n_c;
+        const int k0 = on0 ? (int)klist[lane] : 0;
+        const unsigned rc0 = on0 ? rclist[lane] : 0u;
+        if (any0) gather_issue(rc0, k0, on0, l0);
         // ---- under the round trip: prior table, footprint tables of the m x m algebra, the padding record
         {
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
@@ -445,21 +445,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
             if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
-        if (any0) gather_store(crc[0], ck[0], tid < n_c, tid, l0);
+        if (any0) gather_store(rc0, k0, on0, lane, l0);
     }
 #pragma unroll 1
-    for (int j = 1; j < RJ; ++j) {
-        if (j * NT + wave * kWave >= n_c) break;  // (wave-uniform)
-        // (a select chain on the wave-uniform j: a register array cannot be indexed dynamically)
-        unsigned rc = crc[RJ - 1];
-        int kk = ck[RJ - 1];
-#pragma unroll
-        for (int q = 1; q < RJ - 1; ++q)
-            if (j == q) { rc = crc[q]; kk = ck[q]; }
-        const int t = tid + j * NT;
+    for (int t0 = kWave; t0 < n_c; t0 += kWave) {  // (wave-uniform; the lists stay in place until the barrier below)
+        const int t = t0 + lane;
+        const bool on = t < n_c;
+        const int kk = on ? (int)klist[t] : 0;
+        const unsigned rc = on ? rclist[t] : 0u;
         float l[MC][4];
-        gather_issue(rc, kk, t < n_c, l);
-        gather_store(rc, kk, t < n_c, t, l);
+        gather_issue(rc, kk, on, l);
+        gather_store(rc, kk, on, t, l);
     }
     if ((flags & IPP_UPDATE_PREV) && tid == 0) {
         // (every thread took its copy of prev_action in batch 1, in front of the barrier above)

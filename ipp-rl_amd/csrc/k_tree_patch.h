@@ -242,22 +242,20 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     for (int j = 0; j < RJ; ++j)
         if (con[j]) { klist[pos[j]] = (unsigned short)(tid + j * NT); rclist[pos[j]] = rcs[j]; }
     __syncthreads();
-    unsigned crc[RJ];
-    long long coff[RJ];
-#pragma unroll
-    for (int j = 0; j < RJ; ++j) {
-        const int t = tid + j * NT;
-        const int k = (t < n_c) ? (int)klist[t] : 0;
-        crc[j] = (t < n_c) ? rclist[t] : 0u;
+    // (no barrier behind the reads: nothing below writes the two lists' areas before the barrier that ends the gather)
+
+    // ------------------------------------------------------------------ gather HT for the contributing columns
+    // (lanes <-> columns in rounds of 64; the waves of the item share a round, wave w takes the measurement blocks i = w (mod NW):
+    // k_step_patch.h)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto mine = [&](int i) { return (i % NW) == wave_u; };
+    auto col_off = [&](int k) {  // byte offset of chain column k from base0: root column k, or column k - poff[d] of path node d
         long long off = root_off + (long long)k * v.pstride * 4;
 #pragma unroll
         for (int d = 0; d < kTreeDepth; ++d)
             if (k >= poff[d]) off = node_off + ((long long)pid[d] * MC + (k - poff[d])) * (long long)v.pstride * 4;
-        coff[j] = off;
-    }
-    // (no barrier behind the reads: nothing below writes the two lists' areas before the barrier that ends the gather)
-
-    // ------------------------------------------------------------------ gather HT for the contributing columns (owner lanes)
+        return off;
+    };
     auto gather_issue = [&](unsigned rc, long long off, bool on, float (&l)[MC][4]) {
         const unsigned r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
         // patch_k[(fy - r0k) * pw + (fx - c0k)]; lanes without a column (and cells outside it) read the arena's first float
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
         for (int i = 0; i < MC; ++i) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) l[i][a] = 0.f;
-            if (i < m) {  // wave-uniform
+            if (i < m && mine(i)) {  // wave-uniform
                 const int cnt = uni(pl.bcnt[i]);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -284,39 +282,33 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     };
     auto gather_store = [&](unsigned rc, long long off, bool on, int a_pos, const float (&l)[MC][4]) {
         if (!on) return;
-        float rec[kPatchRec];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) rec[i] = 0.f;
+        float* dst = (a_pos < cap) ? lds.rec + (size_t)a_pos * kPatchRec : ovf + (size_t)(a_pos - cap) * kPatchRec;
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
-            if (i < m) {
+            if (i < m && mine(i)) {
                 const int cnt = uni(pl.bcnt[i]);
                 float t = l[i][0];
                 if (cnt > 1) t += l[i][1];
                 if (cnt > 2) t += l[i][2] + l[i][3];
-                rec[i] = -(t * lds.fb_w[4 * i]);
+                dst[i] = -(t * lds.fb_w[4 * i]);
             }
         }
+        if (wave_u != 0) return;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (i >= m) dst[i] = 0.f;
         const int r0k = rc & 0xff, r1k = (rc >> 8) & 0xff, c0k = (rc >> 16) & 0xff, c1k = rc >> 24;
         const int shift = (r0n - r0k) * pw + (c0n - c0k);
-        rec[12] = __uint_as_float((unsigned)((off + (long long)shift * 4) >> 3));          // shifted patch: offset from base0 in 8-byte units
-        rec[13] = __int_as_float(r0k | (c0k << 16));
-        rec[14] = __int_as_float((r1k - r0k) | ((c1k - c0k) << 16));
-        rec[15] = 0.f;
-        if (a_pos < cap) {
-            float4* dst = reinterpret_cast<float4*>(lds.rec + (size_t)a_pos * kPatchRec);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-        } else {
-            float4* dst = reinterpret_cast<float4*>(ovf + (size_t)(a_pos - cap) * kPatchRec);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-        }
+        reinterpret_cast<float4*>(dst)[3] = make_float4(__uint_as_float((unsigned)((off + (long long)shift * 4) >> 3)),  // shifted patch: offset from base0 in 8-byte units
+                                                        __int_as_float(r0k | (c0k << 16)), __int_as_float((r1k - r0k) | ((c1k - c0k) << 16)), 0.f);
     };
     {
         float l0[MC][4];
-        const bool any0 = wave * kWave < n_c;  // (wave-uniform)
-        if (any0) gather_issue(crc[0], coff[0], tid < n_c, l0);
+        const bool any0 = n_c > 0;  // (wave-uniform)
+        const bool on0 = lane < n_c;
+        const unsigned rc0 = on0 ? rclist[lane] : 0u;
+        const long long off0 = col_off(on0 ? (int)klist[lane] : 0);
+        if (any0) gather_issue(rc0, off0, on0, l0);
         {
             const float s3 = (float)(kSqrt3 * v.res) / h.ls;
             const int lw = v.plw;
@@ -327,20 +319,17 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
             if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
-        if (any0) gather_store(crc[0], coff[0], tid < n_c, tid, l0);
+        if (any0) gather_store(rc0, off0, on0, lane, l0);
     }
 #pragma unroll 1
-    for (int j = 1; j < RJ; ++j) {
-        if (j * NT + wave * kWave >= n_c) break;  // (wave-uniform)
-        unsigned rc = crc[RJ - 1];
-        long long off = coff[RJ - 1];
-#pragma unroll
-        for (int q = 1; q < RJ - 1; ++q)
-            if (j == q) { rc = crc[q]; off = coff[q]; }
-        const int t = tid + j * NT;
+    for (int t0 = kWave; t0 < n_c; t0 += kWave) {  // (wave-uniform; the lists stay in place until the barrier below)
+        const int t = t0 + lane;
+        const bool on = t < n_c;
+        const unsigned rc = on ? rclist[t] : 0u;
+        const long long off = col_off(on ? (int)klist[t] : 0);
         float l[MC][4];
-        gather_issue(rc, off, t < n_c, l);
-        gather_store(rc, off, t < n_c, t, l);
+        gather_issue(rc, off, on, l);
+        gather_store(rc, off, on, t, l);
     }
     const int n_lds = min(n_c, cap), n_ovf = n_c - n_lds;
     if (n_ovf > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

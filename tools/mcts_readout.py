@@ -55,3 +55,5 @@ pr.enable()
 m.get_policy(roots, prev, budgets)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+if os.environ.get("IPP_TIMELINE_FILE"):  # (-DIPP_TIMELINE=1 build: marks of the last tree-step launch -> tools/timeline.py)
+    eng.streamed_bytes()
