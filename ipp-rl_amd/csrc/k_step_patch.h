@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     static_assert(KPN <= kPatchKP, "the row lists are padded for kPatchKP entries");
     constexpr int RJ = (kPatchMaxRank + NT - 1) / NT;      // rectangles per thread, loaded with the inputs
     constexpr int OW = (NW > 1) ? 1 : 0;                   // the wave that evaluates the observation
+    constexpr int TW = (NW > 2) ? 2 : OW;                  // the wave that fills the small per-item tables (block cells, fp64 prior of the footprint)
     constexpr bool ONE = (NW == 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
     const PatchLds lds(smem_sp, v.pcap, SPLIT ? 0 : v.plw * v.plw, SPLIT ? 1 : NW, v.punits, v.rank_cap);  // (split step: no prior table, one list area)
@@ -306,16 +307,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
         bal[j] = __ballot(con[j]);
         if (!ONE && lane == 0) wcnt[j * NW + wave] = __popcll(bal[j]);
     }
-    if (tid < MC) {  // measurement blocks of the footprint as flat (cell, weight) tables + the tables of the m x m algebra
-        const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+    const int ttid = tid - kWave * TW;
+    if (ttid >= 0 && ttid < MC) {  // measurement blocks of the footprint as flat (cell, weight) tables + the tables of the m x m algebra
+        const Block bb = block_of(min(ttid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, bb.count() - 1);
             const int ly = bb.y0 + blk_dy(aa, bb.bw), lx = bb.x0 + blk_dx(aa, bb.bw);
-            lds.fb_yx[4 * tid + a] = (h.yu + ly) | ((h.xl + lx) << 16);  // grid row | grid column << 16 (the packing of the rectangle tests)
-            lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
-            if (tid < m) pl.bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
+            lds.fb_yx[4 * ttid + a] = (h.yu + ly) | ((h.xl + lx) << 16);  // grid row | grid column << 16 (the packing of the rectangle tests)
+            lds.fb_w[4 * ttid + a] = (ttid < m && a < bb.count()) ? (float)bb.weight : 0.f;
+            if (ttid < m) pl.bfi[4 * ttid + a] = bfi_pack(ly, lx, h.w);
         }
-        if (tid < m) { pl.bcnt[tid] = bb.count(); pl.bwt[tid] = bb.weight; }
+        if (ttid < m) { pl.bcnt[ttid] = bb.count(); pl.bwt[ttid] = bb.weight; }
     }
     patch_sync<ONE>();
     if (tid == 0) IPP_MARK(item, 4);
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
                 const int dr = div_small(i, lw), dc = i - dr * lw;
                 lut_dst[i] = matern_f(dr, dc, s3, h.sv);
             }
-            if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
+            if (ttid >= 0 && ttid < f) { const int ky = div_small(ttid, h.w); pl.ktab[ttid] = matern_d(ky, ttid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
         if (any0) gather_store(rc0, k0, on0, lane, l0);

@@ -207,16 +207,18 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
         bal[j] = __ballot(con[j]);
         if (lane == 0) wcnt[j * NW + wave] = __popcll(bal[j]);
     }
-    if (tid < MC) {  // measurement blocks of the footprint as flat (cell, weight) tables
-        const Block bb = block_of(min(tid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
+    constexpr int TW = (NW > 2) ? 2 : 1;  // the wave that fills the small per-item tables (k_step_patch.h)
+    const int ttid = tid - kWave * TW;
+    if (ttid >= 0 && ttid < MC) {  // measurement blocks of the footprint as flat (cell, weight) tables
+        const Block bb = block_of(min(ttid, m - 1), h.nx, h.rf, h.w, h.h);  // sensor_models.py:57-79
         for (int a = 0; a < 4; ++a) {
             const int aa = min(a, bb.count() - 1);
             const int ly = bb.y0 + blk_dy(aa, bb.bw), lx = bb.x0 + blk_dx(aa, bb.bw);
-            lds.fb_yx[4 * tid + a] = (h.yu + ly) | ((h.xl + lx) << 16);  // grid row | grid column << 16 (k_step_patch.h)
-            lds.fb_w[4 * tid + a] = (tid < m && a < bb.count()) ? (float)bb.weight : 0.f;
-            if (tid < m) pl.bfi[4 * tid + a] = bfi_pack(ly, lx, h.w);
+            lds.fb_yx[4 * ttid + a] = (h.yu + ly) | ((h.xl + lx) << 16);  // grid row | grid column << 16 (k_step_patch.h)
+            lds.fb_w[4 * ttid + a] = (ttid < m && a < bb.count()) ? (float)bb.weight : 0.f;
+            if (ttid < m) pl.bfi[4 * ttid + a] = bfi_pack(ly, lx, h.w);
         }
-        if (tid < m) { pl.bcnt[tid] = bb.count(); pl.bwt[tid] = bb.weight; }
+        if (ttid < m) { pl.bcnt[ttid] = bb.count(); pl.bwt[ttid] = bb.weight; }
     }
     __syncthreads();
     if (tid == 0) IPP_MARK(item, 4);
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
                 const int dr = div_small(i, lw), dc = i - dr * lw;
                 lds.lut[i] = matern_f(dr, dc, s3, h.sv);
             }
-            if (tid < f) { const int ky = div_small(tid, h.w); pl.ktab[tid] = matern_d(ky, tid - ky * h.w, v.res, sv_d, ls_d); }
+            if (ttid >= 0 && ttid < f) { const int ky = div_small(ttid, h.w); pl.ktab[ttid] = matern_d(ky, ttid - ky * h.w, v.res, sv_d, ls_d); }
         }
         if (tid == 0) IPP_MARK(item, 5);
         if (any0) gather_store(rc0, off0, on0, lane, l0);
