@@ -542,8 +542,10 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
     planning/mcts_zero/mcts.py:83-296) with a stubbed network (uniform priors, constant value): 1024 roots x 256
     simulations on 200x200.  driver="device": selection, valid sets, expansion and backup in csrc/k_mcts.h (DeviceMCTS, one
     wavefront per root); driver="host": the same search with selection and bookkeeping in NumPy, vectorised over the roots
-    (VectorMCTS; host-bound, kept for comparison).  Either way every covariance step runs on the device in per-level
-    ipp_tree_step launches shared by all roots."""
+    (VectorMCTS; host-bound, kept for comparison).  Either way every covariance step runs on the device in ipp_tree_step
+    launches shared by all roots (device driver: ONE launch per wave of simulations; host driver: one per tree level).
+    seconds_per_search returns the policies in the reference's format (per-root dicts); seconds_per_search_device_policies leaves
+    them on the device as [roots, kmax] arrays (get_policy(as_arrays=True))."""
     from ipp_rl_amd import EngineConfig, IPPEngine
     from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
     from ipp_rl_amd.planning.mcts_zero.vector_mcts import VectorMCTS
@@ -581,6 +583,14 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
     dt = time.perf_counter() - t0
     ok = all(o is not None and abs(sum(o[0].values() if isinstance(o[0], dict) else o[0]) - 1.0) < 1e-9 for o in out)
     st = dict(mcts.stats)
+    dt_arrays = None
+    if driver == "device":
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        arr = mcts.get_policy(list(range(roots)), prev, [100.0] * roots, as_arrays=True)
+        torch.cuda.synchronize()
+        dt_arrays = time.perf_counter() - t0
+        ok = ok and bool((arr["ok"] == 1).all().item()) and bool(((arr["policy"].sum(dim=1) - 1.0).abs() < 1e-9).all().item())
     eng.close()
     del eng, mcts
     torch.cuda.empty_cache()
@@ -588,7 +598,8 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
         "PUCT / backup on the host, vectorised over the roots (host-bound)"
     return {"name": f"BASELINE configs[4] through the tree-search driver: {roots} roots x {sims} simulations ({in_flight} in flight per "
                     f"root), {grid}x{grid}, horizon {horizon}, stubbed network; {where}",
-            "value": roots * sims / dt, "unit": "simulations/s", "seconds_per_search": dt, "device_tree_steps": st["device_steps"],
+            "value": roots * sims / dt, "unit": "simulations/s", "seconds_per_search": dt, "seconds_per_search_device_policies": dt_arrays,
+            "device_tree_steps": st["device_steps"],
             "launches": st["launches"], "nodes": st["nodes"], "inferences": st["inferences"], "all_policies_valid": ok}
 
 
@@ -775,10 +786,11 @@ def main(argv=None):
                 extra.append(extra_record(name, r, kw["envs_local"]))
             except Exception as exc:
                 extra.append({"name": name, "error": repr(exc)})
-        try:
-            extra.append(run_tree_wave(torch, device))
-        except Exception as exc:
-            extra.append({"name": "BASELINE configs[4] tree wave", "error": repr(exc)})
+        for w in (4, 8):  # (simulations of a root per launch: 4096 / 8192 items, as the device search has them in flight)
+            try:
+                extra.append(run_tree_wave(torch, device, wave=w))
+            except Exception as exc:
+                extra.append({"name": "BASELINE configs[4] tree wave", "error": repr(exc)})
         # (4 simulations in flight per root is what the parity tests pin; 8 halves the launches: the virtual visits keep the
         # descents apart either way, and 1 reproduces the reference's sequential search)
         for drv, w in (("device", 4), ("device", 8), ("host", 4)):

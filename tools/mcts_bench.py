@@ -21,4 +21,4 @@ ap.add_argument("--in-flight", type=int, default=4)
 a = ap.parse_args()
 for _ in range(a.reps):
     r = bench.run_mcts_driver(torch, torch.device("cuda:0"), grid=a.grid, roots=a.roots, sims=a.sims, driver=a.driver, in_flight=a.in_flight)
-    print(json.dumps({k: r[k] for k in ("value", "seconds_per_search", "device_tree_steps", "launches", "nodes", "all_policies_valid")}))
+    print(json.dumps({k: r[k] for k in ("value", "seconds_per_search", "seconds_per_search_device_policies", "device_tree_steps", "launches", "nodes", "all_policies_valid")}))
