@@ -314,10 +314,15 @@ class VectorMCTS(BatchedMCTS):
         if st.any():
             ids = self.pool.allocate(int(st.sum()))
             new_ids[st] = np.atleast_1d(ids)
-        reward, status = self.engine.tree_step(roots_np[js], paths, acts, prevs, new_ids=new_ids, adaptive=self.adaptive,
-                                               use_flight_time=self.uav is not None)
-        r = reward.detach().cpu().numpy().astype(np.float64)
-        stt = status.detach().cpu().numpy()
+        rs, sts = [], []
+        step = int(getattr(self.engine, "max_batch", n) or n)
+        for lo in range(0, n, step):  # (a level of many simulations in flight can exceed the engine's launch size)
+            hi = min(n, lo + step)
+            reward, status = self.engine.tree_step(roots_np[js[lo:hi]], paths[lo:hi], acts[lo:hi], prevs[lo:hi], new_ids=new_ids[lo:hi],
+                                                   adaptive=self.adaptive, use_flight_time=self.uav is not None)
+            rs.append(reward.detach().cpu().numpy().astype(np.float64))
+            sts.append(status.detach().cpu().numpy())
+        r, stt = np.concatenate(rs), np.concatenate(sts)
         if np.any(stt != 0):
             raise RuntimeError(f"ipp_tree_step reported status {stt[stt != 0][:4]} (rank_cap / footprint)")
         self.stats["device_steps"] += n

@@ -254,8 +254,10 @@ def _search_setup(dim, R, sims, horizon, eps, node_slack=8, max_dist=11.5):
     return eng, prev, hyper, meta
 
 
-@pytest.mark.parametrize("max_dist", [11.5, 19.5])  # rows of 162 (edge rows in registers) / 338 valid actions (general kernel)
-def test_device_search_builds_the_same_trees_as_the_host_driver(max_dist):
+# rows of 162 (edge rows in registers) / 338 valid actions (general kernel); 16 in flight: more recorded steps than a wave has lanes (the
+# serial backup kernel) and more requests per wave of simulations than the engine's max_batch (launched in chunks after the read-back)
+@pytest.mark.parametrize("max_dist,W", [(11.5, 4), (19.5, 4), (11.5, 16)])
+def test_device_search_builds_the_same_trees_as_the_host_driver(max_dist, W):
     """DeviceMCTS (selection, valid sets, expansion, backup in csrc/k_mcts.h; one wavefront per root) against VectorMCTS on
     the same device states: identical root statistics with lowest-index tie-breaking -- 16 roots x 48 simulations, 4 in
     flight per root, values from a 'network' that is asked with tensors (the value depends on the leaf's valid set).
@@ -282,9 +284,9 @@ def test_device_search_builds_the_same_trees_as_the_host_driver(max_dist):
         assert bool((vi[:, 1:][vi[:, 1:] >= 0] > vi[:, :-1][vi[:, 1:] >= 0]).all())  # ascending action indices
         return None, 0.05 * torch.remainder(K, 7.0) + 0.3
 
-    a = VectorMCTS(eng, hyper, meta, infer_host, sims_in_flight=4, tie_break="first")
+    a = VectorMCTS(eng, hyper, meta, infer_host, sims_in_flight=W, tie_break="first")
     out_a = a.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
-    b = DeviceMCTS(eng, hyper, meta, infer_dev, sims_in_flight=4, tie_break="first")
+    b = DeviceMCTS(eng, hyper, meta, infer_dev, sims_in_flight=W, tie_break="first")
     out_b = b.get_policy(roots, prev, [60.0] * R, rngs=[np.random.RandomState(7 + r) for r in roots])
     idx_b, nsa_b, q_b = b.root_statistics()
     for j in roots:
@@ -293,7 +295,8 @@ def test_device_search_builds_the_same_trees_as_the_host_driver(max_dist):
         assert K == int(b.n_K[j]) and np.array_equal(a.t_idx[rt, :K], idx_b[j, :K])
         assert np.array_equal(a.t_Nsa[rt, :K], nsa_b[j, :K]), (j, a.t_Nsa[rt, :K], nsa_b[j, :K])
         assert np.max(np.abs(a.t_Qsa[rt, :K] - q_b[j, :K])) < 1e-6
-        assert np.allclose(out_a[j][0], out_b[j][0], atol=1e-9)
+        if W == 4:  # (16 in flight leave several equally most-visited actions at a root: the read-out then DRAWS the one it keeps, and the
+            assert np.allclose(out_a[j][0], out_b[j][0], atol=1e-9)  # host driver's generators have been used by its search; trees only)
     assert a.stats["nodes"] == b.stats["nodes"] and a.stats["device_steps"] == b.stats["device_steps"]
     assert a.stats["inferences"] == b.stats["inferences"] == sum(asked)
     # a second search on the same object starts from clean tables and gives the same result
