@@ -32,6 +32,10 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg
 # configs[4]: the tree wave (k_tree_patch) and the device-side search (k_mcts_*)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tree -o kt -- python3 tools/tree_wave.py --reps 2 > $O/trace_tree.log 2>&1; tail -1 $O/trace_tree.log | cut -c1-300
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_mcts -o kt -- python3 tools/mcts_bench.py --reps 2 > $O/trace_mcts.log 2>&1; tail -1 $O/trace_mcts.log | cut -c1-300
+# one search of 1024 roots x 256 simulations, 8 in flight: host times, then kernels and gaps of the last search from a kernel trace
+{ timeout 300 python tools/mcts_readout.py 8 2>&1 | grep -v amdgpu.ids | head -2
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_search -o kt -- python3 tools/mcts_readout.py 8 > /dev/null 2>&1
+  python tools/mcts_trace.py $O/trace_search; } > $O/mcts_trace.txt 2>&1; head -9 $O/mcts_trace.txt
 # PMC passes (separate runs, counters only)
 bash tools/pmc_run.sh $O/pmc --parts 1 > $O/pmc_run.log 2>&1
 python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json

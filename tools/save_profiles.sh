@@ -17,5 +17,5 @@ cp $R/timeline.txt $P/${tag}_timeline.txt
 cp $R/write_probe_calibration.txt $P/${tag}_write_probe_calibration.txt
 grep -v amdgpu.ids $R/extras.txt > $P/${tag}_extras.txt
 tail -3 $R/pytest_gpu.log > $P/${tag}_pytest_gpu.txt
-for f in issue_probe prio_probe ab_parts trace_overlap parts_probe grf_bench region_sweep ab_split timeline_split; do [ -f $R/$f.txt ] && grep -v amdgpu.ids $R/$f.txt > $P/${tag}_$f.txt; done
+for f in issue_probe prio_probe ab_parts trace_overlap parts_probe grf_bench region_sweep ab_split timeline_split mcts_trace; do [ -f $R/$f.txt ] && grep -v amdgpu.ids $R/$f.txt > $P/${tag}_$f.txt; done
 ls -la $P | grep ${tag}_

@@ -1,7 +1,7 @@
 """Per-item timeline of the partitioned schedule in steady state (IPP_TIMELINE build, `make -C ipp-rl_amd/csrc timeline`):
 VecIPPEnv(parts=P) at configs[1], a few hundred async steps, then the marks of every item's LAST step (100 MHz wall
 clock): item durations, phases, and how many workgroup slots are taken over time.
-    IPP_HIP_LIB=tools/probes/libipp_timing.so python tools/timeline_parts.py [parts] [episode_steps]"""
+    IPP_HIP_LIB=tools/probes/libipp_timing.so python tools/timeline_parts.py [parts] [episode_steps] [grid] [envs]"""
 import os
 import sys
 
@@ -16,8 +16,9 @@ from ipp_rl_amd.vec_env import VecIPPEnv, cell_centre_actions
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-B = 4096
-cfg = EngineConfig(x_dim=50, y_dim=50)
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+cfg = EngineConfig(x_dim=G, y_dim=G)
 ALTS = [float(a) for a in range(5, 15)]
 env = VecIPPEnv(cfg, B, episode_steps=T, stagger=True, window_rows=-1, seed=1, parts=P)
 env.reset()
