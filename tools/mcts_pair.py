@@ -17,6 +17,7 @@ from ipp_rl_amd.vec_env import cell_centre_actions
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 R_all = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+NG = int(sys.argv[3]) if len(sys.argv) > 3 else 2  # groups of roots (one engine and one stream each)
 grid, sims, root_steps, horizon = 200, 256, 3, 5
 cfg = EngineConfig(x_dim=grid, y_dim=grid)
 hyper = dict(gamma=1.0, puct_init=15.0, puct_base=10000.0, forced_playout_factor=2.0, max_valid_action_distance=11.5,
@@ -97,16 +98,18 @@ def pick_two(eng):
             continue
         if all(eng.probe_stream_pair(st, g, 12) <= thr for g in got):
             got.append(st)
-        if len(got) == 2:
+        if len(got) == NG:
             break
+    while len(got) < NG:  # (fewer hardware queues than groups: the rest share)
+        got.append(got[len(got) % max(1, len(got))] if got else main)
     return got
 
 
 whole = make(R_all, 9)
-A, B = make(R_all // 2, 9), make(R_all // 2, 11)
+groups = [make(R_all // NG, 9 + 2 * g) for g in range(NG)]
 torch.cuda.synchronize()
-streams = pick_two(A[0])
-assert len(streams) == 2, "no two free hardware queues"
+streams = pick_two(groups[0][0])
+print(f"{len(set(id(x) for x in streams))} distinct streams for {NG} groups", flush=True)
 for rep in range(3):
     s0 = Search(whole, streams[0])
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -114,20 +117,22 @@ for rep in range(3):
     while s0.wave():
         pass
     torch.cuda.synchronize(); t_whole = time.perf_counter() - t0
-    sa, sb = Search(A, streams[0]), Search(B, streams[0])
+    ss = [Search(g, streams[0]) for g in groups]
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for s in (sa, sb):
+    for s in ss:
         s.begin()
         while s.wave():
             pass
     torch.cuda.synchronize(); t_seq = time.perf_counter() - t0
-    sa, sb = Search(A, streams[0]), Search(B, streams[1])
+    ss = [Search(g, st) for g, st in zip(groups, streams)]
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    sa.begin(); sb.begin()
+    for s in ss:
+        s.begin()
     more = True
     while more:
-        ma = sa.wave(); mb = sb.wave()
-        more = ma or mb
+        more = False
+        for s in ss:
+            more = s.wave() or more
     torch.cuda.synchronize(); t_pair = time.perf_counter() - t0
-    print(f"{W} in flight, {sims} simulations: one search of {R_all} roots {t_whole * 1e3:.1f} ms | two of {R_all // 2} one after the other {t_seq * 1e3:.1f} ms | "
-          f"alternating on two queues {t_pair * 1e3:.1f} ms", flush=True)
+    print(f"{W} in flight, {sims} simulations: one search of {R_all} roots {t_whole * 1e3:.1f} ms | {NG} of {R_all // NG} one after the other {t_seq * 1e3:.1f} ms | "
+          f"alternating on {NG} queues {t_pair * 1e3:.1f} ms", flush=True)
