@@ -36,7 +36,7 @@ for t in range(root_steps):
     a = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
     eng.step(a, prev, meas_noise=noise[t])
     prev = a
-m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break="random", leaf_value=0.3)
+m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break=os.environ.get("TIE", "random"), leaf_value=0.3)
 roots, budgets = list(range(R)), [100.0] * R
 for _ in range(2):
     m.get_policy(roots, prev, budgets)
