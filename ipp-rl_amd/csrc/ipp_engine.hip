@@ -462,7 +462,12 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
             else if (e->patch_waves == 4)
                 timed_launch(e, 0, k_step_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else if (e->patch_waves == 3)
-                timed_launch(e, 0, k_step_patch<3>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                if (v.rank_cap <= 192)       // (rounds of 192 threads over the columns' rectangles: k_step_patch.h, RJN)
+                    timed_launch(e, 0, k_step_patch<3, kPatchKP, kPatchMinW, false, 1>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                else if (v.rank_cap <= 384)
+                    timed_launch(e, 0, k_step_patch<3, kPatchKP, kPatchMinW, false, 2>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
+                else
+                    timed_launch(e, 0, k_step_patch<3>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else if (e->big_min_items > 0 && n >= e->big_min_items) {
                 View vb = v;  // (six waves per SIMD pay once a launch is many rounds of workgroups: k_step_patch.h)
                 vb.pcap = e->pcap_big;
@@ -932,6 +937,8 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3, kPatchKP, kPatchMinW, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3, kPatchKP, kPatchMinW, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<2, IPP_PATCH_BIGKP, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<1, kPatchKP, kSplitMinWP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
@@ -939,6 +946,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_patch<3, kPatchKP, kSplitMinWP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<3>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_patch<4>), hipFuncAttributeMaxDynamicSharedMemorySize, pl);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grf_conv<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
@@ -1342,7 +1350,9 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
         const int nw = e->patch_waves >= 2 ? e->patch_waves : 2;
         const size_t tlds = PatchLds::bytes(v.pcap, v.plw * v.plw, nw, v.punits, v.rank_cap);
         const TreeEdgeOut eo = edge_out ? *edge_out : TreeEdgeOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-        if (nw == 3)
+        if (nw == 3 && v.rank_cap <= 192)
+            timed_launch(e, 0, k_tree_patch<3, 1>, dim3(n), dim3(192), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);
+        else if (nw == 3)
             timed_launch(e, 0, k_tree_patch<3>, dim3(n), dim3(192), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);
         else if (nw == 4)
             timed_launch(e, 0, k_tree_patch<4>, dim3(n), dim3(256), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);

@@ -177,14 +177,17 @@ __device__ __forceinline__ void patch_sync() {
 
 // (KPN = 4 rows per request group: 12 workgroups of two waves per CU, 5 % faster for launches of 32768 items and 27 % slower for 4096
 // -- two-wave engines take it for large launches only, ipp_info.patch_big_min_items)
-template <int NW, int KPN = kPatchKP, int MINW = kPatchMinW, bool SPLIT = false>
+// RJN: rounds of NW x 64 threads over the columns' rectangles (tests, compaction); 0 = enough for kPatchMaxRank.  An engine whose rank_cap
+// fits fewer rounds runs the instantiation without the empty ones (configs[2]: 1 of 3, the headline: 2 of 3 -- they are predicated
+// instructions otherwise, 2-3 % of an item's at configs[2], whose step is bound by the vector units).
+template <int NW, int KPN = kPatchKP, int MINW = kPatchMinW, bool SPLIT = false, int RJN = 0>
 __global__ __launch_bounds__(64 * NW, MINW) void k_step_patch(
     View v, const int* __restrict__ env_ids, int n_items, const double* __restrict__ action,
     const double* __restrict__ prev_action, const float* __restrict__ meas_noise, unsigned flags,
     int* __restrict__ status_out, float* __restrict__ reward_out, AutoReset ar) {
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = KPN;
     static_assert(KPN <= kPatchKP, "the row lists are padded for kPatchKP entries");
-    constexpr int RJ = (kPatchMaxRank + NT - 1) / NT;      // rectangles per thread, loaded with the inputs
+    constexpr int RJ = RJN > 0 ? RJN : (kPatchMaxRank + NT - 1) / NT;  // rectangles per thread, loaded with the inputs
     constexpr int OW = (NW > 1) ? 1 : 0;                   // the wave that evaluates the observation
     constexpr int TW = (NW > 2) ? 2 : OW;                  // the wave that fills the small per-item tables (block cells, fp64 prior of the footprint)
     constexpr bool ONE = (NW == 1);

@@ -77,7 +77,7 @@ struct TreeEdgeOut {
     double* t_num; int* err; int kmax;                    // t_num == nullptr: off
 };
 
-template <int NW>
+template <int NW, int RJN = 0>  // (RJN: k_step_patch.h)
 __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
     int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     // n_dev: the item count lives on the device (ipp_mcts_level_steps with n < 0: the search driver queues the levels of a
     // wave of simulations without reading their request counts back); the grid then has n_items >= *n_dev workgroups
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
-    constexpr int RJ = (kPatchMaxRank + NT - 1) / NT;
+    constexpr int RJ = RJN > 0 ? RJN : (kPatchMaxRank + NT - 1) / NT;
     static_assert(NW >= 2 && NW <= 4, "two to four waves per item");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tp2[];
     const PatchLds lds(smem_tp2, v.pcap, v.plw * v.plw, NW, v.punits, v.rank_cap);
