@@ -39,6 +39,16 @@ def main():
         print(f"[{n}x{n}, {fields} fields] {ms:.3f} ms per call, {fields / ms * 1e3:.3e} fields/s, "
               f"{2 * fma / ms / 1e9:.1f} fp64 TFLOP/s on the 3 n^3 FMA count"
               + (f", {2 * gemm / ms / 1e9:.1f} TFLOP/s on the padded GEMMs" if gemm else ""))
+        # the same with the white noise drawn inside the generator (what the batched env driver runs)
+        if eng.generate_grf_rows(fields, 3, 1 << 40, out):
+            for _ in range(3):
+                eng.generate_grf_rows(fields, 3, 1 << 40, out)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.generate_grf_rows(fields, 3, 1 << 40, out)
+            torch.cuda.synchronize()
+            print(f"    noise drawn in the kernel: {1e3 * (time.perf_counter() - t0) / reps:.3f} ms per call")
         eng.close()
 
 
