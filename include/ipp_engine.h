@@ -323,6 +323,10 @@ typedef struct ipp_mcts_tables {
     double* rq_cost; double* rq_prev; double* rq_action; int32_t* rq_count;  /* rq_count [1] */
     int32_t* ts_paths; float* ts_reward; int32_t* ts_status;
     int32_t* err;                /* [4] node range / device-node range exhausted, tree-step status, kmax too small */
+    /* optional (NULL / 0: evaluated in the kernel): the two factors of the PUCT prior that depend on a node's visit count only,
+     * for Ns = 0 .. ns_table_n - 1 -- puct_c[Ns] = puct_init + log((Ns + puct_base + 1) / puct_base), sqrt_ns1[Ns] = sqrt(Ns + 1)
+     * (mcts.py:280-296), tabulated by the host: an fp64 log and a square root per tree level of every descent otherwise */
+    const double* puct_c; const double* sqrt_ns1; int64_t ns_table_n;
 } ipp_mcts_tables;
 
 /* W descents per root (virtual visits between them), from waypoint prev0[j] with budget0[j] at tree depth `depth`;

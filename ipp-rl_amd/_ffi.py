@@ -80,6 +80,7 @@ class IppMctsTables(C.Structure):
         ("rq_child", _P), ("rq_newdev", _P), ("rq_cost", _P), ("rq_prev", _P),
         ("rq_action", _P), ("rq_count", _P), ("ts_paths", _P), ("ts_reward", _P),
         ("ts_status", _P), ("err", _P),
+        ("puct_c", _P), ("sqrt_ns1", _P), ("ns_table_n", C.c_int64),
     ]
 
 # name -> (restype, argtypes); exactly the symbols include/ipp_engine.h declares

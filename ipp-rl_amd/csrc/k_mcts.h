@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                 }
             }
             const int pv = lane < kMctsPath ? m.n_devpath[(size_t)kMctsPath * cur + lane] : -1;  // (this node's device path: lanes 0..5)
+            // the factors of the prior that depend on Ns only: from the host's table when it reaches (requested with the rows)
+            double pc_ld, sq_ld;
+            {
+                const long long nsi = (long long)ns;
+                if (m.puct_c && nsi >= 0 && nsi < m.ns_table_n && (double)nsi == ns) { pc_ld = m.puct_c[nsi]; sq_ld = m.sqrt_ns1[nsi]; }
+                else { pc_ld = m.puct_init + log((ns + m.puct_base + 1) / m.puct_base); sq_ld = sqrt(ns + 1); }
+            }
             double lo = INFINITY, hi = -INFINITY;
             int nz = 0;
             if (NE > 0) {
@@ -156,14 +163,17 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             }
             MC_STAMP(1);
             if (K < m.num_actions) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); }  // the zeros of the invalid actions take part (mcts.py:267-278)
-            const bool allzero = nz == 0;
-            const double pc = m.puct_init + log((ns + m.puct_base + 1) / m.puct_base);
-            const double sq = sqrt(ns + 1);
+            // (wave-uniform facts as scalars: the compiler then branches instead of evaluating every form of qn -- two fp64 divisions
+            // per edge -- and selecting)
+            const bool allzero = __builtin_amdgcn_readfirstlane(nz) == 0;
+            const bool flat = __builtin_amdgcn_readfirstlane((int)(lo == hi)) != 0;
+            const double pc = pc_ld, sq = sq_ld;  // (requested with the rows)
             const bool force = d == 0;
             double best = -INFINITY, best_u = -1.0, best_nsa = 0.0;
             int best_k = 0x7fffffff, best_a = -1, best_c = -2;  // (best_c = -2: not loaded with the rows)
             auto consider = [&](int k, double q, double nsa, double ps, int ai, int ci) {
-                const double qn = allzero ? q : ((lo == hi) ? q / hi : (q - lo) / (hi - lo));
+                double qn = q;
+                if (!allzero) { if (flat) qn = q / hi; else qn = (q - lo) / (hi - lo); }
                 double uct = qn + pc * (ps * (sq / (1 + nsa)));
                 if (force) {
                     double nfp = ceil(sqrt(m.fpf * ps * ns));

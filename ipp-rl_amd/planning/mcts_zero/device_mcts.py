@@ -121,6 +121,12 @@ class DeviceMCTS(VectorMCTS):
         for name, buf in b.items():
             if name != "counts":
                 setattr(tab, name, buf.data_ptr())
+        # the Ns-only factors of the PUCT prior, tabulated with NumPy (the arithmetic VectorMCTS._uct_rows does per node): a node is
+        # visited at most once per simulation, virtual visits included
+        ns = np.arange(self.num_simulations + W + 8, dtype=np.float64)
+        self._ns_tables = (torch.as_tensor(self.puct_init + np.log((ns + self.puct_base + 1) / self.puct_base), device=dev),
+                           torch.as_tensor(np.sqrt(ns + 1), device=dev))
+        tab.puct_c, tab.sqrt_ns1, tab.ns_table_n = self._ns_tables[0].data_ptr(), self._ns_tables[1].data_ptr(), len(ns)
         tab.pend_count = b["counts"].data_ptr()
         tab.rq_count = b["counts"].data_ptr() + 4 * R
         self._tab, self._buf, self._tab_roots, self._tab_depth = tab, b, R, D

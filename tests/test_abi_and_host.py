@@ -54,14 +54,14 @@ def test_struct_layouts_match_header_order():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for stmt in body.split(";"):
-        m = re.match(r"\s*(?:const\s+)?(int32_t|double|uint64_t|uint8_t|float)\s*(\*?)\s*(.*)", stmt, flags=re.S)
+        m = re.match(r"\s*(?:const\s+)?(int32_t|int64_t|double|uint64_t|uint8_t|float)\s*(\*?)\s*(.*)", stmt, flags=re.S)
         if not m or not m.group(3).strip():
             continue
         for name in m.group(3).split(","):
             is_ptr = bool(m.group(2)) or name.strip().startswith("*")
-            fields.append((name.strip().lstrip("*").strip(), ctypes.c_void_p if is_ptr else {"int32_t": ctypes.c_int32, "double": ctypes.c_double}[m.group(1)]))
+            fields.append((name.strip().lstrip("*").strip(), ctypes.c_void_p if is_ptr else {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "double": ctypes.c_double}[m.group(1)]))
     assert fields == list(_ffi.IppMctsTables._fields_)
-    assert ctypes.sizeof(_ffi.IppMctsTables) == 16 * 4 + 8 * 8 + 46 * 8
+    assert ctypes.sizeof(_ffi.IppMctsTables) == 16 * 4 + 8 * 8 + 46 * 8 + 2 * 8 + 8  # (.. + the optional Ns tables and their length)
 
 
 def test_arena_sizing_and_validation_without_gpu():
