@@ -117,6 +117,80 @@ def maybe_self_launch(args, argv):
     sys.exit(proc.returncode)
 
 
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every AMD display / processing-accelerator PCI function, in PCI address order (= the HIP device order on one
+    node unless HIP_VISIBLE_DEVICES reorders it); -1 where the platform does not say.  Reads sysfs only: no GPU call."""
+    import glob
+
+    nodes = []
+    for dev in sorted(glob.glob(os.path.join(sysfs, "bus/pci/devices/*"))):
+        try:
+            with open(os.path.join(dev, "vendor")) as fh:
+                if fh.read().strip() != "0x1002":
+                    continue
+            with open(os.path.join(dev, "class")) as fh:
+                cls = fh.read().strip()
+            if not (cls.startswith("0x03") or cls.startswith("0x12")):
+                continue
+            with open(os.path.join(dev, "numa_node")) as fh:
+                nodes.append(int(fh.read().strip()))
+        except (OSError, ValueError):
+            continue
+    return nodes
+
+
+def plan_rank_cores(local_rank, local_world, allowed, gpu_nodes=None, node_cpus=None):
+    """The cores rank `local_rank` of `local_world` ranks on this node pins itself to: DISJOINT sets; when the platform tells which
+    NUMA node each GPU hangs on (gpu_nodes[i], node_cpus[node]), a rank takes its share of ITS GPU's node -- the ranks of one node
+    split that node's allowed cores evenly -- else an even contiguous split of the allowed cores.  Returns (cores, how)."""
+    allowed = sorted(allowed)
+    if local_world <= 1 or len(allowed) < local_world:
+        return allowed, "all allowed cores (one rank, or fewer cores than ranks)"
+    if gpu_nodes and node_cpus and len(gpu_nodes) >= local_world and all(n >= 0 for n in gpu_nodes[:local_world]):
+        mine = gpu_nodes[local_rank]
+        peers = [r for r in range(local_world) if gpu_nodes[r] == mine]
+        cpus = [c for c in node_cpus.get(mine, []) if c in set(allowed)]
+        if len(cpus) >= len(peers):
+            k, per = peers.index(local_rank), len(cpus) // len(peers)
+            return cpus[k * per:(k + 1) * per], f"NUMA node {mine} of GPU {local_rank}: share {k} of {len(peers)}"
+    per = len(allowed) // local_world
+    return allowed[local_rank * per:(local_rank + 1) * per], "even contiguous split (no NUMA information)"
+
+
+def pin_rank(local_rank, local_world):
+    """Pins this process (before anything touches the GPU or starts a thread pool) to its cores; the report goes on the line.
+    At 8 ranks the value is the MAX over ranks of a host-issued loop: a rank whose Python thread is descheduled or migrated across
+    sockets is the job's number.  IPP_BENCH_PIN=0: leave the affinity alone."""
+    if local_world <= 1 or os.environ.get("IPP_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False, "cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    allowed = os.sched_getaffinity(0)
+    node_cpus = {}
+    try:
+        import glob
+
+        for nd in glob.glob("/sys/devices/system/node/node[0-9]*"):
+            with open(os.path.join(nd, "cpulist")) as fh:
+                node_cpus[int(os.path.basename(nd)[4:])] = _parse_cpulist(fh.read())
+    except (OSError, ValueError):
+        node_cpus = {}
+    cores, how = plan_rank_cores(local_rank, local_world, allowed, gpu_numa_nodes(), node_cpus)
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError as exc:
+        return {"pinned": False, "cores": len(allowed), "error": repr(exc)}
+    return {"pinned": True, "cores": len(cores), "first_core": min(cores), "how": how}
+
+
 def shard_plan(args, rank, world):
     """Contiguous env-id range of `rank`: weak scaling = args.envs per rank, strong scaling
     (--envs-total) = the total split evenly.  Returns (lo, hi, total_envs, scaling)."""
@@ -167,6 +241,17 @@ class Ranks:
         self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
         return [float(x.item()) for x in out], float(tmax.item())
 
+    def gather(self, x: float):
+        """[x of every rank] (one small all_gather, outside every timed region)."""
+        if self.dist is None:
+            return [float(x)]
+        import torch
+
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device or "cpu")
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(v.item()) for v in out]
+
     def all_agree(self, flag: bool) -> bool:
         """True iff `flag` holds on EVERY rank (a choice that changes how many collectives a rank enters must be the same everywhere)."""
         if self.dist is None:
@@ -186,17 +271,21 @@ class Ranks:
 
 def timed_region(run_steps, steps, sync, ranks, info=None):
     """Time EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns (per-rank seconds,
-    max over ranks).  info (optional list): receives this rank's host time to ISSUE the steps (before the closing sync)."""
+    max over ranks).  info (optional list): receives this rank's (host time to ISSUE the steps -- before the closing sync --,
+    time until its OWN device had finished them -- before the closing barrier).  The per-rank seconds include the wait at that
+    barrier, so they are nearly equal on every rank: which rank the job waited for is in the second figure."""
     sync()
     ranks.barrier()
     sync()
     t0 = time.perf_counter()
     run_steps(steps)
-    if info is not None:
-        info.append(time.perf_counter() - t0)
+    t_issue = time.perf_counter() - t0
     sync()
+    t_own = time.perf_counter() - t0
     ranks.barrier()
     sync()
+    if info is not None:
+        info.append((t_issue, t_own))
     return ranks.all_times(time.perf_counter() - t0)
 
 
@@ -363,6 +452,10 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     issue_s = []  # host time to issue a region's steps (the launches queue up behind the device: issue time < region time = device-bound)
     timed_regions = [timed_region(run_steps, steps, sync_all, ranks, issue_s) for _ in range(max(1, regions))]
     per_rank, elapsed_max = median_region(timed_regions)
+    # every rank's host time to issue a step (median region): at N ranks the slowest HOST loop can be what the MAX over ranks reports
+    med = lambda xs: sorted(xs)[len(xs) // 2]  # noqa: E731
+    issue_per_rank = ranks.gather(1e3 * med([i for i, _ in issue_s]) / steps)
+    own_per_rank = ranks.gather(1e3 * med([o for _, o in issue_s]) / steps)  # (without the wait for the other ranks at the closing barrier)
     sync_regions = None
     if use_parts:
         env.wait()
@@ -435,7 +528,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "grid": grid, "envs_local": B, "episode_steps": T, "state": state, "predict_only": bool(predict_only),
         "window_rows": int(eng.info.window_rows), "tile_threads": int(eng.info.tile_threads),
         "per_rank_s": per_rank, "elapsed_max_s": elapsed_max, "steps": steps, "warmup": warmup,
-        "region_elapsed_max_s": [r[1] for r in timed_regions], "region_issue_s": issue_s,
+        "region_elapsed_max_s": [r[1] for r in timed_regions], "region_issue_s": [i for i, _ in issue_s], "issue_ms_per_rank": issue_per_rank, "own_ms_per_rank": own_per_rank,
         "queues": getattr(env, "queue_report", None),
         "split_min_items": int(getattr(eng.info, "patch_split_min_items", 0)),
         "mean_rank_after_step": mean_rank_after, "bad_status": bad, "bad_rewards": bad_rewards,
@@ -446,6 +539,7 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "formula_bytes_per_launch": formula_bytes, "achieved_gbs": achieved,
         "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
         "arena_gb": float(eng.info.arena_bytes) / 1e9,
+        "arena_kind": getattr(eng, "arena_kind", None), "arena_chunk_mib": (getattr(eng.arena, "chunk_bytes", 0) >> 20) or None,
     }
     env.close()
     del env, eng, actions
@@ -642,7 +736,53 @@ def extra_record(name, rec, total_envs):
             "window_rows": rec["window_rows"], "schedule_parts": rec["parts"], "single_launch_ms_avg": rec["single_launch_ms"],
             "sync_schedule": sync_record(rec, total_envs, rec["steps"]),
             "mean_rank_after_step": rec["mean_rank_after_step"], "arena_gb": rec["arena_gb"],
+            "arena_kind": rec["arena_kind"], "arena_chunk_mib": rec["arena_chunk_mib"],
             "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"]}
+
+
+def _config_block(args, rec, B, T, total_envs, pinning):
+    """`config` of the line.  ORDER MATTERS: the driver's parser keeps the first ~20 keys, so the scalars that say whether a run is
+    valid and where its streams / arena / ranks landed come first, prose and lists last."""
+    q = rec["queues"] or {}
+    issue = rec.get("issue_ms_per_rank") or []
+    per_rank = rec["per_rank_s"]
+    own = rec.get("own_ms_per_rank") or []
+    slowest = max(range(len(own)), key=lambda r: own[r]) if own else 0  # (by the time until a rank's OWN device was done)
+    regs = rec["region_elapsed_max_s"]
+    head = {
+        "workload": f"{baseline_config_name(args.grid, B, T, total_envs)}: {B} parallel envs per GPU, {args.grid}x{args.grid} grid, 10 altitude "
+                    f"levels 5-14 m, example.yaml sensor/prior/UAV, GRF ground truth, adaptive reward with "
+                    f"flight-time cost; {'predict-only (reward) calls' if args.predict_only else 'full fused env step (predict + observe + update)'}",
+        "envs_per_gpu": B, "grid": f"{args.grid}x{args.grid}", "episode_steps": T, "window_rows": rec["window_rows"],
+        "schedule_parts": rec["parts"],
+        "arena_kind": rec["arena_kind"], "arena_chunk_mib": rec["arena_chunk_mib"],
+        "queues_n_queues": q.get("n_queues"), "queues_parts_distinct": q.get("parts_distinct"),
+        "queues_staging_shares_a_part_queue": q.get("staging_shares_a_part_queue"),
+        "host_issue_ms_per_step": issue[0] if issue else None,
+        "host_issue_ms_min_over_ranks": min(issue) if issue else None, "host_issue_ms_max_over_ranks": max(issue) if issue else None,
+        "slowest_rank": slowest,
+        "region_ms_min": 1e3 * min(regs) / args.steps, "region_ms_max": 1e3 * max(regs) / args.steps,
+        "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"],
+        "ranks_pinned": bool(pinning.get("pinned")),
+    }
+    rest = {
+        "envs_total": total_envs, "state_repr": args.state, "mean_rank_after_step": rec["mean_rank_after_step"],
+        "tile_threads": rec["workgroup_threads"],
+        "prior": "shuffled per episode (window sized for 1.2 l)" if args.shuffle_prior else "fixed (example.yaml)",
+        "rng": "device Philox4x32-10 keyed on the global env id", "episodes": "staggered (stationary rank mix)",
+        "timed_regions": len(regs), "value_is": "median timed region",
+        "region_ms_first": 1e3 * regs[0] / args.steps,
+        "region_ms_per_step": [1e3 * t / args.steps for t in regs],
+        "per_rank_ms_per_step": [1e3 * t / args.steps for t in per_rank],
+        "per_rank_env_steps_per_s": [B * args.steps / t for t in per_rank],
+        "host_issue_ms_per_rank": issue, "own_ms_per_step_per_rank": own,
+        "rank_pinning": pinning,
+        "split_min_items": rec["split_min_items"],
+        **{"queues_" + k: v for k, v in q.items() if k not in ("n_queues", "parts_distinct", "staging_shares_a_part_queue")},
+        "schedule": schedule_text(rec),
+        "sync_schedule": sync_record(rec, total_envs, args.steps),
+    }
+    return {**head, **rest}
 
 
 def main(argv=None):
@@ -653,9 +793,10 @@ def main(argv=None):
         return
     maybe_self_launch(args, argv)  # N > 1 without a launcher: become the launcher (before any GPU call)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pinning = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))  # before torch / HIP start threads
     import torch
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Test hook for single-GPU boxes (tests/test_hip_bench_launcher.py): IPP_BENCH_SHARE_GPU=1 puts every rank on cuda:0
     # and uses gloo (RCCL refuses two ranks on one device), so that the launcher, the rank plumbing, the shard offsets and
     # the aggregation run end to end; the numbers of such a run mean nothing.
@@ -692,38 +833,18 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": f"{baseline_config_name(args.grid, B, T, total_envs)}: {B} parallel envs per GPU, {args.grid}x{args.grid} grid, 10 altitude "
-                            f"levels 5-14 m, example.yaml sensor/prior/UAV, GRF ground truth, adaptive reward with "
-                            f"flight-time cost; {'predict-only (reward) calls' if args.predict_only else 'full fused env step (predict + observe + update)'}",
-                "envs_per_gpu": B, "envs_total": total_envs, "grid": f"{args.grid}x{args.grid}", "state_repr": args.state,
-                "episode_steps": T, "episode_phase": "staggered (stationary rank mix)",
-                "mean_rank_after_step": rec["mean_rank_after_step"], "tile_threads": rec["workgroup_threads"], "window_rows": rec["window_rows"],
-                "prior": "shuffled per episode (window sized for 1.2 l)" if args.shuffle_prior else "fixed (example.yaml)",
-                "items_with_nonzero_status": rec["bad_status"], "non_finite_rewards": rec["bad_rewards"],
-                "rng": "device Philox4x32-10 keyed on the global env id",
-                "timed_regions": len(rec["region_elapsed_max_s"]),
-                "region_ms_per_step": [1e3 * t / args.steps for t in rec["region_elapsed_max_s"]],
-                "region_ms_per_step_min_max": [1e3 * min(rec["region_elapsed_max_s"]) / args.steps, 1e3 * max(rec["region_elapsed_max_s"]) / args.steps],
-                "value_is": "median of the timed regions (each exactly `steps` steps, max over ranks)",
-                "per_rank_ms_per_step": [1e3 * t / args.steps for t in rec["per_rank_s"]],
-                "per_rank_env_steps_per_s": [B * args.steps / t for t in rec["per_rank_s"]],
-                # flat scalars (a parser that keeps only scalars still sees where the streams landed and how the regions spread)
-                "region_ms_min": 1e3 * min(rec["region_elapsed_max_s"]) / args.steps, "region_ms_max": 1e3 * max(rec["region_elapsed_max_s"]) / args.steps,
-                "region_ms_first": 1e3 * rec["region_elapsed_max_s"][0] / args.steps,
-                "host_issue_ms_per_step": (1e3 * sorted(rec["region_issue_s"])[len(rec["region_issue_s"]) // 2] / args.steps) if rec["region_issue_s"] else None,
-                "schedule_parts": rec["parts"], "split_min_items": rec["split_min_items"],
-                **{"queues_" + k: v for k, v in (rec["queues"] or {}).items()},
-                "schedule": schedule_text(rec),
-                "sync_schedule": sync_record(rec, total_envs, args.steps),
-            },
+            "config": _config_block(args, rec, B, T, total_envs, pinning),
             "roofline": {
                 "bound": "hbm", "achieved": rec["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rec["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_definition": "HBM bytes per step (2 x FETCH_SIZE + WRITE_SIZE, KiB) of the whole batch run as one launch (--parts 1 under --pmc)",
                 "traffic_over_algorithmic": (traffic / rec["bytes_per_launch"]) if traffic and rec["bytes_per_launch"] else None,
+                # the same bytes over the STEP PERIOD of the timed regions (no events attached; every launch of the step, resets and
+                # ground-truth generation inside): kernel <= step holds for this pair, the event leg's kernel_ms_avg can exceed ms_per_step
+                "frac_step_clock": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "step_frac": rec["bytes_per_launch"] / (rec["elapsed_max_s"] / args.steps) / 1e9 / HBM_PEAK_GBS,
-                "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "launches": rec["launches"],
+                "kernel": rec["kernel"], "kernel_ms_avg": rec["kernel_ms"], "kernel_ms_avg_is": "event leg (a HIP-event pair on every dispatch, separate from the timed regions)",
+                "launches": rec["launches"],
                 "kernel_ms_definition": kernel_ms_text(rec), "launches_per_step": rec["parts"],
                 "single_launch_ms_avg": rec["single_launch_ms"],
                 "single_launch_frac": (rec["bytes_per_launch"] / (rec["single_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if rec["single_launch_ms"] else None,
@@ -756,7 +877,7 @@ def main(argv=None):
                 "other_kernels_ms_avg": rec["other_kernels_ms_avg"],
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: at N > 1 the ranks are pinned to their share of the cores)
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, args)
             except Exception as exc:  # the baseline is a reported extra; never lose the GPU line over it

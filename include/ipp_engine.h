@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IPP_ABI_VERSION 13
+#define IPP_ABI_VERSION 14
 
 /* covariance state representation */
 #define IPP_DENSE  0 /* P[N][N] fp32 per env, updated in place (mapping/grid_maps.py:10-11)         */
@@ -189,7 +189,10 @@ int ipp_reset_episode(void* engine, const int32_t* env_ids, int32_t n, const dou
  *               the reset: use it with env_ids == NULL (item == env) unless the two index spaces agree
  *   reset_src   [dev] int32[n]: index into reset_gt, or -1 (no reset); NULL: plain ipp_step
  *   reset_gt    [dev] float[..][H][W] ground-truth fields (e.g. from ipp_generate_grf); NULL: every resetting env takes the field staged
- *               in its alternate plane (ipp_generate_grf_groups with gt_out == NULL) -- a flip, no copy
+ *               in its alternate plane (ipp_generate_grf_groups with gt_out == NULL) -- a flip, no copy.  The engine keeps one
+ *               "staged" flag per env (set by that generator, taken by the flip): a flip of an env whose alternate plane holds no
+ *               field generated since its last flip would observe a stale plane, so it poisons the env instead (prior, mean,
+ *               variance NaN: every later step of the episode returns IPP_STATUS_NOT_PD and a NaN reward)
  *   init_action [host] double[3]
  */
 int ipp_step_autoreset(void* engine, const int32_t* env_ids, int32_t n, const double* action, double* prev_action,
@@ -497,6 +500,30 @@ int ipp_fill_normal_rows(void* engine, float* out /*[dev]*/, int32_t planes, int
  * when a dependent launch waits ~10 us for its queue's turn -- which depends on the queues the runtime happened to give the streams).
  * The batched driver times a few candidate pairs and keeps the best.  Synchronises both streams. */
 int ipp_probe_stream_pair(void* engine, void* stream_a, void* stream_b, int32_t launches, double* ms /*[host]*/);
+
+/* Arena placement (round 6).  The engine lives in ONE caller-owned arena (ipp_engine_create); where that arena lies in PHYSICAL
+ * memory decides whether a large batch runs in its fast or its slow mode (12 % at 32768 envs of 50x50, profiles/r06_arena_modes.txt),
+ * which a framework's caching allocator hides.  These three calls give the host a handle on it: arenas straight from the driver --
+ * IPP_ARENA_HIPMALLOC: hipMalloc; IPP_ARENA_VMM: a 1-GiB-aligned virtual reservation backed by physical chunks of `chunk_bytes`
+ * (0 = 1 GiB; rounded up to the device's recommended granularity) through hipMemCreate / hipMemMap -- and a bare probe of the
+ * step kernel's row stream (512-byte slices of 656-float patches spread over `items` equal slots of the arena, `rows` stored
+ * columns per unit, no arithmetic) that times a placement in about a millisecond: ms = average duration of one of `launches`
+ * launches on `stream` (synchronises).  VecIPPEnv(arena_candidates = K) holds K arenas, keeps the fastest and frees the rest.
+ * No reference counterpart: the reference's state is NumPy arrays in host memory (mapping/grid_maps.py:10-11). */
+#define IPP_ARENA_HIPMALLOC 0
+#define IPP_ARENA_VMM       1
+int ipp_arena_alloc(int device, uint64_t bytes, int32_t kind, uint64_t chunk_bytes, uint64_t align_bytes,
+                    void** arena /*[host] out: [dev] pointer*/);
+int ipp_arena_free(void* arena /*[dev], from ipp_arena_alloc*/);
+/* ipp_arena_free of an IPP_ARENA_VMM arena returns its physical memory but keeps its ADDRESS range reserved (a range that is
+ * mapped again after a free has been seen to fault on this runtime); this is how many bytes of address space are retired so far. */
+int ipp_arena_retired_bytes(uint64_t* bytes /*[host]*/);
+int ipp_arena_probe(int device, const void* arena /*[dev]*/, uint64_t bytes, int32_t items, int32_t rows, int32_t launches,
+                    void* stream, double* ms /*[host]*/);
+/* ... and its latency: `waves` single-wave workgroups each follow a chain of `hops` DEPENDENT 512-byte requests to pseudo-random
+ * patches of the arena; ns_per_hop = duration of the launch / hops (synchronises). */
+int ipp_arena_latency(int device, const void* arena /*[dev]*/, uint64_t bytes, int32_t waves, int32_t hops, void* stream,
+                      double* ns_per_hop /*[host]*/);
 
 /* Copy the prologue record of item `idx` of the most recent ipp_step to the host (synchronises).  The fp64 copies of S, L^-1, z
  * and y are written by the step only after ipp_debug_capture(engine, 1) (they cost 1.4 KB of stores per item); footprint, m, cost

@@ -14,7 +14,9 @@ IPP_DENSE, IPP_FACTOR = 0, 1
 IPP_COV_ONLY, IPP_PREDICT_ONLY, IPP_ADAPTIVE, IPP_USE_FLIGHT_TIME, IPP_GIVEN_OBSERVATION, IPP_UPDATE_PREV = 1, 2, 4, 8, 16, 32
 STATUS_OK, STATUS_CHOL_FALLBACK, STATUS_NOT_PD, STATUS_RANK_FULL, STATUS_BAD_FOOTPRINT = 0, 1, 2, 3, 4
 IPP_MAX_MEAS = 25
-ABI_VERSION = 13
+ABI_VERSION = 14
+AB_MIN_ABI = 13  # oldest library tools/ab_kernels.py may load under IPP_AB_OLD_LIB (v14 added the ipp_arena_* calls, nothing else)
+IPP_ARENA_HIPMALLOC, IPP_ARENA_VMM = 0, 1
 
 
 class IppConfig(C.Structure):
@@ -129,6 +131,11 @@ PROTOTYPES = {
     "ipp_fill_normal": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "ipp_fill_normal_rows": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "ipp_probe_stream_pair": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(C.c_double)]),
+    "ipp_arena_alloc": (C.c_int, [C.c_int, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(_P)]),
+    "ipp_arena_free": (C.c_int, [_P]),
+    "ipp_arena_retired_bytes": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "ipp_arena_latency": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
+    "ipp_arena_probe": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     "ipp_debug_capture": (C.c_int, [_P, C.c_int32]),
     "ipp_debug_step_item": (C.c_int, [_P, C.c_int32, C.POINTER(IppStepItem), _P]),
     "ipp_streamed_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int32, _P]),
@@ -164,17 +171,23 @@ def load():
     except ImportError:  # symbol checks on a machine without torch
         pass
     lib = C.CDLL(LIB_PATH)
+    # tools/ab_kernels.py may time an OLDER build of the library against this binding (IPP_AB_OLD_LIB=1): only a library whose
+    # ABI is at least AB_MIN_ABI (struct layouts and call signatures unchanged since then; newer entry points may be absent
+    # and are then not bound) and only when the library is not the in-tree product build -- never a general switch
+    lib.ipp_abi_version.restype, lib.ipp_abi_version.argtypes = C.c_int, []
+    abi = lib.ipp_abi_version()
+    ab_old = bool(os.environ.get("IPP_AB_OLD_LIB")) and bool(os.environ.get("IPP_HIP_LIB")) and AB_MIN_ABI <= abi <= ABI_VERSION
+    if abi != ABI_VERSION and not ab_old:
+        raise IppError(f"libipp_hip.so ABI {abi} != binding ABI {ABI_VERSION}: rebuild")
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)  # AttributeError here = header / library mismatch
         except AttributeError:
-            if os.environ.get("IPP_AB_OLD_LIB"):  # tools/ab_kernels.py timing an older build of the same ABI version
+            if ab_old:
                 continue
             raise
         fn.restype = res
         fn.argtypes = args
-    if lib.ipp_abi_version() != ABI_VERSION and not os.environ.get("IPP_AB_OLD_LIB"):  # (A/B runs may time the previous ABI's build: new trailing ipp_info fields read 0)
-        raise IppError(f"libipp_hip.so ABI {lib.ipp_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
 

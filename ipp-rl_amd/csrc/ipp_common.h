@@ -131,7 +131,8 @@ struct View {
     float* diag;     // [cap][Npad]
     float* gt;       // [2 cap][Npad] ground-truth planes: env e reads plane gt_slot[e] (e or cap + e); the OTHER one receives the next
                      // episode's field ahead of time (ipp_generate_grf_groups with gt_out == NULL) and a folded reset only flips the slot
-    int* gt_slot;    // [cap]
+    int* gt_slot;    // [2 cap]: [e] = the plane env e reads; [cap + e] = 1 while a field generated for e's NEXT episode waits in the alternate
+                     // plane (set by the generator, taken by the flip: a flip that finds 0 would install a stale plane and poisons the env instead)
     double* prior;   // [cap][2]  (sigma^2, l)
     int* rank;       // [cap]
     int* colspan;    // factor: [cap][rank_cap]  lo_tile | hi_tile << 16 of every column of U
@@ -199,10 +200,11 @@ __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& a
     // window was not sized for poisons the env instead of losing accuracy silently)
     double sv_d = ar.prior ? ar.prior[2 * k + 0] : v.sv0, ls_d = ar.prior ? ar.prior[2 * k + 1] : v.ls0;
     if (v.ls_max > 0.0 && ls_d > v.ls_max * (1.0 + 1e-12)) sv_d = ls_d = NAN;
-    const float sv = (float)sv_d;
-    const float m0 = isnan(sv_d) ? NAN : 0.5f;
     float* mean = v.mean + (size_t)env * v.Npad;
     float* diag = v.diag + (size_t)env * v.Npad;
+    if (!ar.gt && v.gt_slot[v.cap + env] == 0) sv_d = ls_d = NAN;  // nothing was staged for this env: no flip to a stale plane without a trace
+    const float sv = (float)sv_d;
+    const float m0 = isnan(sv_d) ? NAN : 0.5f;
     if (!ar.gt) {
         // the ground truth of the new episode was generated into the env's alternate plane: no 2 x 4 N bytes of copy (at 100x100 and
         // 2048 resets per step the copies were 164 MB of a step's traffic) -- mean and variance planes, then the flip
@@ -221,6 +223,7 @@ __device__ __forceinline__ void wave_reset_env(const View& v, const AutoReset& a
         }
         if (lane == 0) {
             v.gt_slot[env] = alt;
+            v.gt_slot[v.cap + env] = 0;
             v.rank[env] = 0;
             v.prior[2 * env + 0] = sv_d;
             v.prior[2 * env + 1] = ls_d;

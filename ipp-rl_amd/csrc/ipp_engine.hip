@@ -46,6 +46,14 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+}  // namespace
+namespace ipp {
+int set_error(int code, const char* msg) {  // other translation units of the library (ipp_arena.hip) report through the same slot
+    g_err = msg;
+    return code;
+}
+}  // namespace ipp
+namespace {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -263,7 +271,7 @@ int plan(const ipp_config& c, Layout& L, bool allow_patch = true) {
     L.off_mean = o; o += up(cap * np * 4);
     L.off_diag = o; o += up(cap * np * 4);
     L.off_gt = o; o += up(2 * cap * np * 4);  // two ground-truth planes per env: the current one and the one staged for its next episode
-    L.off_gtslot = o; o += up(cap * 4);
+    L.off_gtslot = o; o += up(2 * cap * 4);  // [cap] current plane of every env + [cap] "alternate plane staged" flags
     L.off_prior = o; o += up(cap * 2 * 8);
     L.off_rank = o; o += up(cap * 4);
     L.off_span = o; o += (c.state_repr == IPP_FACTOR) ? up(2 * cap * (uint64_t)c.rank_cap * 4) : 0;  // tile spans, then rectangles

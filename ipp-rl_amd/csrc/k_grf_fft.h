@@ -225,6 +225,7 @@ __global__ __launch_bounds__(N1 == 10 ? 512 : 256) void k_grf_fft(View v, const 
     }
     if (!gt_out)
         for (int i = N + tid; i < v.Npad; i += NT) gt[i] = 0.f;
+    if (!gt_out && gn.to_alt && tid == 0) v.gt_slot[v.cap + env] = 1;  // the env's next folded reset may flip (stream order: the reset's launch waits for this one)
 }
 
 }  // namespace ipp

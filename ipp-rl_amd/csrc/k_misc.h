@@ -47,11 +47,17 @@ __global__ void k_reset_flagged(View v, const int* __restrict__ env_ids, int n_i
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell == 0) {
         v.rank[env] = 0;
-        v.prior[2 * env + 0] = sv;
-        v.prior[2 * env + 1] = ls;
+        // a flip without a staged field (only this thread looks at / takes the flag): the env's prior becomes NaN -- every later
+        // step of the episode then reports IPP_STATUS_NOT_PD and a NaN reward instead of observing a stale plane
+        const bool stale = !ar.gt && v.gt_slot[v.cap + env] == 0;
+        v.prior[2 * env + 0] = stale ? NAN : sv;
+        v.prior[2 * env + 1] = stale ? NAN : ls;
         if (ar.prev)
             for (int j = 0; j < 3; ++j) ar.prev[3 * env + j] = ar.init[j];
-        if (!ar.gt) v.gt_slot[env] = gt_alt_slot(v, env);  // (the new ground truth was staged into the alternate plane: no other thread reads the slot here)
+        if (!ar.gt) {  // (the new ground truth was staged into the alternate plane: no other thread reads the slot here)
+            v.gt_slot[env] = gt_alt_slot(v, env);
+            v.gt_slot[v.cap + env] = 0;
+        }
     }
     if (cell >= v.Npad) return;
     const bool valid = cell < v.N;
@@ -70,7 +76,7 @@ __global__ void k_copy_gt(View v, int env, float* __restrict__ out, const float*
 
 __global__ void k_init_gt_slots(View v) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < v.cap) v.gt_slot[e] = e;
+    if (e < v.cap) { v.gt_slot[e] = e; v.gt_slot[v.cap + e] = 0; }
 }
 
 // Dense state: P <- Matern prior (mapping/mappings.py:242-261).  Workgroup = kBandRows rows x 1024 columns.

@@ -74,6 +74,7 @@ FORK_MESSAGE = ("this process was fork()ed from a parent that had already opened
                 "fork.  Start workers with the spawn method (multiprocessing.set_start_method('spawn'), "
                 "multiprocessing.get_context('spawn').Pool(...), torch.multiprocessing.spawn): a spawned worker opens its own "
                 "engine.")
+ARENA_VMM_MIN_BYTES = 256 << 20  # arena="auto": arenas of at least this size come from the virtual-memory API (DeviceArena "vmm")
 _LIVE = weakref.WeakSet()
 _ABANDONED = []
 _forked_with_gpu = False
@@ -97,14 +98,87 @@ def _after_fork_in_child():
 os.register_at_fork(after_in_child=_after_fork_in_child)
 
 
+class DeviceArena:
+    """Device memory for an engine's state straight from the driver (ipp_arena_alloc): kind "hip" = hipMalloc, "vmm" = a
+    1-GiB-aligned reservation backed by physical chunks of `chunk_bytes` (0 = 1 GiB).  No caching allocator in between, so
+    freeing it returns the physical memory and a new one draws a new placement -- what VecIPPEnv(arena_candidates=K) is built on."""
+
+    def __init__(self, nbytes: int, device_index: int = 0, kind: str = "hip", chunk_bytes: int = 0, align_bytes: int = 0):
+        self._lib = _ffi.load()
+        if not _torch().cuda.is_available():
+            raise _ffi.IppError("DeviceArena needs a HIP device")
+        _torch().cuda.init()
+        kinds = {"hip": _ffi.IPP_ARENA_HIPMALLOC, "vmm": _ffi.IPP_ARENA_VMM}
+        if kind not in kinds:
+            raise ValueError("kind must be 'hip' or 'vmm'")
+        self.kind, self.nbytes, self.device_index = kind, int(nbytes), int(device_index)
+        p = C.c_void_p()
+        _ffi.check(self._lib.ipp_arena_alloc(self.device_index, self.nbytes, kinds[kind], int(chunk_bytes), int(align_bytes), C.byref(p)))
+        self._ptr = p.value
+        self._pid = os.getpid()
+        self.chunk_bytes = int(chunk_bytes) if kind == "vmm" else 0
+        if os.environ.get("IPP_ARENA_LOG"):
+            import sys
+            print(f"[arena] alloc {kind} 0x{self._ptr:x} .. 0x{self._ptr + self.nbytes:x} ({self.nbytes} bytes, chunk {self.chunk_bytes >> 20} MiB)", file=sys.stderr, flush=True)
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def probe(self, items: int, rows: int = 32, launches: int = 5, nbytes: Optional[int] = None) -> float:
+        """ms per launch of the bare row stream of the step kernel over this arena (ipp_arena_probe)."""
+        ms = C.c_double(0.0)
+        stream = C.c_void_p(_torch().cuda.current_stream(self.device_index).cuda_stream)
+        _ffi.check(self._lib.ipp_arena_probe(self.device_index, C.c_void_p(self._ptr), int(nbytes or self.nbytes), int(items), int(rows),
+                                             int(launches), stream, C.byref(ms)))
+        return float(ms.value)
+
+    def latency(self, waves: int = 256, hops: int = 2000, nbytes: Optional[int] = None) -> float:
+        """ns per hop of chains of dependent requests to random patches of this arena (ipp_arena_latency)."""
+        ns = C.c_double(0.0)
+        stream = C.c_void_p(_torch().cuda.current_stream(self.device_index).cuda_stream)
+        _ffi.check(self._lib.ipp_arena_latency(self.device_index, C.c_void_p(self._ptr), int(nbytes or self.nbytes), int(waves), int(hops),
+                                               stream, C.byref(ns)))
+        return float(ns.value)
+
+    def as_tensor(self, device):
+        """A uint8 view of the arena (tests: poisoning); valid while the arena lives."""
+        torch = _torch()
+
+        class _Iface:
+            pass
+
+        h = _Iface()
+        h.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self._ptr, False), "version": 2}
+        return torch.as_tensor(h, device=device)
+
+    def free(self):
+        if getattr(self, "_ptr", None) and os.getpid() != self._pid:
+            self._ptr = None  # a forked child: the mapping is the parent's (HIP state does not survive fork)
+        if getattr(self, "_ptr", None):
+            if os.environ.get("IPP_ARENA_LOG"):
+                import sys
+                print(f"[arena] free 0x{self._ptr:x}", file=sys.stderr, flush=True)
+            _torch().cuda.synchronize(self.device_index)
+            _ffi.check(self._lib.ipp_arena_free(C.c_void_p(self._ptr)))
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class IPPEngine:
     """B environment slots on one GPU; state lives in one caller-owned arena tensor."""
 
     def __init__(self, cfg: EngineConfig, capacity: int, state: str = "factor", rank_cap: int = 360,
                  max_batch: Optional[int] = None, device: str = "cuda:0", max_measurements: int = 9,
                  tile_threads: int = 0, window_rows: int = 0, score_scratch: bool = False, node_capacity: int = 0,
-                 fixed_prior: bool = False):
-        """window_rows: 0 = exact columns, R > 0 = columns kept within R grid rows of their footprint, -1 = the smallest
+                 fixed_prior: bool = False, arena=None):
+        """arena: None / "auto" = a torch.uint8 tensor for small arenas, a "vmm" DeviceArena from 256 MiB; "torch"; "hip" / "vmm" = a
+        DeviceArena of that kind owned by the engine; a DeviceArena instance = the caller's (the engine never frees it).
+        window_rows: 0 = exact columns, R > 0 = columns kept within R grid rows of their footprint, -1 = the smallest
         R the engine accepts for this prior (ipp_min_window_rows).  fixed_prior: no reset will install a length scale above
         cfg.length_scale (no shuffle_prior_cov), which lets the window be 10 instead of 12 rows for the example config."""
         if _forked_with_gpu:
@@ -148,12 +222,51 @@ class IPPEngine:
         self._c = c
         nbytes = C.c_uint64(0)
         _ffi.check(self._lib.ipp_engine_arena_bytes(C.byref(c), C.byref(nbytes)))
-        self.arena = torch.empty(int(nbytes.value) + 256, dtype=torch.uint8, device=self.device)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        # the arena: a torch tensor (default), or memory straight from the driver (DeviceArena: "hip" = hipMalloc, "vmm" = the
+        # virtual-memory API) -- an arena the caching allocator has never seen, whose physical placement the caller can re-draw
+        self.arena_bytes = int(nbytes.value) + 256
+        if arena is None:
+            arena = os.environ.get("IPP_ARENA", "auto")
+        self._own_arena = isinstance(arena, str) and arena != "torch"
+        self.arena_kind = arena if isinstance(arena, str) else "caller"
+        if isinstance(arena, str) and arena not in ("torch", "auto", "hip", "vmm"):
+            raise ValueError("arena must be 'auto', 'torch', 'hip', 'vmm' or a DeviceArena")
+        if arena == "auto":
+            # Large arenas from the virtual-memory API in 1-GiB physical chunks at 1-GiB-aligned addresses: the driver then maps
+            # them with large translation fragments, and a batch whose items walk a few hundred MB .. tens of GB of state runs
+            # in what rounds 4-5 knew as the "fast mode" in EVERY process (configs[3] share 0.597 -> 0.511 ms per step, configs[2]
+            # 0.592 -> 0.488; torch.empty / hipMalloc land there by chance: profiles/r06_arena_modes.txt).  Small arenas stay
+            # torch tensors (tests build hundreds of engines; a mapping costs milliseconds and rounds up to the granularity).
+            arena = "torch"
+            if self.arena_bytes >= ARENA_VMM_MIN_BYTES:
+                try:
+                    chunk = int(os.environ.get("IPP_ARENA_CHUNK_MIB", "1024")) << 20
+                    while chunk > (64 << 20) and chunk > self.arena_bytes:
+                        chunk >>= 1
+                    arena = DeviceArena(self.arena_bytes, dev_index, kind="vmm", chunk_bytes=chunk, align_bytes=chunk)
+                    self.arena_kind = "vmm"
+                except _ffi.IppError as e:  # (no VMM support / no contiguous physical memory left: the allocator's memory then)
+                    self.arena_fallback_reason = str(e)
+                    self.arena_kind = "torch"
+            else:
+                self.arena_kind = "torch"
+        elif isinstance(arena, str) and arena != "torch":
+            chunk = int(os.environ.get("IPP_ARENA_CHUNK_MIB", "1024")) << 20  # (A/B; aligned to its own size)
+            arena = DeviceArena(self.arena_bytes, dev_index, kind=arena, chunk_bytes=chunk, align_bytes=chunk)
+        if isinstance(arena, DeviceArena):
+            if arena.nbytes < self.arena_bytes:
+                raise ValueError(f"arena of {arena.nbytes} bytes for an engine that needs {self.arena_bytes}")
+            self.arena = arena
+        else:
+            self.arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
         if os.environ.get("IPP_POISON_ARENA"):  # tests: every float the engine does not initialise reads as NaN
-            self.arena.fill_(0xFF)
+            if isinstance(self.arena, DeviceArena):
+                self.arena.as_tensor(self.device).fill_(0xFF)
+            else:
+                self.arena.fill_(0xFF)
         base = (self.arena.data_ptr() + 255) // 256 * 256
         handle = C.c_void_p()
-        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _ffi.check(self._lib.ipp_engine_create(C.byref(c), dev_index, C.c_void_p(base), nbytes.value, C.byref(handle)))
         self._h = handle
         _LIVE.add(self)
@@ -174,6 +287,8 @@ class IPPEngine:
                 pass
             self._lib.ipp_engine_destroy(self._h)
             self._h = None
+            if getattr(self, "_own_arena", False) and isinstance(self.arena, DeviceArena):
+                self.arena.free()
             self.arena = None
             self._parts_ring = None
             self._keep = None
@@ -412,10 +527,12 @@ class IPPEngine:
         if ring is None or ring[0] != key[1]:
             torch = _torch()
             if ring is not None:
-                for evs in ring[2]:
-                    for ev in evs:
-                        ev.synchronize()
-            ring = self._parts_ring = [key[1], [None] * 16, [[torch.cuda.Event() for _ in streams] for _ in range(2)], 0, [False, False]]
+                # other streams from now on (rare): the old ring's tuples -- also those of the half that has not recorded its
+                # events yet -- are read by launches on the OLD streams; join those before the tuples go
+                for st in ring[5]:
+                    st.synchronize()
+            ring = self._parts_ring = [key[1], [None] * 16, [[torch.cuda.Event() for _ in streams] for _ in range(2)], 0, [False, False],
+                                       list(streams)]
         i = ring[3]
         half = i // 8
         if i % 8 == 0 and ring[4][half]:

@@ -60,7 +60,7 @@ class VecIPPEnv:
                  device: str = "cuda:0", seed: int = 1234, env_id_offset: int = 0, shuffle_prior_cov: bool = False,
                  rank_cap: Optional[int] = None, stagger: bool = False, tile_threads: int = 0,
                  adaptive: bool = True, use_flight_time: bool = True, window_rows: int = 0, fused_reset: bool = True,
-                 parts: int = 1):
+                 parts: int = 1, arena=None):
         import torch
 
         self.torch = torch
@@ -73,7 +73,8 @@ class VecIPPEnv:
         self.adaptive, self.use_flight_time = adaptive, use_flight_time
         rank_cap = int(rank_cap) if rank_cap else 9 * self.episode_steps
         self.engine = IPPEngine(cfg, capacity=self.num_envs, state=state, rank_cap=rank_cap, device=device,
-                                tile_threads=tile_threads, window_rows=window_rows, fixed_prior=not shuffle_prior_cov)
+                                tile_threads=tile_threads, window_rows=window_rows, fixed_prior=not shuffle_prior_cov,
+                                arena=arena)
         dev = self.engine.device
         self.device = dev
         B = self.num_envs
@@ -346,7 +347,9 @@ class VecIPPEnv:
             epi.append(int(e_p[0]) if len(e_p) else 0)
         # where the resets are folded into the step launches the fields go straight into the envs' alternate planes and a reset is a
         # flip (no copy of H W floats in and out per reset); else into the set's buffer, which the separate reset launch copies
-        alt = bool(self._fused_reset) and self._gt_flip_ok
+        # (2 K > episode_steps: a block is staged when its first step arrives, behind the `free` event of block b - 2 only -- while
+        # block b - 1, whose resets flip the very planes this launch would write, may still be running: staged buffers + copies then)
+        alt = bool(self._fused_reset) and self._gt_flip_ok and 2 * K <= self.episode_steps
         ok = self.engine.generate_grf_rows(K * nm, self.seed, self.GT_STREAM, None if alt else self._staged_sets[set_], row_ids=ids,
                                            row_offset=self.env_id_offset, stream=self._side, group_rows=nm, group_subsequence=epi)
         if not ok:

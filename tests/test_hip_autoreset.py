@@ -100,7 +100,7 @@ def test_vec_env_fused_resets_equal_separate_resets(shuffle):
         assert torch.equal(envs[0].ground_truth(e), envs[1].ground_truth(e))
 
 
-@pytest.mark.parametrize("dim,B,T,parts", [(50, 2048, 8, 2), (100, 512, 6, 1)])
+@pytest.mark.parametrize("dim,B,T,parts", [(50, 2048, 8, 2), (100, 512, 6, 1), (50, 256, 1, 2), (50, 256, 1, 1), (50, 256, 2, 2), (50, 384, 3, 1)])
 def test_flipped_ground_truth_planes_equal_copied_ones(monkeypatch, dim, B, T, parts):
     """Resets folded into the step launches take their ground truth from the env's ALTERNATE plane (generated there ahead of time,
     ipp_generate_grf_groups with gt_out == NULL) and flip to it; with IPP_GT_FLIP=0 the fields go through staged buffers and are
@@ -131,7 +131,12 @@ def test_flipped_ground_truth_planes_equal_copied_ones(monkeypatch, dim, B, T, p
             ids = np.array([1, 7, B // 2, B - 1], dtype=np.int32)
             copy.reset(env_ids=ids)
             flip.reset(env_ids=ids)
-    assert flip.alt_blocks >= 3 and copy.alt_blocks == 0  # (after the hand-made reset the phases' episode counters differ: per-phase staging again)
+    if 2 * flip._blk_K <= T:
+        assert flip.alt_blocks >= 3 and copy.alt_blocks == 0  # (after the hand-made reset the phases' episode counters differ: per-phase staging again)
+    else:
+        # episodes shorter than two staging blocks (T = 1): a block is staged when its first step arrives, while the previous block's
+        # flips may still be running -- the alternate planes are not used, the staged buffers are
+        assert flip.alt_blocks == 0 and copy.alt_blocks == 0
     assert torch.equal(copy.engine.ranks(), flip.engine.ranks()) and np.array_equal(copy.episode, flip.episode)
     for e in (0, 1, 7, T - 1, T, B // 2, B - 1):
         assert torch.equal(copy.ground_truth(e), flip.ground_truth(e)), e
@@ -141,3 +146,43 @@ def test_flipped_ground_truth_planes_equal_copied_ones(monkeypatch, dim, B, T, p
     w = torch.empty((1, cfg.n_cells), dtype=torch.float32, device="cuda")
     flip.engine.write_gt(3, w.fill_(0.25)[0])
     assert float(flip.ground_truth(3).min()) == 0.25 and float(flip.ground_truth(3).max()) == 0.25
+
+
+def test_a_flip_without_a_staged_field_poisons_the_env_instead_of_installing_a_stale_plane():
+    """ipp_step_autoreset(reset_src, reset_gt = NULL) flips an env to its alternate ground-truth plane; that plane holds the next
+    episode's field only if ipp_generate_grf_groups(gt_out = NULL) put one there since the last flip.  Without one the env is
+    poisoned (prior / mean / variance NaN -> NaN rewards, status 2 from then on); its neighbours are untouched."""
+    import torch
+    from ipp_rl_amd import EngineConfig, IPPEngine
+
+    cfg = EngineConfig(x_dim=50, y_dim=50)
+    B = 8
+    eng = IPPEngine(cfg, capacity=B, state="factor", rank_cap=90, window_rows=-1, fixed_prior=True)
+    assert int(eng.info.fused_step) == 1 and int(eng.info.patch_layout) == 1
+    rs = np.random.RandomState(3)
+    eng.reset(white_noise=rs.normal(size=(B, 50, 50)))
+    prev = torch.tensor([2.0, 2.0, 14.0], dtype=torch.float64, device="cuda").repeat(B, 1)
+    ids = torch.arange(B, dtype=torch.int32, device="cuda")
+    # stage fields for envs 2 and 5 only
+    staged = torch.tensor([2, 5], dtype=torch.int32, device="cuda")
+    assert eng.generate_grf_rows(2, 11, 1 << 40, None, row_ids=staged)
+    src = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    src[2], src[5], src[6] = 0, 1, 2  # env 6 flips although nothing was staged for it
+    acts = np.stack([4.0 * rs.randint(0, 50, B) + 2.0, 4.0 * rs.randint(0, 50, B) + 2.0, rs.randint(5, 15, B).astype(float)], axis=1)
+    eps = rs.normal(size=(B, 9))
+    r, st = eng.step(acts, prev, meas_noise=eps, reset_src=src, reset_gt=None, init_action=(2.0, 2.0, 14.0), update_prev=True)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0 and bool(torch.isfinite(r).all())  # the step itself ran before the resets
+    assert eng.ranks().cpu().tolist()[2] == 0 and eng.ranks().cpu().tolist()[6] == 0
+    assert bool(torch.isfinite(eng.read_mean(2)).all()) and bool(torch.isfinite(eng.read_mean(5)).all())
+    assert bool(torch.isnan(eng.read_mean(6)).all()) and bool(torch.isnan(eng.read_diag(6)).all())
+    r2, st2 = eng.step(acts, prev, meas_noise=eps)
+    torch.cuda.synchronize()
+    bad = st2.cpu().numpy() != 0
+    assert bad.tolist() == [e == 6 for e in range(B)] and bool(torch.isnan(r2[6])) and bool(torch.isfinite(r2[ids != 6]).all())
+    # a second flip of env 2 without a new field is stale as well (the flag is taken by the flip)
+    src.fill_(-1); src[2] = 0
+    eng.step(acts, prev, meas_noise=eps, reset_src=src, reset_gt=None, init_action=(2.0, 2.0, 14.0), update_prev=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(eng.read_mean(2)).all()) and bool(torch.isfinite(eng.read_mean(5)).all())
+    eng.close()

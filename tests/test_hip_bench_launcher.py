@@ -31,6 +31,18 @@ def test_bench_starts_its_own_ranks_and_reports_the_whole_job():
     assert cfg["envs_per_gpu"] == 256 and cfg["envs_total"] == 512
     assert len(cfg["per_rank_ms_per_step"]) == 2 and len(cfg["per_rank_env_steps_per_s"]) == 2
     assert cfg["items_with_nonzero_status"] == 0 and cfg["non_finite_rewards"] == 0
+    # what a parser that keeps the first 20 keys of `config` still sees: validity, streams, arena, the ranks' host loops
+    head = list(cfg)[:20]
+    for k in ("workload", "envs_per_gpu", "arena_kind", "queues_n_queues", "queues_parts_distinct", "queues_staging_shares_a_part_queue",
+              "host_issue_ms_per_step", "host_issue_ms_min_over_ranks", "host_issue_ms_max_over_ranks", "slowest_rank", "region_ms_min",
+              "region_ms_max", "items_with_nonzero_status", "non_finite_rewards", "ranks_pinned"):
+        assert k in head, (k, head)
+    assert len(cfg["host_issue_ms_per_rank"]) == 2 and cfg["slowest_rank"] in (0, 1)
+    assert cfg["host_issue_ms_min_over_ranks"] <= cfg["host_issue_ms_max_over_ranks"]
+    assert cfg["slowest_rank"] == max(range(2), key=lambda r: cfg["own_ms_per_step_per_rank"][r])
+    pin = cfg["rank_pinning"]
+    assert pin["pinned"] == ((os.cpu_count() or 1) >= 2) and (not pin["pinned"] or pin["cores"] >= 1)
+    assert d["roofline"]["frac_step_clock"] == d["roofline"]["step_frac"] and "event leg" in d["roofline"]["kernel_ms_avg_is"]
     # value = envs of ALL ranks x steps / the slowest rank's time
     assert abs(d["value"] - 512 * 6 / (max(cfg["per_rank_ms_per_step"]) * 6e-3)) / d["value"] < 1e-6
     assert d["roofline"]["kernel"] in ("k_step_patch", "k_step_factor") and d["roofline"]["achieved"] > 0

@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--layout", default="row", help="row: patch rows of pw floats (as built); half: two half-width patches; tile4x8: 4 x 8-cell tiles of 128 B")
     ap.add_argument("--pw", type=int, default=0, help="row stride of a patch in floats (0: the engine's 2 R + 6)")
+    ap.add_argument("--vec", type=int, default=2, help="cells per lane: 2 = as built (8-byte lanes, rectangles on even columns, units of 128 cells); 4 = the "
+                                                       "16-byte-lane unit of VERDICT r05 item 2 (rectangles on multiples of 4 columns -- virtual columns beyond "
+                                                       "an odd grid edge --, units of 256 cells, pw rounded up to a multiple of 4)")
     args = ap.parse_args()
     from ipp_rl_amd.engine import EngineConfig
     from ipp_rl_amd.vec_env import cell_centre_actions
@@ -50,7 +53,10 @@ def main():
     B, T, R = args.envs, args.episode_steps, args.window
     alts = [float(a) for a in range(5, 15)]
     tanx, tany = math.tan(math.radians(cfg.angle_x) / 2), math.tan(math.radians(cfg.angle_y) / 2)
+    V = args.vec
     pw = args.pw or min((W + 1) & ~1, ((2 * R + 5 + 2) // 2) * 2)
+    if V == 4 and not args.pw:
+        pw = min((W + 3) & ~3, (2 * R + 5 + 3 + 3 + 3) & ~3)  # widest footprint 5 + 2 R, first column rounded down, last rounded up
     ph = min(H, 2 * R + 6)
     pstride = (pw * ph + 15) & ~15
     rank_cap = 9 * T
@@ -61,7 +67,9 @@ def main():
     def rect_of(fp):
         xl, xr, yu, yd, rf = fp
         r0, r1 = max(0, yu - R), min(H - 1, yd + R)
-        c0, c1 = max(0, xl - R) & ~1, min(W - 1, min(W - 1, xr + R) | 1)
+        c0, c1 = max(0, xl - R) & ~(V - 1), min(W - 1, min(W - 1, xr + R) | 1)
+        if V == 4:
+            c1 = min(W - 1, xr + R) | 3  # (virtual columns W .. beyond an edge that is no multiple of 4: stored zeros)
         return r0, r1, c0, c1
 
     tot = collections.Counter()
@@ -82,7 +90,8 @@ def main():
         m = ((xr - xl) // rf + 1) * ((yd - yu) // rf + 1)
         r0n, r1n, c0n, c1n = rect_of(fp)
         hn, wn = r1n - r0n + 1, c1n - c0n + 1
-        n_units = (hn * wn + 127) // 128
+        UC = 64 * V  # cells of a unit
+        n_units = (hn * wn + UC - 1) // UC
         contrib = [(rc, ms, k0) for rc, ms, k0 in stored if rc[0] <= yd and rc[1] >= yu and rc[2] <= xr and rc[3] >= xl]
         n_c = sum(ms for _, ms, _ in contrib)
         tot["items"] += 1; tot["units"] += n_units; tot["records"] += n_c; tot["rank"] += k
@@ -101,22 +110,23 @@ def main():
                     tot["gather_lines128"] += hi // 128 - lo // 128 + 1
                     tot["gather_sect64"] += hi // 64 - lo // 64 + 1
         # units
-        idx = 2 * np.arange(64)
+        idx = V * np.arange(64)
+        LB = 4 * V  # bytes per lane request
         for u in range(n_units):
-            cell = u * 128 + idx
+            cell = u * UC + idx
             prow, pcol = cell // wn, cell % wn
             valid = prow < hn
             rrow, rcol = r0n + np.minimum(prow, hn - 1), c0n + pcol
-            urow0, urow1 = r0n + (u * 128) // wn, r0n + min(hn - 1, (u * 128 + 127) // wn)
+            urow0, urow1 = r0n + (u * UC) // wn, r0n + min(hn - 1, (u * UC + UC - 1) // wn)
             n_valid = int(valid.sum())
             # mean / variance: 8 bytes per lane and plane, planes of W floats per row
             a = ((rrow * W + rcol) * 4)[valid]
             for _ in range(2):
-                tot["md_useful"] += n_valid * 8
-                tot["md_lines128"] += len(np.unique(a // 128)) + int(np.any((a + 7) // 128 != a // 128))
-                tot["md_sect64"] += len(np.unique(np.concatenate([a // 64, (a + 7) // 64])))
+                tot["md_useful"] += n_valid * LB
+                tot["md_lines128"] += len(np.unique(np.concatenate([a // 128, (a + LB - 1) // 128])))
+                tot["md_sect64"] += len(np.unique(np.concatenate([a // 64, (a + LB - 1) // 64])))
             # new rows + planes written
-            tot["write_useful"] += n_valid * 8 * (m + 2)
+            tot["write_useful"] += n_valid * LB * (m + 2)
             nact = 0
             for (a0, a1, b0, b1), ms, k0 in contrib:
                 if a1 < urow0 or a0 > urow1:
@@ -128,7 +138,7 @@ def main():
                 if nl == 0:
                     tot["rows_empty"] += ms
                     continue
-                cols = int(rcol[inr].max() - rcol[inr].min()) + 2
+                cols = int(rcol[inr].max() - rcol[inr].min()) + V
                 rows = int(rrow[inr].max() - rrow[inr].min()) + 1
                 col_hist[cols] += ms; row_hist[rows] += ms
                 rel_r, rel_c = (rrow - a0)[inr], (rcol - b0)[inr]
@@ -144,16 +154,18 @@ def main():
                         ad = base + (((rel_r // 4) * tc + rel_c // 8) * 32 + (rel_r % 4) * 8 + rel_c % 8) * 4
                     else:
                         raise SystemExit("unknown layout")
-                    tot["row_useful"] += nl * 8
-                    tot["row_lines128"] += len(np.unique(np.concatenate([ad // 128, (ad + 7) // 128])))
-                    tot["row_sect64"] += len(np.unique(np.concatenate([ad // 64, (ad + 7) // 64])))
+                    tot["row_useful"] += nl * LB
+                    tot["row_lines128"] += len(np.unique(np.concatenate([ad // 128, (ad + LB - 1) // 128])))
+                    tot["row_sect64"] += len(np.unique(np.concatenate([ad // 64, (ad + LB - 1) // 64])))
             tot["row_requests"] += nact
-            tot["alg_floats"] += (nact + m + 4) * n_valid * 2
+            tot["alg_floats"] += (nact + m + 4) * n_valid * V
+            tot["lane_slots"] += nact * 64
     n = tot["items"]
     MB = 1e-6
     print(f"{n} items of step {t_now}: layout {args.layout}, pw {pw}, ph {ph}, pstride {pstride} floats; mean rank before {tot['rank'] / n:.1f}, records {tot['records'] / n:.1f} per item, "
           f"{tot['units'] / n:.2f} units per item, row requests {tot['row_requests'] / tot['units']:.1f} per unit ({tot['rows_empty'] / max(tot['row_requests'], 1):.1%} of them with no lane inside the rectangle)")
-    print(f"SURVEY count (algorithmic) {tot['alg_floats'] * 4 * MB:7.1f} MB per launch")
+    print(f"SURVEY count (algorithmic) {tot['alg_floats'] * 4 * MB:7.1f} MB per launch; row requests (wave instructions) {tot['row_requests'] / n:.1f} per item, "
+          f"lanes inside a stored rectangle {tot['row_useful'] / (4 * V) / max(tot['lane_slots'], 1):.1%} of the request lanes")
     for name, key in (("row stream", "row"), ("gather", "gather"), ("mean / variance reads", "md")):
         u, l, s = tot[key + "_useful"] * MB, tot[key + "_lines128"] * 128 * MB, tot[key + "_sect64"] * 64 * MB
         print(f"{name:24s} useful {u:7.1f} MB   128-byte lines {l:7.1f} MB ({l / u:4.2f} x)   64-byte sectors {s:7.1f} MB ({s / u:4.2f} x)")
