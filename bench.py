@@ -902,7 +902,9 @@ def main(argv=None):
         ]
         for name, kw in todo:
             try:
-                kw = dict(dict(steps=20, warmup=4, parts=args.parts), **kw)
+                # (three regions, the median one reported: a single 20-step region now and then catches a 40-ms stall right behind the
+                # release of the previous workload's arena -- the driver clears freed device memory in the background)
+                kw = dict(dict(steps=20, warmup=4, parts=args.parts, regions=3), **kw)
                 r, _ = run_env_workload(torch, ranks, device, env_lo=0, total_envs=kw["envs_local"], **kw)
                 extra.append(extra_record(name, r, kw["envs_local"]))
             except Exception as exc:
