@@ -535,7 +535,9 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": down_n if kernel_name == "k_downdate" else gain_n,
         "bytes_per_launch": bytes_per_launch, "mask_reread_bytes_per_launch": mask_reread if state == "factor" else 0.0,
         "necessary_bytes_per_launch": needed if (state == "factor" and needed > 0) else None,
-        "workgroup_threads": 64 * int(eng.info.patch_waves) if (state == "factor" and int(eng.info.patch_layout)) else int(eng.info.tile_threads),
+        # (patch kernel: three waves per item, two for launches of at least ipp_info.patch_two_wave_min_items items)
+        "workgroup_threads": (64 * (2 if 0 < int(getattr(eng.info, "patch_two_wave_min_items", 0)) <= B // (env.parts if use_parts else 1)
+                                    else int(eng.info.patch_waves))) if (state == "factor" and int(eng.info.patch_layout)) else int(eng.info.tile_threads),
         "formula_bytes_per_launch": formula_bytes, "achieved_gbs": achieved,
         "other_kernels_ms_avg": {"k_prepare": prep_ms, "k_gain": gain_ms, "k_downdate": down_ms},
         "arena_gb": float(eng.info.arena_bytes) / 1e9,

@@ -107,12 +107,16 @@ typedef struct ipp_info {
     int32_t fused_step;       /* 1: ipp_step is ONE fused kernel per launch (ipp_step_autoreset folds the resets into it) */
     int32_t patch_layout;     /* 1: factor columns stored as compact patches of their rectangles (k_step_patch.h) */
     int32_t patch_waves;      /* patch layout: waves per item of the step kernel (workgroup = 64 x this many threads), else 0 */
-    int32_t patch_big_min_items; /* patch layout, two-wave engines (IPP_PATCH_WAVES=2) only: launches of at least this many items take
+    int32_t patch_big_min_items; /* patch layout, launches that run two waves per item (IPP_PATCH_WAVES=2, or patch_two_wave_min_items): launches of at least this many items take
                                  the instantiation with four rows per request group (k_step_patch<2, 4, 6>); 0: one instantiation for every
                                  launch size (the default: k_step_patch<3, 8, 6>) */
     int32_t patch_split_min_items; /* patch layout: launches of at least this many items run the SPLIT step -- an item-parallel prologue
                                  kernel and a unit-parallel streaming kernel (csrc/k_step_split.h) -- instead of the fused kernel; results are
                                  bit-identical; 0: never */
+    int32_t patch_two_wave_min_items; /* patch layout, three-wave engines (the default): launches of at least this many items run two waves
+                                 per item (k_step_patch<2>: 12 items per CU instead of 8; from patch_big_min_items items its
+                                 four-rows-per-group form) -- a launch of many rounds of workgroup slots has no tail of heavy items to
+                                 shorten and is paid in items in flight; bit-identical results; 0: never */
 } ipp_info;
 
 /* Debug / test view of the last ipp_step's per-item prologue (host struct, filled by ipp_debug_step_item). */

@@ -41,7 +41,7 @@ class IppInfo(C.Structure):
         ("n_tiles", C.c_int32), ("meas_cap", C.c_int32), ("fp_cap", C.c_int32), ("window_rows", C.c_int32),
         ("arena_bytes", C.c_uint64), ("cov_slot_bytes", C.c_uint64), ("step_lds_bytes", C.c_uint64),
         ("fused_step", C.c_int32), ("patch_layout", C.c_int32), ("patch_waves", C.c_int32), ("patch_big_min_items", C.c_int32),
-        ("patch_split_min_items", C.c_int32),
+        ("patch_split_min_items", C.c_int32), ("patch_two_wave_min_items", C.c_int32),
     ]
 
 

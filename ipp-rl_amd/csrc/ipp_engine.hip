@@ -109,6 +109,10 @@ struct Engine {
     size_t lds_p = 0, lds_u = 0;
     int pcap_big = 0, big_min_items = 0;  // large launches: k_step_patch<2, 4, 6> with LDS for 12 workgroups per CU (0: never)
     size_t lds_big = 0;
+    // three-wave engines (the default): launches of at least two_wave_min_items items run TWO waves per item (k_step_patch<2>, 12 items
+    // per CU = 3072 slots; from big_min_items its four-rows-per-group form) -- 0: never
+    int pcap2 = 0, two_wave_min_items = 0;
+    size_t lds2 = 0;
     const double* reset_prior = nullptr;  // ipp_set_reset_prior: priors of the episodes started by ipp_step_autoreset
     bool rect_ok = false;      // rectangle tiles (k_gain_factor.h) possible: clipped windows, 128-cell tiles, even grid width
     bool rect_commit = false;  // ... used for committed steps too (else for predict-only calls only)
@@ -469,7 +473,7 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                 timed_launch(e, 0, k_step_patch<1>, dim3(n), dim3(64), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
             else if (e->patch_waves == 4)
                 timed_launch(e, 0, k_step_patch<4>, dim3(n), dim3(256), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
-            else if (e->patch_waves == 3)
+            else if (e->patch_waves == 3 && !(e->two_wave_min_items > 0 && n >= e->two_wave_min_items))
                 if (v.rank_cap <= 192)       // (rounds of 192 threads over the columns' rectangles: k_step_patch.h, RJN)
                     timed_launch(e, 0, k_step_patch<3, kPatchKP, kPatchMinW, false, 1>, dim3(n), dim3(192), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
                 else if (v.rank_cap <= 384)
@@ -480,6 +484,10 @@ void launch_chunk(Engine* e, const View& v, const int32_t* env_ids, const int32_
                 View vb = v;  // (six waves per SIMD pay once a launch is many rounds of workgroups: k_step_patch.h)
                 vb.pcap = e->pcap_big;
                 timed_launch(e, 0, k_step_patch<2, IPP_PATCH_BIGKP, 6>, dim3(n), dim3(128), e->lds_big, s, vb, env_ids, n, action, prev, noise, flags, status, reward, ar);
+            } else if (e->patch_waves == 3) {
+                View v2 = v;  // a large launch of a three-wave engine: two waves per item, LDS share of 12 workgroups per CU
+                v2.pcap = e->pcap2;
+                timed_launch(e, 0, k_step_patch<2>, dim3(n), dim3(128), e->lds2, s, v2, env_ids, n, action, prev, noise, flags, status, reward, ar);
             } else
                 timed_launch(e, 0, k_step_patch<2>, dim3(n), dim3(128), e->gain_lds, s, v, env_ids, n, action, prev, noise, flags, status, reward, ar);
         }
@@ -907,7 +915,24 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
                                          GainLds<25>::bytes(v.rank_cap, step_work_floats<25>(v.rank_cap), lutf, step_small_floats<25>(), waves, v.win_tiles, 0, 0, v.vec));
         }
         if (e->patch) e->gain_lds = PatchLds::bytes(v.pcap, v.plw * v.plw, e->patch_waves, v.punits, v.rank_cap);
-        if (e->patch && e->patch_waves == 2 && !getenv("IPP_PATCH_CAP")) {
+        if (e->patch && e->patch_waves == 3 && !getenv("IPP_PATCH_CAP")) {
+            // Launch-size rule of the default engine (round 6).  Three waves per item shorten the chains of the heaviest items, which end
+            // a launch of one or two rounds of workgroup slots (2048 items: 55 M env-steps/s against 37 M with two waves); a launch of
+            // many rounds has no tail to shorten and is paid in items in flight: two waves per item are 12 items per CU instead of 8.
+            // Same box, two groups of launches: 8192 envs of 50x50 (4096 items per launch) 64.9 M with three waves against 54.5 M with
+            // two; 16384 envs 62.9 against 66.5 M; 32768 envs (configs[3] share) 61.8-64.3 against 66.1 M; configs[2] 66.1-67.0
+            // against 70.1-71.6 M (profiles/r06_experiments.txt 3).  Same arithmetic per cell, same order: bit-identical results
+            // (tests/test_hip_rect_meta.py).  IPP_PATCH_TWO_MIN=<items> (0: never) for A/B.
+            const size_t budget = (size_t)160 * 1024 / 12 / 1280 * 1280;
+            const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, 2, v.punits, v.rank_cap);
+            int p2 = fixed + 17 * kPatchRec * 4 <= budget ? (int)((budget - fixed) / (kPatchRec * 4)) - 1 : 16;
+            p2 = p2 >= v.rank_cap ? v.rank_cap : (p2 & ~7);  // (below the rank a multiple of 8: solve_wave_fast sums the records in groups of eight)
+            e->pcap2 = std::min(p2, (int)v.pcap);
+            e->lds2 = PatchLds::bytes(e->pcap2, v.plw * v.plw, 2, v.punits, v.rank_cap);
+            e->two_wave_min_items = 6144;
+            if (const char* t = getenv("IPP_PATCH_TWO_MIN")) e->two_wave_min_items = std::max(0, atoi(t));
+        }
+        if (e->patch && (e->patch_waves == 2 || e->two_wave_min_items > 0) && !getenv("IPP_PATCH_CAP")) {
             // second configuration for large launches: LDS share of 12 workgroups per CU (10 granules of 1280 bytes)
             const size_t budget = (size_t)160 * 1024 / 12 / 1280 * 1280;
             const size_t fixed = PatchLds::bytes(0, v.plw * v.plw, 2, v.punits, v.rank_cap);
@@ -915,7 +940,7 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
             int min_items = 16384;
             if (const char* b = getenv("IPP_PATCH_BIG")) min_items = atoi(b);  // A/B: smallest launch that takes it (0: never)
             if (pc >= 32 && min_items > 0) {
-                e->pcap_big = std::min(pc, (int)v.pcap);
+                e->pcap_big = std::min(pc, (int)(e->patch_waves == 3 ? e->pcap2 : v.pcap));
                 e->lds_big = PatchLds::bytes(e->pcap_big, v.plw * v.plw, 2, v.punits, v.rank_cap);
                 e->big_min_items = min_items;
             }
@@ -1090,6 +1115,7 @@ int ipp_engine_info(void* engine, ipp_info* out) {
     out->patch_layout = e->patch ? 1 : 0;
     out->patch_waves = e->patch ? e->patch_waves : 0;
     out->patch_big_min_items = e->patch ? e->big_min_items : 0;
+    out->patch_two_wave_min_items = e->patch ? e->two_wave_min_items : 0;
     out->patch_split_min_items = e->patch ? e->split_min_items : 0;
     return 0;
 }

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/ipp_engine.h"
+#include "ipp_common.h"
 
 namespace ipp {
 
@@ -35,6 +36,36 @@ __device__ __forceinline__ double mc_first(double x) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ double mc_shfl_xor(double x, int m) { return __shfl_xor(x, m, 64); }
+// Wave-wide max / min without LDS permutes: a butterfly of __shfl_xor is six DEPENDENT ds_bpermute round trips per value (two per fp64),
+// and a level of the selection reduced five values for the Q range and six for the argmax -- 84 permutes, most of the 2 us that "PUCT +
+// argmax" cost a lone wave.  Quads, half rows and rows through DPP moves, the four row results through v_readlane (as wave_sum_dpp);
+// max / min do not round, so the result does not depend on the order.  Every lane returns the result.
+__device__ __forceinline__ double mc_wave_max(double x) {
+    x = fmax(x, dpp_mov_f64<0xB1>(x));
+    x = fmax(x, dpp_mov_f64<0x4E>(x));
+    x = fmax(x, dpp_mov_f64<0x141>(x));
+    x = fmax(x, dpp_mov_f64<0x140>(x));
+    return fmax(fmax(bcast_lane(x, 0), bcast_lane(x, 16)), fmax(bcast_lane(x, 32), bcast_lane(x, 48)));
+}
+__device__ __forceinline__ double mc_wave_min(double x) {
+    x = fmin(x, dpp_mov_f64<0xB1>(x));
+    x = fmin(x, dpp_mov_f64<0x4E>(x));
+    x = fmin(x, dpp_mov_f64<0x141>(x));
+    x = fmin(x, dpp_mov_f64<0x140>(x));
+    return fmin(fmin(bcast_lane(x, 0), bcast_lane(x, 16)), fmin(bcast_lane(x, 32), bcast_lane(x, 48)));
+}
+__device__ __forceinline__ int mc_wave_min_i32(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true));
+    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true));
+    return min(min(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+__device__ __forceinline__ double mc_readlane(double x, int lane_s) {  // lane_s wave-uniform
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, lane_s), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane_s);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // splitmix64: tie-break draws and the Dirichlet noise (counter-based: a draw depends on (seed, root, simulation, ...) only)
 __device__ __forceinline__ uint64_t mc_mix(uint64_t x) {
@@ -155,12 +186,9 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     nz |= (q != 0.0) ? 1 : 0;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lo = fmin(lo, mc_shfl_xor(lo, o));
-                hi = fmax(hi, mc_shfl_xor(hi, o));
-                nz |= __shfl_xor(nz, o, 64);
-            }
+            lo = mc_wave_min(lo);
+            hi = mc_wave_max(hi);
+            nz = __ballot(nz != 0) != 0ull ? 1 : 0;
             MC_STAMP(1);
             if (K < m.num_actions) { lo = fmin(lo, 0.0); hi = fmax(hi, 0.0); }  // the zeros of the invalid actions take part (mcts.py:267-278)
             // (wave-uniform facts as scalars: the compiler then branches instead of evaluating every form of qn -- two fp64 divisions
@@ -190,13 +218,26 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             } else {
                 for (int k = lane; k < K; k += 64) consider(k, m.t_qsa[row + k], m.t_nsa[row + k], m.t_ps[row + k], m.t_idx[row + k], -2);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = mc_shfl_xor(best, o), ou = mc_shfl_xor(best_u, o), on = mc_shfl_xor(best_nsa, o);
-                const int ok = __shfl_xor(best_k, o, 64), oa = __shfl_xor(best_a, o, 64), oc = __shfl_xor(best_c, o, 64);
-                if (ob > best || (ob == best && (m.tie_break ? (ou > best_u || (ou == best_u && ok < best_k)) : ok < best_k))) {
-                    best = ob; best_k = ok; best_u = ou; best_nsa = on; best_a = oa; best_c = oc;
+            // the winner over the lanes: largest uct, then (random tie-break) largest draw, then lowest k -- a total order, so the result
+            // is the butterfly's.  ONE max-reduction of uct and a ballot name it unless lanes tie (forced playouts: uct = inf on several
+            // edges), the other fields come from its lane (k = lane + 64 i: the lane of an edge is k & 63) by v_readlane.
+            {
+                const double bmax = mc_wave_max(best);
+                unsigned long long tie = __ballot(best == bmax);
+                int win = (int)__builtin_ctzll(tie);
+                if (tie & (tie - 1ull)) {  // (wave-uniform)
+                    bool in = best == bmax;
+                    if (m.tie_break) {
+                        const double umax = mc_wave_max(in ? best_u : -1.0);
+                        in = in && best_u == umax;
+                    }
+                    win = mc_wave_min_i32(in ? best_k : 0x7fffffff) & 63;
                 }
+                win = __builtin_amdgcn_readfirstlane(win);
+                best_nsa = mc_readlane(best_nsa, win);
+                best_k = __builtin_amdgcn_readlane(best_k, win);
+                best_a = __builtin_amdgcn_readlane(best_a, win);
+                best_c = __builtin_amdgcn_readlane(best_c, win);
             }
             MC_STAMP(2);
             const int k = best_k, a_idx = best_a;  // (K >= 1 for an expanded node)
@@ -244,7 +285,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
             const double cns = child_known ? cns_pre : m.n_ns[child];
             int pth[kMctsPath];
 #pragma unroll
-            for (int s = 0; s < kMctsPath; ++s) pth[s] = __shfl(pv, s, 64);
+            for (int s = 0; s < kMctsPath; ++s) pth[s] = __builtin_amdgcn_readlane(pv, s);
             MC_STAMP(5);
             if (lane == 0) {
                 if (isnan(num)) {  // first traversal of the edge: one device step

@@ -59,7 +59,8 @@ def test_fullsize_batch_invariants_subset_parity_and_reproducibility(grid, B, T,
     # would put these configs back on the band-tile kernels with every numeric check below still green
     assert full.info.window_rows == 10
     assert full.info.patch_layout == 1 and full.info.fused_step == 1 and full.info.patch_waves == 3
-    assert full.info.patch_big_min_items == 0  # (the two-wave engines' second instantiation: IPP_PATCH_WAVES=2 only)
+    # launches of this size (32768 items, or 16384 per group) run two waves per item, in the four-rows-per-group form (launch_chunk)
+    assert full.info.patch_two_wave_min_items == 6144 and full.info.patch_big_min_items == 16384
     print(f"[{name}] arena {full.info.arena_bytes / 1e9:.1f} GB, {full.info.cov_slot_bytes / 1e6:.2f} MB of columns per env")
     white = torch.empty((B, N), dtype=torch.float32, device="cuda")
     full.normal_rows(white, N, 11, 1 << 40)
@@ -398,7 +399,7 @@ def test_baseline_configs_take_the_patch_kernels(grid, capacity, T, node_capacit
                     fixed_prior=True, node_capacity=node_capacity)
     assert eng.info.window_rows == 10
     assert eng.info.patch_layout == 1 and eng.info.fused_step == 1 and eng.info.patch_waves == 3
-    assert eng.info.patch_big_min_items == 0
+    assert eng.info.patch_two_wave_min_items == 6144 and eng.info.patch_big_min_items == 16384
     eng.close()
 
 
@@ -409,5 +410,5 @@ def test_two_wave_engines_keep_their_large_launch_instantiation(monkeypatch):
     fresh_gpu()
     monkeypatch.setenv("IPP_PATCH_WAVES", "2")
     eng = IPPEngine(EngineConfig(x_dim=50, y_dim=50), capacity=64, state="factor", rank_cap=360, window_rows=-1, fixed_prior=True)
-    assert eng.info.patch_waves == 2 and eng.info.patch_big_min_items == 16384
+    assert eng.info.patch_waves == 2 and eng.info.patch_big_min_items == 16384 and eng.info.patch_two_wave_min_items == 0
     eng.close()
