@@ -1011,7 +1011,13 @@ int ipp_engine_create(const ipp_config* cfg, int device, void* arena, uint64_t a
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<9, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_step<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_step_lds);
+    if (e->tv.node_cap > 0 && v.meas_cap == 25) {
+        // MC = 25 tree steps: ALWAYS the two launches (prologue + gain kernel), like the env steps of these engines -- the fused
+        // k_tree_step<25, 2> spilled 381 VGPRs (1412 bytes of scratch per lane) and is no longer instantiated
+        e->tree_gain_lds = (GainLds<25>::bytes(v.rank_cap, 0, e->lut_rows * v.W, 0, e->tree_T / kWave, v.win_tiles, 0, v.rank_cap, v.vec) + 15) & ~(size_t)15;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_prepare<25>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_gain<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->tree_gain_lds);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_factor<25, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<9, 4, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain<25, 2, IPP_DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, glds);
@@ -1411,9 +1417,13 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
         else            { if (e->rect_tree) IPP_TREE_STEP(4, true); else IPP_TREE_STEP(4, false); }
 #undef IPP_TREE_STEP
     }
-    else
-        timed_launch(e, 0, k_tree_step<25, 2>, dim3(n), dim3(kStepThreads), e->tree_step_lds, s, v, e->tv, root_ids, path_ids, new_ids, n,
-                     action, prev_action, flags, e->lut_rows, status, reward);
+    else {
+        if (v.vec != 2) return fail(-1, "tree steps with max_measurements = 25 need two cells per lane");
+        timed_launch(e, 2, k_tree_prepare<25>, dim3(n), dim3(kPrepThreads), e->prep_lds, s, v, e->tv, root_ids, path_ids, new_ids, n, action,
+                     prev_action, flags, status);
+        timed_launch(e, 0, k_tree_gain<25, 2>, dim3(n), dim3(e->tree_T), e->tree_gain_lds, s, v, e->tv, (const float*)v.q, root_ids, path_ids,
+                     new_ids, n, flags, e->lut_rows, reward);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -191,6 +191,15 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_tree_prepar
     const unsigned flags_eff = (flags | IPP_COV_ONLY | (expand ? 0u : (unsigned)IPP_PREDICT_ONLY)) & ~(unsigned)IPP_UPDATE_PREV;
     float* blk_out = v.q + (size_t)item * v.q_item;  // [L^-1 | y | pad | Q rows | zero rows]
     float* big = reinterpret_cast<float*>(smem_tp + ((prep_small_bytes<MC>() + 15) & ~(size_t)15));
+    if constexpr (MC != 9) {
+        // (m up to 25: the whole prologue by the workgroup, m x m algebra in LDS -- the register form of solve_wave_fast is written for MC = 9;
+        // writes L^-1 | y and the Q rows of the chained state into the item's block itself)
+        prepare_item_ex<MC, IPP_FACTOR, kPrepThreads, false, NoMidWork, true>(
+            v, item, root_ids, nullptr, action, prev_action, nullptr, flags_eff, status_out, nullptr, nullptr, nullptr, smem_tp, big, 0, 1,
+            blk_out + LQ, v.linv + (size_t)item * MC * MC, blk_out, v.yv + (size_t)item * MC, blk_out + MC * MC, nullptr, NoMidWork(), &cc,
+            n_cols);
+        return;
+    }
     ItemHdr* hs = prepare_item_ex<MC, IPP_FACTOR, kPrepThreads, true, NoMidWork, true>(
         v, item, root_ids, nullptr, action, prev_action, nullptr, flags_eff, status_out, nullptr, nullptr, nullptr, smem_tp, big, 0, 1,
         nullptr, v.linv + (size_t)item * MC * MC, blk_out, v.yv + (size_t)item * MC, blk_out + MC * MC, nullptr, NoMidWork(), &cc,
@@ -201,11 +210,13 @@ __global__ __launch_bounds__(kPrepThreads, IPP_PREP_MINWAVES) void k_tree_prepar
     const PrepLds<MC> pl(smem_tp);
     float* Ls = reinterpret_cast<float*>(pl.L);  // (the L scratch is free: 90 doubles >= 81 + 9 floats)
     float* ys = Ls + MC * MC;
-    solve_wave_fast<MC>(v, h, item, flags_eff, smem_tp, big, (h.rank + 3) & ~3, 1, Ls, ys, blk_out + LQ, status_out);
-    wave_lds_sync();
-    const int lane = threadIdx.x;
-    for (int i = lane; i < MC * MC; i += kWave) blk_out[i] = Ls[i];
-    if (lane < MC) blk_out[MC * MC + lane] = ys[lane];
+    if constexpr (MC == 9) {
+        solve_wave_fast<MC>(v, h, item, flags_eff, smem_tp, big, (h.rank + 3) & ~3, 1, Ls, ys, blk_out + LQ, status_out);
+        wave_lds_sync();
+        const int lane = threadIdx.x;
+        for (int i = lane; i < MC * MC; i += kWave) blk_out[i] = Ls[i];
+        if (lane < MC) blk_out[MC * MC + lane] = ys[lane];
+    }
 }
 
 template <int MC, int VEC, bool RECT = false>
