@@ -681,6 +681,7 @@ def run_mcts_driver(torch, device, *, grid=200, roots=1024, sims=256, in_flight=
     st = dict(mcts.stats)
     dt_arrays = None
     if driver == "device":
+        mcts.get_policy(list(range(roots)), prev, [100.0] * roots, as_arrays=True)  # (first call in this form: the result tensors are allocated)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         arr = mcts.get_policy(list(range(roots)), prev, [100.0] * roots, as_arrays=True)

@@ -334,6 +334,13 @@ typedef struct ipp_mcts_tables {
      * for Ns = 0 .. ns_table_n - 1 -- puct_c[Ns] = puct_init + log((Ns + puct_base + 1) / puct_base), sqrt_ns1[Ns] = sqrt(Ns + 1)
      * (mcts.py:280-296), tabulated by the host: an fp64 log and a square root per tree level of every descent otherwise */
     const double* puct_c; const double* sqrt_ns1; int64_t ns_table_n;
+    /* A search split into GROUPS of roots, one table set per group (DeviceMCTS(groups = 2): the groups' waves of simulations alternate on
+     * two streams, so that one group's selection -- one wave per SIMD, latency-bound -- runs beside the other's tree steps).  All 0 for a
+     * search in one piece.  Results do not depend on the split: the counter-based draws (tie breaks, Dirichlet noise) are keyed on
+     * root_base + j, root j of this set uses the device nodes [dev_base + j dev_per_root, ..) of the engine's node pool, and the tree
+     * steps of this set use the engine's per-item scratch slots from scratch_base (sets stepped at the same time: disjoint ranges;
+     * scratch_base + roots x wave <= ipp_config.max_batch; patch-layout engines only). */
+    int32_t root_base; int32_t dev_base; int32_t scratch_base; int32_t reserved0;
 } ipp_mcts_tables;
 
 /* W descents per root (virtual visits between them), from waypoint prev0[j] with budget0[j] at tree depth `depth`;

@@ -83,6 +83,7 @@ class IppMctsTables(C.Structure):
         ("rq_action", _P), ("rq_count", _P), ("ts_paths", _P), ("ts_reward", _P),
         ("ts_status", _P), ("err", _P),
         ("puct_c", _P), ("sqrt_ns1", _P), ("ns_table_n", C.c_int64),
+        ("root_base", C.c_int32), ("dev_base", C.c_int32), ("scratch_base", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 # name -> (restype, argtypes); exactly the symbols include/ipp_engine.h declares

@@ -1389,7 +1389,7 @@ static int tree_step_impl(void* engine, const int32_t* root_ids, const int32_t* 
         // (LDS sized for the waves this kernel really has: the step kernel may run 1 wave per item -- IPP_PATCH_WAVES --, the tree kernel 2 to 4)
         const int nw = e->patch_waves >= 2 ? e->patch_waves : 2;
         const size_t tlds = PatchLds::bytes(v.pcap, v.plw * v.plw, nw, v.punits, v.rank_cap);
-        const TreeEdgeOut eo = edge_out ? *edge_out : TreeEdgeOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        const TreeEdgeOut eo = edge_out ? *edge_out : TreeEdgeOut{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
         if (nw == 3 && v.rank_cap <= 192)
             timed_launch(e, 0, k_tree_patch<3, 1>, dim3(n), dim3(192), tlds, s, v, e->tv, root_ids, path_ids, new_ids, n, action, prev_action, flags, status, reward, n_dev, eo);
         else if (nw == 3)
@@ -1449,6 +1449,7 @@ static int mcts_check(const ipp_mcts_tables* t) {
         !t->rq_parent || !t->rq_k || !t->rq_child || !t->rq_newdev || !t->rq_cost || !t->rq_prev || !t->rq_action || !t->rq_count ||
         !t->ts_paths || !t->ts_reward || !t->ts_status || !t->err)
         return fail(-1, "ipp_mcts_tables: null buffer");
+    if (t->root_base < 0 || t->dev_base < 0 || t->scratch_base < 0) return fail(-1, "ipp_mcts_tables: root_base, dev_base and scratch_base must be >= 0");
     return 0;
 }
 
@@ -1484,13 +1485,17 @@ int ipp_mcts_steps(void* engine, const ipp_mcts_tables* t, int32_t first, int32_
     if (first < 0 || (!dev_count && (int64_t)first + n > cap)) return fail(-1, "requests [%d, %d) outside the list of %lld", first, first + n, (long long)cap);
     if (n == 0) return 0;
     const int n_grid = dev_count ? (int)std::min<int64_t>(e->v.max_batch, (int64_t)t->roots * t->wave) : n;
-    if ((int64_t)t->roots * t->dev_per_root > e->tv.node_cap)
-        return fail(-1, "roots x dev_per_root = %lld device nodes exceed ipp_config.node_capacity = %d", (long long)t->roots * t->dev_per_root, e->tv.node_cap);
+    if ((int64_t)t->dev_base + (int64_t)t->roots * t->dev_per_root > e->tv.node_cap)
+        return fail(-1, "dev_base + roots x dev_per_root = %lld device nodes exceed ipp_config.node_capacity = %d",
+                    (long long)t->dev_base + (long long)t->roots * t->dev_per_root, e->tv.node_cap);
+    if (t->scratch_base > 0 && !e->patch) return fail(-1, "ipp_mcts_tables.scratch_base needs the patch layout");
+    if ((int64_t)t->scratch_base + n_grid > e->v.max_batch)
+        return fail(-1, "scratch_base + items = %lld exceed ipp_config.max_batch = %d", (long long)t->scratch_base + n_grid, e->v.max_batch);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(e->device));
     const size_t o = (size_t)first;
     // (the path arguments ts_paths were written by ipp_mcts_select; the patch kernel writes the edge numerators itself)
-    const TreeEdgeOut eo{t->rq_parent + o, t->rq_k + o, t->rq_cost + o, t->t_num, t->err, t->kmax};
+    const TreeEdgeOut eo{t->rq_parent + o, t->rq_k + o, t->rq_cost + o, t->t_num, t->err, t->kmax, (int)t->scratch_base};
     if (int rc = tree_step_impl(engine, t->rq_root + o, t->ts_paths + kMctsPath * o, t->rq_newdev + o, n_grid, t->rq_action + 3 * o, t->rq_prev + 3 * o,
                                 flags, t->ts_reward + o, t->ts_status + o, stream, dev_count ? t->rq_count : nullptr, e->patch ? &eo : nullptr))
         return rc;

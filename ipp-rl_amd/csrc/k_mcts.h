@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                     if (nsa == 0) nfp = 0;
                     if (nsa < nfp) uct = INFINITY;
                 }
-                const double u = m.tie_break ? mc_u01(mc_mix(seed ^ mc_mix(((uint64_t)(uint32_t)cur << 32) | (uint32_t)(k + 1)) ^ ((uint64_t)(sim0 + w) << 20))) : 0.0;
+                const double u = m.tie_break ? mc_u01(mc_mix(seed ^ mc_mix(((uint64_t)(uint32_t)(cur + m.root_base * m.nodes_per_root) << 32) | (uint32_t)(k + 1)) ^ ((uint64_t)(sim0 + w) << 20))) : 0.0;
                 if (uct > best || (uct == best && (m.tie_break ? u > best_u : k < best_k))) { best = uct; best_k = k; best_u = u; best_nsa = nsa; best_a = ai; best_c = ci; }
             };
             if (NE > 0) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_mcts_select(ipp_mcts_tables m, const in
                         const int dc = m.dev_count[j];
                         if (dc >= m.dev_per_root) m.err[1] = 1;  // device-node range exhausted: the state is not kept
                         else {
-                            newdev = j * m.dev_per_root + dc;
+                            newdev = m.dev_base + j * m.dev_per_root + dc;
                             m.dev_count[j] = dc + 1;
                             m.n_flags[child] = cfl | kNodeStored;
                         }
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_mcts_expand(ipp_mcts_tables m, const do
     }
     const double uni = m.uniform_ps[K];  // (1/A) / sum of K copies of 1/A, summed like NumPy does (host table)
     double gsum = 0.0, rest = 0.0;
-    const uint64_t nkey = mc_mix(seed ^ ((uint64_t)(uint32_t)j << 24));
+    const uint64_t nkey = mc_mix(seed ^ ((uint64_t)(uint32_t)(j + m.root_base) << 24));  // (the root's number in the whole search: ipp_mcts_tables.root_base)
     if (noise) {
         // Dirichlet(alpha) over all A actions, looked at on the K valid ones: independent Gamma(alpha) draws for those, one
         // Gamma((A - K) alpha) draw for the total of the rest (aggregation property); the reference normalises the noisy

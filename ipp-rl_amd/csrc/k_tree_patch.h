@@ -75,6 +75,8 @@ struct TreeIo {
 struct TreeEdgeOut {
     const int* parent; const int* k; const double* cost;  // [n_items] the edge (node, slot) and the cost the reward was divided by
     double* t_num; int* err; int kmax;                    // t_num == nullptr: off
+    int item_base;  // this launch's items use the per-item scratch slots [item_base, item_base + n) of the engine (overflow records, byte
+                    // counters): two searches stepped on two streams at once must not share them (ipp_mcts_tables.scratch_base)
 };
 
 template <int NW, int RJN = 0>  // (RJN: k_step_patch.h)
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     const char* base0 = reinterpret_cast<const char*>(v.cov) - kTreePatchGuard;  // offsets of the records are relative to this
     const long long root_off = (long long)root * (long long)v.cov_slot * 4 + kTreePatchGuard;
     const long long node_off = (reinterpret_cast<const char*>(tv.node_cov) - reinterpret_cast<const char*>(v.cov)) + kTreePatchGuard;
-    float* ovf = v.q + (size_t)item * v.q_item;
+    float* ovf = v.q + (size_t)(item + eo.item_base) * v.q_item;
     const int cap = v.pcap, pw = v.pw;
 
     // ------------------------------------------------------------------ the chain's columns of this thread: rectangle + byte offset
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
             meta[4] = (int)rect_pack(r0n, r1n, c0n, c1n);
         }
         if (cnt[0]) {  // (per-item totals: k_step_patch.h)
-            unsigned long long* ic = v.item_counts + 2 * (size_t)item;
+            unsigned long long* ic = v.item_counts + 2 * (size_t)(item + eo.item_base);
             atomicAdd(ic, cnt[0]);      // (no return value: the wave does not wait for the round trip; nobody else adds to this line)
             atomicAdd(ic + 1, cnt[1]);
         }

@@ -38,8 +38,21 @@ from .vector_mcts import VectorMCTS
 class DeviceMCTS(VectorMCTS):
     def __init__(self, engine, hyper_params: Dict, meta_data: Dict, infer: Optional[Callable] = None, sims_in_flight: int = 4,
                  tie_break: str = "first", seed: int = 0, leaf_value: float = 0.0, nodes_per_root: Optional[int] = None,
-                 dev_per_root: Optional[int] = None, queue_ahead: bool = True):
+                 dev_per_root: Optional[int] = None, queue_ahead: bool = True, groups: int = 2):
+        """groups > 1: the roots of a search are split into that many contiguous groups, each with its own node tables, whose waves of
+        simulations alternate on their own streams -- one group's selection (one wavefront per SIMD: latency-bound) runs beside the
+        other's tree steps, and the host's one read-back per wave of simulations waits for one group while the other's launches are
+        queued.  Same trees and policies as groups = 1 (the counter-based draws are keyed on a root's number in the whole search).
+        Used when the read-out runs on the device (temperature > 0, rngs=None, a large action set) and the engine's max_batch holds
+        all roots x sims_in_flight items; otherwise the search runs in one piece."""
         super().__init__(engine, hyper_params, meta_data, infer, None, sims_in_flight, tie_break, seed)
+        self.groups = max(1, int(groups))
+        self._ctor = dict(hyper_params=hyper_params, meta_data=meta_data, infer=infer, sims_in_flight=sims_in_flight, tie_break=tie_break,
+                          seed=seed, leaf_value=leaf_value, nodes_per_root=nodes_per_root, dev_per_root=dev_per_root, queue_ahead=queue_ahead)
+        self._root_base = self._dev_base = self._scratch_base = 0  # (a group's offsets in the whole search: ipp_mcts_tables)
+        self._total_roots = None
+        self._subs = None
+        self._group_streams = None
         self.leaf_value = float(leaf_value)
         self.queue_ahead = bool(queue_ahead)  # (False: every step launch waits for the wave's request count -- tests, A/B)
         self.seed = int(seed)
@@ -82,8 +95,8 @@ class DeviceMCTS(VectorMCTS):
         dev = eng.device
         geo = self._geometry(torch, dev)
         K, npr, W = geo["kmax"], self.nodes_per_root, self.sims_in_flight
-        if R * self.dev_per_root > eng._c.node_capacity:
-            raise ValueError(f"{R} roots x {self.dev_per_root} device nodes exceed the engine's node_capacity {eng._c.node_capacity}")
+        if self._dev_base + R * self.dev_per_root > eng._c.node_capacity:
+            raise ValueError(f"{R} roots x {self.dev_per_root} device nodes (from node {self._dev_base}) exceed the engine's node_capacity {eng._c.node_capacity}")
         cap = R * npr
         tsz = 1
         while tsz < 2 * npr:
@@ -114,7 +127,8 @@ class DeviceMCTS(VectorMCTS):
             horizon=self.horizon, grid_w=self._W, grid_h=self._H, n_levels=self._n_lv, n_off=len(self._off_x),
             num_actions=self.num_actions, use_flight_time=1 if uav is not None else 0, tie_break=0 if self.tie_break == "first" else 1,
             device=dev.index or 0, res=self._res, max_dist=self.max_dist, gamma=self.gamma, puct_init=self.puct_init,
-            puct_base=self.puct_base, fpf=self.fpf, vmax=float(uav["max_v"]) if uav else 1.0, amax=float(uav["max_a"]) if uav else 1.0)
+            puct_base=self.puct_base, fpf=self.fpf, vmax=float(uav["max_v"]) if uav else 1.0, amax=float(uav["max_a"]) if uav else 1.0,
+            root_base=self._root_base, dev_base=self._dev_base, scratch_base=self._scratch_base)
         for name in ("actions", "cell_action", "off_x", "off_y", "zkey"):
             setattr(tab, name, geo[name].data_ptr())
         tab.uniform_ps = geo["uniform"].data_ptr()
@@ -147,6 +161,22 @@ class DeviceMCTS(VectorMCTS):
         the roots share one generator (rngs=None); the reference's per-root (dict, valid indices) pairs are then built from two
         arrays.  as_arrays=True skips that: returns {"policy": [R, kmax] float64, "valid_idx": [R, kmax] int32 (-1 padded),
         "K": [R], "ok": [R] (0 where the reference returns None)} as DEVICE tensors (valid until the next search)."""
+        R = len(roots)
+        on_device = (rngs is None and temperature > 0 and self.num_actions > self.DENSE_ACTIONS
+                     and os.environ.get("IPP_MCTS_HOST_READOUT", "0") != "1")
+        G = min(self.groups, R // 2)
+        if G > 1 and on_device and self.queue_ahead and bool(int(self.engine.info.patch_layout)) and \
+                self.engine.max_batch >= R * self.sims_in_flight:
+            return self._get_policy_groups(G, roots, previous_actions, budgets, depth, temperature, deploy_time, as_arrays)
+        self._subs_used = None
+        state = {}
+        for _ in self._search(roots, previous_actions, budgets, depth, state):
+            pass  # (one piece: wait where the generator says the host has to)
+        return self._policies(state["b"], R, self.nodes_per_root, state["prev0"], state["budget0"], temperature, deploy_time, rngs, roots, as_arrays)
+
+    def _search(self, roots, previous_actions, budgets, depth, state):
+        """The waves of simulations of one search on the CURRENT stream, as a generator: it yields right before the host has to wait
+        for the wave's counts, so that a caller with several groups of roots can issue the other groups' launches first."""
         import torch
 
         eng, lib = self.engine, self.engine._lib
@@ -167,7 +197,7 @@ class DeviceMCTS(VectorMCTS):
         b["n_flags"][root_nodes] = 2
         b["n_value"].zero_()
         b["n_devpath"].fill_(-1)
-        b["n_hash"][root_nodes] = (torch.arange(R, device=dev, dtype=torch.int64) + 1) * (-7046029254386353131)  # 0x9E3779B97F4A7C15
+        b["n_hash"][root_nodes] = (torch.arange(R, device=dev, dtype=torch.int64) + 1 + self._root_base) * (-7046029254386353131)  # 0x9E3779B97F4A7C15
         b["root_count"].fill_(1)
         b["dev_count"].zero_()
         b["h_keys"].zero_()
@@ -193,6 +223,7 @@ class DeviceMCTS(VectorMCTS):
             ev.record()
             if ahead:
                 _ffi.check(lib.ipp_mcts_steps(eng._h, tp, 0, -1, flags, stream))
+            yield sim
             ev.synchronize()  # the one synchronisation of the wave
             n, n_pending = int(counts_h[R]), int(counts_h[:R].sum())
             first = R * W if ahead else 0
@@ -214,7 +245,84 @@ class DeviceMCTS(VectorMCTS):
                                f"raise nodes_per_root / the engine's node_capacity")
         if err[2]:
             raise RuntimeError(f"ipp_tree_step reported status {int(err[2])} (rank_cap / footprint)")
-        return self._policies(b, R, npr, prev0, budget0, temperature, deploy_time, rngs, roots, as_arrays)
+        state.update(b=b, prev0=prev0, budget0=budget0)
+
+    # ------------------------------------------------------------------ groups of roots on their own streams
+    def _group_setup(self, G, R):
+        """Sub-searches (one table set each) for the contiguous groups of R roots and one stream per group, on different hardware
+        queues where the runtime has them (ipp_probe_stream_pair, as VecIPPEnv picks the streams of its parts)."""
+        import torch
+
+        sizes = [R // G + (1 if g < R % G else 0) for g in range(G)]
+        if self._subs is None or [s._group_size for s in self._subs] != sizes:
+            self._subs = []
+            base = 0
+            for g, n in enumerate(sizes):
+                sub = DeviceMCTS(self.engine, groups=1, **self._ctor)
+                sub.nodes_per_root, sub.dev_per_root = self.nodes_per_root, self.dev_per_root
+                sub._root_base, sub._dev_base, sub._scratch_base = base, base * self.dev_per_root, base * self.sims_in_flight
+                sub._total_roots, sub._group_size = R, n
+                sub.stats = self.stats  # (one set of counters for the whole search)
+                self._subs.append(sub)
+                base += n
+        if self._group_streams is None or len(self._group_streams) != G:
+            eng, main = self.engine, torch.cuda.current_stream(self.engine.device)
+            got = []
+            try:
+                thr = 0.75 * min(eng.probe_stream_pair(main, main, 12) for _ in range(2))
+                for _ in range(12):
+                    st = torch.cuda.Stream(device=eng.device)
+                    with torch.cuda.stream(st):
+                        torch.zeros(8, device=eng.device).add_(1)
+                    if eng.probe_stream_pair(st, main, 12) > thr:
+                        continue  # (shares the caller's queue)
+                    if all(eng.probe_stream_pair(st, o, 12) <= thr for o in got):
+                        got.append(st)
+                    if len(got) == G:
+                        break
+            except Exception:
+                got = []
+            while len(got) < G:  # (fewer hardware queues than groups, or no probe: streams as they come)
+                got.append(torch.cuda.Stream(device=eng.device))
+            self._group_streams = got
+        return sizes
+
+    def _get_policy_groups(self, G, roots, previous_actions, budgets, depth, temperature, deploy_time, as_arrays):
+        import torch
+
+        R = len(roots)
+        sizes = self._group_setup(G, R)
+        prev = np.asarray(previous_actions, dtype=np.float64).reshape(R, 3)
+        bud = np.asarray(budgets, dtype=np.float64).reshape(R)
+        main = torch.cuda.current_stream(self.engine.device)
+        gens, states, lo = [], [], 0
+        for sub, n, st in zip(self._subs, sizes, self._group_streams):
+            st.wait_stream(main)  # (the roots' states were written on the caller's stream)
+            state = {}
+            gens.append(sub._search(list(roots[lo:lo + n]), prev[lo:lo + n], bud[lo:lo + n], depth, state))
+            states.append(state)
+            lo += n
+        alive = list(range(G))
+        while alive:  # a turn = everything a group can issue before its next wait: the other groups' launches are queued by then
+            for g in list(alive):
+                with torch.cuda.stream(self._group_streams[g]):
+                    try:
+                        next(gens[g])
+                    except StopIteration:
+                        alive.remove(g)
+        outs = []
+        for sub, n, st, state in zip(self._subs, sizes, self._group_streams, states):
+            with torch.cuda.stream(st):
+                outs.append(sub._policies(state["b"], n, self.nodes_per_root, state["prev0"], state["budget0"], temperature, deploy_time, None,
+                                          None, as_arrays))
+            main.wait_stream(st)
+        self.stats["nodes"] = sum(sub._nodes_last for sub in self._subs)
+        self._subs_used = self._subs
+        self._host_rows = {}
+        self.root_ids = np.arange(R)
+        if as_arrays:
+            return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+        return [p for o in outs for p in o]
 
     def _expand(self, lib, tp, b, R, W, root_env, stream):
         import torch
@@ -283,7 +391,9 @@ class DeviceMCTS(VectorMCTS):
         if not deploy_time:
             shared = np.random.RandomState(self.seed & 0x7fffffff)
             self._shared_rng = shared
-            o["u"].copy_(torch.from_numpy(shared.random_sample(R)))
+            # (a group of a split search takes ITS roots' draws of the whole search's sequence)
+            u_all = shared.random_sample(self._total_roots or R)
+            o["u"].copy_(torch.from_numpy(u_all[self._root_base:self._root_base + R]))
             u_ptr = o["u"].data_ptr()
         _ffi.check(eng._lib.ipp_mcts_policy(C.byref(self._tab), u_ptr, float(temperature), int(bool(deploy_time)), o["policy"].data_ptr(),
                                             o["valid_idx"].data_ptr(), o["ok"].data_ptr(), eng.stream))
@@ -291,7 +401,7 @@ class DeviceMCTS(VectorMCTS):
         root_nodes = torch.arange(R, device=o["ok"].device, dtype=torch.int64) * npr
         K_dev = b["n_k"][root_nodes]
         if as_arrays:
-            self.stats["nodes"] = int(nodes.item())
+            self._nodes_last = self.stats["nodes"] = int(nodes.item())
             return dict(policy=o["policy"], valid_idx=o["valid_idx"], K=K_dev, ok=o["ok"])
         h = self._out_host
         h["policy"].copy_(o["policy"], non_blocking=True)
@@ -300,7 +410,7 @@ class DeviceMCTS(VectorMCTS):
         h["K"].copy_(K_dev, non_blocking=True)
         h["nodes"].copy_(nodes, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        self.stats["nodes"] = int(h["nodes"].item())
+        self._nodes_last = self.stats["nodes"] = int(h["nodes"].item())
         p, ok, K = h["policy"].numpy(), h["ok"].numpy(), h["K"].numpy()
         t_idx = h["valid_idx"].numpy().astype(np.int64)
         self._host_rows["t_idx"] = t_idx
@@ -391,6 +501,9 @@ class DeviceMCTS(VectorMCTS):
     def _root_rows(name):  # noqa: N805 (builds the properties below)
         def get(self):
             rows = self.__dict__.setdefault("_host_rows", {})
+            subs = self.__dict__.get("_subs_used")
+            if name not in rows and subs:
+                rows[name] = np.concatenate([getattr(sub, name) for sub in subs])
             if name not in rows:
                 src = self.__dict__.get("_rows_src")
                 if src is None:

@@ -61,7 +61,8 @@ def test_struct_layouts_match_header_order():
             is_ptr = bool(m.group(2)) or name.strip().startswith("*")
             fields.append((name.strip().lstrip("*").strip(), ctypes.c_void_p if is_ptr else {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "double": ctypes.c_double}[m.group(1)]))
     assert fields == list(_ffi.IppMctsTables._fields_)
-    assert ctypes.sizeof(_ffi.IppMctsTables) == 16 * 4 + 8 * 8 + 46 * 8 + 2 * 8 + 8  # (.. + the optional Ns tables and their length)
+    # (.. + the optional Ns tables and their length + the four int32 of a search split into groups of roots)
+    assert ctypes.sizeof(_ffi.IppMctsTables) == 16 * 4 + 8 * 8 + 46 * 8 + 2 * 8 + 8 + 4 * 4
 
 
 def test_arena_sizing_and_validation_without_gpu():

@@ -425,3 +425,51 @@ def test_device_search_step_launch_behind_the_selection_equals_exact_launches():
     assert st_a["nodes"] == st_b["nodes"] and st_a["device_steps"] == st_b["device_steps"] and st_a["inferences"] == st_b["inferences"]
     for j in roots:
         assert out_a[j][0] == out_b[j][0]
+
+
+@pytest.mark.parametrize("R,groups,W,tie", [(48, 2, 4, "random"), (37, 2, 8, "random"), (30, 3, 4, "first")])
+def test_grouped_search_equals_the_search_in_one_piece(R, groups, W, tie):
+    """DeviceMCTS(groups=G): the roots as G contiguous groups with their own node tables, their waves of simulations alternating on G
+    streams (one group's selection beside the other's tree steps; ipp_mcts_tables.root_base / dev_base / scratch_base).  Roots are
+    independent searches (planning/mcts_zero/mcts.py:166-265 per root) and every counter-based draw is keyed on a root's number in the
+    WHOLE search, so statistics and policies must equal the search in one piece exactly -- uneven groups, random ties + Dirichlet noise."""
+    from ipp_rl_amd.planning.mcts_zero.device_mcts import DeviceMCTS
+
+    dim, sims, horizon = 50, 64, 4
+    eng, prev, hyper, meta = _search_setup(dim, R, sims, horizon, eps=0.25, node_slack=16)
+    assert eng.info.patch_layout == 1
+    roots = list(range(R))
+    # (max_batch = 4 R in the shared setup: the grouped path needs roots x W items)
+    if eng.max_batch < R * W:
+        eng.close()
+        from ipp_rl_amd import EngineConfig, IPPEngine
+        from ipp_rl_amd.vec_env import cell_centre_actions
+
+        cfg = EngineConfig(x_dim=dim, y_dim=dim)
+        eng = IPPEngine(cfg, capacity=R, state="factor", rank_cap=9 * (3 + horizon + 2), window_rows=-1, fixed_prior=True,
+                        node_capacity=R * (sims + 16), max_batch=W * R)
+        rs = np.random.RandomState(2)
+        eng.reset(white_noise=rs.normal(size=(R, dim, dim)))
+        prev = np.tile([2.0, 2.0, 14.0], (R, 1))
+        for t in range(3):
+            acts = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
+            eng.step(acts, prev, meas_noise=rs.normal(size=(R, 9)))
+            prev = acts
+    res = []
+    for g in (1, groups):
+        s = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break=tie, seed=9, leaf_value=0.3, groups=g)
+        assert s.num_actions > s.DENSE_ACTIONS
+        out = s.get_policy(roots, prev, [60.0] * R)
+        assert (s._subs_used is not None) == (g > 1) and (g == 1 or len(s._subs_used) == g)
+        assert DeviceMCTS(eng, hyper, meta).groups == 2  # (the default)
+        idx, nsa, q = s.root_statistics()
+        arr = s.get_policy(roots, prev, [60.0] * R, as_arrays=True)
+        res.append((out, idx.copy(), nsa.copy(), q.copy(), dict(s.stats), {k: v.cpu().numpy() for k, v in arr.items()}))
+    (out_a, idx_a, nsa_a, q_a, st_a, arr_a), (out_b, idx_b, nsa_b, q_b, st_b, arr_b) = res
+    assert np.array_equal(idx_a, idx_b) and np.array_equal(nsa_a, nsa_b) and np.array_equal(q_a, q_b)
+    assert st_a["nodes"] == st_b["nodes"] and st_a["device_steps"] == st_b["device_steps"] and st_a["inferences"] == st_b["inferences"]
+    for j in roots:
+        assert out_a[j][0] == out_b[j][0] and np.array_equal(out_a[j][1], out_b[j][1])
+    for k in arr_a:
+        assert np.array_equal(arr_a[k], arr_b[k]), k
+    eng.close()

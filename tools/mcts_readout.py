@@ -36,11 +36,15 @@ for t in range(root_steps):
     a = cell_centre_actions(cfg, t, 0, R, R, [8.0, 14.0])
     eng.step(a, prev, meas_noise=noise[t])
     prev = a
-m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break=os.environ.get("TIE", "random"), leaf_value=0.3)
+m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break=os.environ.get("TIE", "random"), leaf_value=0.3,
+               **({"groups": int(os.environ["MCTS_GROUPS"])} if os.environ.get("MCTS_GROUPS") else {}))
 roots, budgets = list(range(R)), [100.0] * R
 for _ in range(2):
     m.get_policy(roots, prev, budgets)
 torch.cuda.synchronize()
+print("groups", m.groups, "queue_ahead", m.queue_ahead, "patch", int(eng.info.patch_layout), "max_batch", eng.max_batch, "R*W", R * m.sims_in_flight,
+      "actions", m.num_actions, m.DENSE_ACTIONS, flush=True)
+print("groups used:", len(m._subs_used) if getattr(m, "_subs_used", None) else 1, flush=True)
 for kw in ({}, {"as_arrays": True}):
     if kw and "as_arrays" not in DeviceMCTS.get_policy.__code__.co_varnames:
         break
