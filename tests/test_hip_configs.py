@@ -352,25 +352,30 @@ def test_fullsize_device_search_1024_roots_256_sims_200x200():
             "altitude_spacing": 6.0, "uav_specifications": UAV, "scenario_info": {"value_threshold": 0.4, "interval_factor": 0}}
     mcts = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break="random", seed=1, leaf_value=0.3)
     out = mcts.get_policy(list(range(roots)), prev, [100.0] * roots)
-    b = mcts._buf
-    used = b["root_count"].cpu().numpy()
+    pieces = mcts._subs_used or [mcts]  # (the default search runs as two groups of roots with their own tables)
+    assert len(pieces) == mcts.groups == 2
     npr = mcts.nodes_per_root
-    assert used.max() < npr and int(b["dev_count"].max()) <= mcts.dev_per_root and int(b["err"].abs().sum()) == 0
-    print(f"[configs[4] device search] {mcts.stats['nodes']} nodes (most per root {used.max()} of {npr}), "
+    used_max = 0
+    for piece in pieces:
+        b = piece._buf
+        used = b["root_count"].cpu().numpy()
+        used_max = max(used_max, int(used.max()))
+        assert used.max() < npr and int(b["dev_count"].max()) <= mcts.dev_per_root and int(b["err"].abs().sum()) == 0
+        live = (torch.arange(npr, device="cuda")[None, :] < b["root_count"][:, None].to(torch.int64)).reshape(-1)  # node ids in use
+        exp = ((b["n_flags"] & 1) != 0) & live
+        K = b["n_k"].to(torch.int64)
+        col = torch.arange(b["t_idx"].shape[1], device="cuda")[None, :]
+        inside = (col < K[:, None]) & exp[:, None]
+        nsa, q, num, idx = b["t_nsa"], b["t_qsa"], b["t_num"], b["t_idx"]
+        assert bool(((idx >= 0) == (col < K[:, None]))[exp].all())                                   # valid sets are exactly K long
+        assert bool((idx[:, 1:] > idx[:, :-1])[inside[:, 1:]].all())                                 # ... and ascending
+        assert bool(torch.equal(torch.where(inside, nsa, torch.zeros_like(nsa)).sum(dim=1)[exp], b["n_ns"][exp]))  # virtual visits undone
+        assert bool((nsa[inside] >= 0).all()) and bool(torch.isfinite(q[inside]).all()) and bool((q[inside] >= 0).all())
+        trav = inside & ~torch.isnan(num)
+        assert bool(torch.isfinite(num[trav]).all()) and bool((num[trav] > 0).all())                 # every traversed edge has its trace reduction
+        assert bool(((nsa > 0) & inside & torch.isnan(num)).sum() == 0)                              # no visited edge without one
+    print(f"[configs[4] device search] {mcts.stats['nodes']} nodes (most per root {used_max} of {npr}), "
           f"{mcts.stats['device_steps']} device steps in {mcts.stats['launches']} launches")
-    live = (torch.arange(npr, device="cuda")[None, :] < b["root_count"][:, None].to(torch.int64)).reshape(-1)  # node ids in use
-    exp = ((b["n_flags"] & 1) != 0) & live
-    K = b["n_k"].to(torch.int64)
-    col = torch.arange(b["t_idx"].shape[1], device="cuda")[None, :]
-    inside = (col < K[:, None]) & exp[:, None]
-    nsa, q, num, idx = b["t_nsa"], b["t_qsa"], b["t_num"], b["t_idx"]
-    assert bool(((idx >= 0) == (col < K[:, None]))[exp].all())                                   # valid sets are exactly K long
-    assert bool((idx[:, 1:] > idx[:, :-1])[inside[:, 1:]].all())                                 # ... and ascending
-    assert bool(torch.equal(torch.where(inside, nsa, torch.zeros_like(nsa)).sum(dim=1)[exp], b["n_ns"][exp]))  # virtual visits undone
-    assert bool((nsa[inside] >= 0).all()) and bool(torch.isfinite(q[inside]).all()) and bool((q[inside] >= 0).all())
-    trav = inside & ~torch.isnan(num)
-    assert bool(torch.isfinite(num[trav]).all()) and bool((num[trav] > 0).all())                 # every traversed edge has its trace reduction
-    assert bool(((nsa > 0) & inside & torch.isnan(num)).sum() == 0)                              # no visited edge without one
     for j in range(roots):
         Kj = int(mcts.n_K[j])
         assert mcts.n_Ns[j] == sims - W == mcts.t_Nsa[j, :Kj].sum()

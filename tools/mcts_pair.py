@@ -40,7 +40,7 @@ def make(roots, seed):
         a = cell_centre_actions(cfg, t, 0, roots, roots, [8.0, 14.0])
         eng.step(a, prev, meas_noise=noise[t])
         prev = a
-    m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break="random", leaf_value=0.3)
+    m = DeviceMCTS(eng, hyper, meta, None, sims_in_flight=W, tie_break="random", leaf_value=0.3, groups=1)  # (this tool does the grouping itself)
     m.get_policy(list(range(roots)), prev, [100.0] * roots)  # (allocates the tables)
     return eng, m, prev
 
