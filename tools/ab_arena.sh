@@ -14,10 +14,10 @@ for l in sys.stdin:
     done
 }
 {
-for mode in "IPP_ARENA=torch" "IPP_ARENA=vmm IPP_ARENA_CHUNK_MIB=64" "IPP_ARENA=vmm IPP_ARENA_CHUNK_MIB=1024" "IPP_ARENA=vmm IPP_ARENA_CHUNK_MIB=2048"; do
+for mode in "IPP_ARENA=torch" "IPP_ARENA=auto"; do
     run "cfg3share [$mode]" "$mode" --envs 32768 --grid 50
 done
-for mode in "IPP_ARENA=torch" "IPP_ARENA=vmm IPP_ARENA_CHUNK_MIB=64" "IPP_ARENA=vmm IPP_ARENA_CHUNK_MIB=1024"; do
+for mode in "IPP_ARENA=torch" "IPP_ARENA=auto"; do
     run "headline [$mode]" "$mode"
     run "cfg2 [$mode]" "$mode" --envs 32768 --grid 100 --episode-steps 16
 done

@@ -11,12 +11,17 @@ for k in 10 20 50 200; do python bench.py --no-cpu-baseline --no-extra --steps $
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']
 print('steps', d['steps'], 'value %.2f M' % (d['value']/1e6), 'ms/step %.4f' % d['ms_per_step'], 'host issue %.4f' % (c.get('host_issue_ms_per_step') or 0), 'regions', ['%.4f' % x for x in c['region_ms_per_step']])"; done > $O/region_sweep.txt 2>&1; cat $O/region_sweep.txt
+# the split step (prologue kernel + unit kernel) against the fused kernel (round 5's question; ROUND_SPLIT=1 repeats it)
+if [ "$ROUND_SPLIT" = "1" ]; then
 # the split step (prologue kernel + unit kernel) against the fused kernel, same box: headline, one launch per step, configs[2], configs[3] share
 { CFG="--parts 2" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"
   CFG="--parts 1 --steps 100" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"
   CFG="--grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"
   CFG="--grid 50 --envs 32768 --steps 20 --warmup 4" bash tools/ab_cfg.sh "IPP_SPLIT=0" "IPP_SPLIT=1 IPP_SPLIT_WAVES=1"; } > $O/ab_split.txt 2>&1
 [ -f tools/probes/libipp_timing.so ] && { for w in 1 3; do echo "=== split step, prologue kernel with $w waves per item, 2 groups"; IPP_SPLIT_WAVES=$w python tools/timeline_split.py 2 2>&1 | grep -v amdgpu.ids | head -40; done; } > $O/timeline_split.txt 2>&1
+fi
+# round 6: the arena's origin (torch tensor against the virtual-memory API), fresh processes on the driver's protocol
+bash tools/ab_arena.sh > /dev/null 2>&1; cp gpurun_out/arena/ab_arena.txt $O/ab_arena.txt
 {
   python tools/compat_bench.py
   python tools/score_bench.py --steps 12
@@ -39,19 +44,19 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_mct
 # PMC passes (separate runs, counters only)
 bash tools/pmc_run.sh $O/pmc --parts 1 > $O/pmc_run.log 2>&1
 python tools/pmc_summary.py $O/pmc 40 > $O/pmc_summary.json 2>$O/pmc_summary.err; head -c 120 $O/pmc_summary.json
+if [ "$ROUND_SPLIT" = "1" ]; then
 # the split step's kernels (unit kernel: waves' wait share, traffic; prologue kernel) -- its summary is NOT named *pmc_summary*: bench.py
 # replays traffic from those, and the split run has the same command line
 IPP_SPLIT=1 PMC_CUSTOM="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES;FETCH_SIZE;WRITE_SIZE TCC_HIT_sum TCC_MISS_sum;SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" bash tools/pmc_run.sh $O/pmc_split --parts 1 > $O/pmc_run_split.log 2>&1
 python tools/pmc_summary.py $O/pmc_split 40 > $O/split_pmc.json 2>>$O/pmc_summary.err
+fi
 PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_w12 --parts 1 --shuffle-prior > $O/pmc_run_w12.log 2>&1
 python tools/pmc_summary.py $O/pmc_w12 40 > $O/pmc_summary_w12.json 2>>$O/pmc_summary.err
-PMC_SETS=traffic bash tools/pmc_run.sh $O/pmc_cfg2 --parts 1 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
+bash tools/pmc_run.sh $O/pmc_cfg2 --parts 1 --grid 100 --envs 32768 --episode-steps 16 --steps 20 --warmup 4 > $O/pmc_run_cfg2.log 2>&1
 python tools/pmc_summary.py $O/pmc_cfg2 16 > $O/pmc_summary_cfg2.json 2>>$O/pmc_summary.err
 # address-pattern probe of the column layouts (GB/s + FETCH_SIZE per pattern: the FETCH_SIZE calibration on the step kernel's own
 # request shapes) and the occupancy timeline of one k_step_patch launch (needs `make -C ipp-rl_amd/csrc timeline` before gpurun)
 # round 4: issue cost of the kernels' instruction kinds, wave priority, the partitioned schedule against one launch per step
-hipcc --offload-arch=gfx950 -O3 tools/probes/issue_probe.hip -o /tmp/issue_probe 2>/dev/null && /tmp/issue_probe > $O/issue_probe.txt 2>&1
-hipcc --offload-arch=gfx950 -O3 tools/probes/prio_probe.hip -o /tmp/prio_probe 2>/dev/null && /tmp/prio_probe > $O/prio_probe.txt 2>&1
 rm -f gpurun_out/ab/ab_parts.txt; bash tools/ab_parts.sh 1 2 3 > /dev/null 2>&1; cp gpurun_out/ab/ab_parts.txt $O/ab_parts.txt
 python tools/parts_probe.py 2>&1 | grep -v amdgpu.ids > $O/parts_probe.txt
 python tools/grf_bench.py 50:102 50:819 100:2048 > $O/grf_bench.txt 2>&1; IPP_GRF_FFT=0 python tools/grf_bench.py 50:102 50:819 100:2048 >> $O/grf_bench.txt 2>&1
