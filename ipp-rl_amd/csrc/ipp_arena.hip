@@ -91,6 +91,17 @@ __global__ __launch_bounds__(64) void k_arena_latency(const float* __restrict__ 
     if (acc == 123.456f) out[0] = acc;
 }
 
+// scratch of a probe call, released on every return path
+struct ProbeScratch {
+    float* sink = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ~ProbeScratch() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (sink) (void)hipFree(sink);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -223,12 +234,13 @@ int ipp_arena_probe(int device, const void* arena, uint64_t bytes, int32_t items
     if (cols < 1) return ipp::set_error(-1, "ipp_arena_probe: arena smaller than one patch per item");
     ARENA_TRY(hipSetDevice(device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static thread_local float* sink = nullptr;
-    if (!sink) ARENA_TRY(hipMalloc(&sink, 64));
+    ProbeScratch ps;  // (per call: a cached sink would belong to ONE device)
+    ARENA_TRY(hipMalloc(&ps.sink, 64));
     ARENA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_arena_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 20480));
-    hipEvent_t a, b;
-    ARENA_TRY(hipEventCreate(&a));
-    ARENA_TRY(hipEventCreate(&b));
+    ARENA_TRY(hipEventCreate(&ps.a));
+    ARENA_TRY(hipEventCreate(&ps.b));
+    float* sink = ps.sink;
+    hipEvent_t a = ps.a, b = ps.b;
     const int c = (int)(cols > 0x7fffffff ? 0x7fffffff : cols);
     for (int i = 0; i < 2; ++i)
         hipLaunchKernelGGL(k_arena_probe, dim3(items), dim3(128), 20480, s, (const float*)arena, slot_floats, items, rows, c, sink);
@@ -240,8 +252,6 @@ int ipp_arena_probe(int device, const void* arena, uint64_t bytes, int32_t items
     float t = 0.f;
     ARENA_TRY(hipEventElapsedTime(&t, a, b));
     *ms = (double)t / launches;
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
     ARENA_TRY(hipGetLastError());
     return 0;
 }
@@ -252,11 +262,12 @@ int ipp_arena_latency(int device, const void* arena, uint64_t bytes, int32_t wav
     if (n_patches < 1) return ipp::set_error(-1, "ipp_arena_latency: arena smaller than one patch");
     ARENA_TRY(hipSetDevice(device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static thread_local float* sink = nullptr;
-    if (!sink) ARENA_TRY(hipMalloc(&sink, 64));
-    hipEvent_t a, b;
-    ARENA_TRY(hipEventCreate(&a));
-    ARENA_TRY(hipEventCreate(&b));
+    ProbeScratch ps;
+    ARENA_TRY(hipMalloc(&ps.sink, 64));
+    ARENA_TRY(hipEventCreate(&ps.a));
+    ARENA_TRY(hipEventCreate(&ps.b));
+    float* sink = ps.sink;
+    hipEvent_t a = ps.a, b = ps.b;
     hipLaunchKernelGGL(k_arena_latency, dim3(waves), dim3(64), 0, s, (const float*)arena, n_patches, hops, 0u, sink);
     ARENA_TRY(hipEventRecord(a, s));
     hipLaunchKernelGGL(k_arena_latency, dim3(waves), dim3(64), 0, s, (const float*)arena, n_patches, hops, 0u, sink);
@@ -265,8 +276,6 @@ int ipp_arena_latency(int device, const void* arena, uint64_t bytes, int32_t wav
     float t = 0.f;
     ARENA_TRY(hipEventElapsedTime(&t, a, b));
     *ns_per_hop = 1e6 * (double)t / hops;
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
     ARENA_TRY(hipGetLastError());
     return 0;
 }
