@@ -88,6 +88,32 @@ def test_arena_sizing_and_validation_without_gpu():
     assert lib.ipp_engine_arena_bytes(ctypes.byref(c), ctypes.byref(nbytes)) < 0
 
 
+def test_arena_calls_validate_their_arguments_without_gpu():
+    """ipp_arena_* (include/ipp_engine.h "Arena placement"): argument errors are reported before any device call; freeing nothing is fine; the
+    Python layer refuses to build a DeviceArena without a device (no host fallback for device memory)."""
+    from ipp_rl_amd import _ffi, engine
+
+    lib = _ffi.load()
+    out = ctypes.c_void_p()
+    assert lib.ipp_arena_alloc(0, 0, _ffi.IPP_ARENA_VMM, 0, 0, ctypes.byref(out)) == -1 and b"ipp_arena_alloc" in lib.ipp_last_error()
+    assert lib.ipp_arena_alloc(0, 1 << 20, _ffi.IPP_ARENA_VMM, 0, 0, None) == -1
+    assert lib.ipp_arena_free(None) == 0
+    assert lib.ipp_arena_free(ctypes.c_void_p(0x1000)) == -1 and b"not an arena" in lib.ipp_last_error()
+    ms, n = ctypes.c_double(), ctypes.c_uint64(123)
+    assert lib.ipp_arena_probe(0, None, 1 << 20, 4, 4, 1, None, ctypes.byref(ms)) == -1
+    assert lib.ipp_arena_probe(0, ctypes.c_void_p(0x1000), 1 << 20, 0, 4, 1, None, ctypes.byref(ms)) == -1
+    assert lib.ipp_arena_probe(0, ctypes.c_void_p(0x1000), 64, 4, 4, 1, None, ctypes.byref(ms)) == -1 and b"smaller than one patch" in lib.ipp_last_error()
+    assert lib.ipp_arena_latency(0, None, 1 << 20, 4, 4, None, ctypes.byref(ms)) == -1
+    assert lib.ipp_arena_retired_bytes(None) == -1
+    assert lib.ipp_arena_retired_bytes(ctypes.byref(n)) == 0 and n.value == 0
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(_ffi.IppError):
+            engine.DeviceArena(1 << 20, 0, kind="vmm")
+    assert engine.ARENA_VMM_MIN_BYTES == 256 << 20
+
+
 def test_tree_patches_stay_within_reach_of_their_32_bit_record_offsets():
     """k_tree_patch addresses a column patch by a 32-bit offset in 8-byte units from View::cov: root slots and node blocks have to lie
     within 2^35 bytes of it.  The decision is taken on the finished arena layout (the score scratch -- one dense P, 17 GB at
