@@ -190,7 +190,7 @@ __device__ __forceinline__ auto row_load_masked(const float* row, unsigned row_b
 // aliasing); the caller guarantees the rows are complete and visible before the call and unchanged during it.
 // RESET (ipp_step_autoreset): an item with ar->src[item] >= 0 resets its env once its step is complete: every wave
 // waits for its own stores / atomics before it counts itself done, the last wave then rewrites the env's planes.
-// NW > 0: that many waves of the workgroup run the tile loop of this item (k_step_pipe: the consumer waves), else all.
+// NW > 0: that many waves of the workgroup run the tile loop of this item (a persistent variant of rounds 2-4, deleted: the consumer waves), else all.
 template <int MC, int VEC, int KP, bool PRE, bool LMASK, bool CHAIN = false, bool QCONST = false, bool RESET = false, int NW = 0,
           bool RECT = false>
 __device__ __forceinline__ void gain_tiles(const View& v, const ItemHdr& h, const int item, unsigned flags, int lut_rows,

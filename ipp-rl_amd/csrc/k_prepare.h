@@ -175,7 +175,7 @@ struct NoMidWork { __device__ __forceinline__ void operator()(const ItemHdr&) co
 //   mid_work     called once between issuing the footprint-dependent loads and consuming them (free compute slot)
 //   CHAIN / cc   factor columns come from a chained tree state (ChainCols) instead of the env's own slab; rank_chain
 //                is then the state's column count
-// WAVE (NT == 64): the caller is ONE wave of a larger workgroup (the producer wave of k_step_pipe): every barrier of the
+// WAVE (NT == 64): the caller is ONE wave of a larger workgroup (the producer wave of the persistent kernel of rounds 2-4, deleted): every barrier of the
 // prologue becomes a wave-level LDS fence instead of a workgroup barrier.
 __device__ __forceinline__ void wave_lds_sync();
 template <bool WAVE>
@@ -854,7 +854,7 @@ __device__ __forceinline__ int solve_wave(const View& v, const ItemHdr& h, const
 // in the fused kernels' timelines); here lane i holds row i of S / C and lane j column j of L^-1, wave-uniform values
 // travel through v_readlane, and the factor part of S is summed with one lane per stored column k (no serial loop over
 // the rank).  HT(i,k) = ht[i*si + k*sk].  Also writes Q = -HT^T L^-1 (fp32 rows [k][QS], then 8 zero rows) when q_out is
-// not null: the consumers of k_step_pipe stream against Q, so their tile epilogue needs no L^-1.
+// not null: the consumers of the (deleted) persistent kernel streamed against Q, so their tile epilogue needs no L^-1.
 // mapping/mappings.py:178-197.  Same outputs as solve_wave (L^-1 / y in fp32, debug copies in fp64, header, status).
 // The observation of an item by ONE wave (DEFER mode of prepare_item_ex; the same arithmetic in the same order as the
 // block-wide code there): z = clip(INTER_AREA(ground-truth crop) + nv * eps), innovation v = z - H x into the prologue's

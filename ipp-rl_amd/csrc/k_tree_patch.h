@@ -69,7 +69,7 @@ struct TreeIo {
     }
 };
 
-// The search driver's use of an item's reward (ipp_mcts_level_steps): the numerator of the tree edge that asked for the step,
+// The search driver's use of an item's reward (ipp_mcts_steps): the numerator of the tree edge that asked for the step,
 // t_num[parent][k] = reward (cost + 1) (rewards.py:31 undone: the cost depends on the path that led to the node, the masked trace
 // reduction does not), and a non-zero status into err[2] -- written by the kernel itself instead of by a launch behind it.
 struct TreeEdgeOut {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, kPatchMinW) void k_tree_patch(
     View v, TreeView tv, const int* __restrict__ root_ids, const int* __restrict__ path_ids, const int* __restrict__ new_ids,
     int n_items, const double* __restrict__ action, const double* __restrict__ prev_action, unsigned flags,
     int* __restrict__ status_out, float* __restrict__ reward_out, const int* __restrict__ n_dev, TreeEdgeOut eo) {
-    // n_dev: the item count lives on the device (ipp_mcts_level_steps with n < 0: the search driver queues the levels of a
+    // n_dev: the item count lives on the device (ipp_mcts_steps with n < 0: the search driver queues the levels of a
     // wave of simulations without reading their request counts back); the grid then has n_items >= *n_dev workgroups
     constexpr int MC = 9, VEC = 2, NT = kWave * NW, KP = kPatchKP;
     constexpr int RJ = RJN > 0 ? RJN : (kPatchMaxRank + NT - 1) / NT;
