@@ -61,6 +61,10 @@ def test_fullsize_batch_invariants_subset_parity_and_reproducibility(grid, B, T,
     assert full.info.patch_layout == 1 and full.info.fused_step == 1 and full.info.patch_waves == 3
     # launches of this size (32768 items, or 16384 per group) run two waves per item, in the four-rows-per-group form (launch_chunk)
     assert full.info.patch_two_wave_min_items == 6144 and full.info.patch_big_min_items == 16384
+    # ... and an arena of this size comes from the virtual-memory API in 1-GiB chunks at a 1-GiB-aligned address (a silent fall-back to the
+    # allocator's memory would cost 15-20 % of the step rate with every numeric check below still green); the small exact engine stays on torch
+    assert full.arena_kind == "vmm" and full.arena.chunk_bytes == 1 << 30 and full.arena.data_ptr() % (1 << 30) == 0, getattr(full, "arena_fallback_reason", None)
+    assert exact.arena_kind in ("torch", "vmm")
     print(f"[{name}] arena {full.info.arena_bytes / 1e9:.1f} GB, {full.info.cov_slot_bytes / 1e6:.2f} MB of columns per env")
     white = torch.empty((B, N), dtype=torch.float32, device="cuda")
     full.normal_rows(white, N, 11, 1 << 40)
