@@ -28,6 +28,11 @@ def _run(monkeypatch, env_vars, dim, B, T, parts, steps):
         r, s = env.step(a)
         assert int(s.abs().sum()) == 0
         rewards.append(r.clone())
+    # ... and a predict-only call on the final states (Mapping.update_grid_map(predict_only=True), mapping/mappings.py:114: nothing is written)
+    a = torch.as_tensor(cell_centre_actions(cfg, steps, 0, B, B, ALTS), device="cuda")
+    rp, sp = env.engine.step(a, env.prev, predict_only=True, cov_only=True)
+    assert int(sp.abs().sum()) == 0
+    rewards.append(rp.clone())
     torch.cuda.synchronize()
     out = dict(rewards=torch.stack(rewards), ranks=env.engine.ranks().clone(), prev=env.prev.clone(),
                planes=[(env.mean(e).clone(), env.diag(e).clone(), env.ground_truth(e).clone()) for e in (0, 1, B // 2, B - 1)],
