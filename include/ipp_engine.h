@@ -512,14 +512,18 @@ int ipp_fill_normal_rows(void* engine, float* out /*[dev]*/, int32_t planes, int
  * The batched driver times a few candidate pairs and keeps the best.  Synchronises both streams. */
 int ipp_probe_stream_pair(void* engine, void* stream_a, void* stream_b, int32_t launches, double* ms /*[host]*/);
 
-/* Arena placement (round 6).  The engine lives in ONE caller-owned arena (ipp_engine_create); where that arena lies in PHYSICAL
- * memory decides whether a large batch runs in its fast or its slow mode (12 % at 32768 envs of 50x50, profiles/r06_arena_modes.txt),
- * which a framework's caching allocator hides.  These three calls give the host a handle on it: arenas straight from the driver --
- * IPP_ARENA_HIPMALLOC: hipMalloc; IPP_ARENA_VMM: a 1-GiB-aligned virtual reservation backed by physical chunks of `chunk_bytes`
- * (0 = 1 GiB; rounded up to the device's recommended granularity) through hipMemCreate / hipMemMap -- and a bare probe of the
- * step kernel's row stream (512-byte slices of 656-float patches spread over `items` equal slots of the arena, `rows` stored
- * columns per unit, no arithmetic) that times a placement in about a millisecond: ms = average duration of one of `launches`
- * launches on `stream` (synchronises).  VecIPPEnv(arena_candidates = K) holds K arenas, keeps the fastest and frees the rest.
+/* Arena placement (round 6).  The engine lives in ONE caller-owned arena (ipp_engine_create).  How that arena is MAPPED decides 15-20 % of a
+ * large batch's step rate (configs[3] share 0.60 -> 0.51 ms per step, profiles/r06_arena_modes.txt): the driver covers a mapping with large
+ * address-translation fragments only where the virtual address and the physical blocks are mutually aligned, which hipMalloc and a
+ * framework's caching allocator (2-MiB-aligned addresses, whatever blocks the allocator's history left) achieve by chance.  ipp_arena_alloc:
+ * IPP_ARENA_HIPMALLOC = plain hipMalloc; IPP_ARENA_VMM = physical chunks of `chunk_bytes` (0 = 1 GiB; rounded up to the device's
+ * granularity; one tail chunk of the remainder) from hipMemCreate, mapped at an address aligned to `align_bytes` (a power of two, 0 =
+ * chunk_bytes; the reservation's own alignment argument is not honoured by this runtime: one `align_bytes` more is reserved and the chunks
+ * go to the aligned address inside).  chunk = align = 1 GiB is the mapping IPPEngine(arena = "auto") uses from 256 MiB.
+ * ipp_arena_probe: the step kernel's row stream without its arithmetic (512-byte slices of 656-float patches spread over `items` equal
+ * slots of the arena, `rows` stored columns per unit), ms = average duration of one of `launches` launches on `stream` (synchronises).
+ * (Neither this probe nor ipp_arena_latency tells a fast mapping from a slow one -- the fragment size only shows on the step kernel's own
+ * access pattern -- they are the instruments that ruled the memory system's bandwidth and idle latency out.)
  * No reference counterpart: the reference's state is NumPy arrays in host memory (mapping/grid_maps.py:10-11). */
 #define IPP_ARENA_HIPMALLOC 0
 #define IPP_ARENA_VMM       1

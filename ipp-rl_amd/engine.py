@@ -101,7 +101,8 @@ os.register_at_fork(after_in_child=_after_fork_in_child)
 class DeviceArena:
     """Device memory for an engine's state straight from the driver (ipp_arena_alloc): kind "hip" = hipMalloc, "vmm" = a
     1-GiB-aligned reservation backed by physical chunks of `chunk_bytes` (0 = 1 GiB).  No caching allocator in between, so
-    freeing it returns the physical memory and a new one draws a new placement -- what VecIPPEnv(arena_candidates=K) is built on."""
+    freeing it returns the physical memory (a "vmm" arena's ADDRESS range stays reserved, ipp_arena_free); probe() / latency() time the
+    bare row stream and chains of dependent requests on it (profiles/r06_arena_modes.txt)."""
 
     def __init__(self, nbytes: int, device_index: int = 0, kind: str = "hip", chunk_bytes: int = 0, align_bytes: int = 0):
         self._lib = _ffi.load()
