@@ -134,6 +134,8 @@ def gpu_numa_nodes(sysfs="/sys"):
 
     nodes = []
     for dev in sorted(glob.glob(os.path.join(sysfs, "bus/pci/devices/*"))):
+        if not dev.endswith(".0"):
+            continue  # (one entry per device: function 0)
         try:
             with open(os.path.join(dev, "vendor")) as fh:
                 if fh.read().strip() != "0x1002":
