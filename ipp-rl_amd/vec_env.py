@@ -156,7 +156,11 @@ class VecIPPEnv:
         # horizon an env resets at most once, so its episode counter read at staging time names the right ground truth.
         if stagger:
             n_max = max(int(i.numel()) for i in self._reset_ids_by_phase)
-            K = max(1, min(8, self.episode_steps // 2, (256 << 20) // max(1, n_max * cfg.n_cells * 8)))
+            # (cap of the two staged sets: 2 GiB -- with 256 MiB configs[2], 2048 resets of 40 KB per step, staged block by block of ONE step
+            # and paid the streams' meeting every step: 0.4695 against 0.4436 ms per step with blocks of eight, profiles/r06_experiments.txt 14)
+            K = max(1, min(8, self.episode_steps // 2, (2 << 30) // max(1, n_max * cfg.n_cells * 8)))
+            if os.environ.get("IPP_BLK_K"):  # (A/B: steps per staging block)
+                K = max(1, min(int(os.environ["IPP_BLK_K"]), self.episode_steps // 2))
             self._blk_K = K
             # (the K fields of a set are rows [j n_max, (j + 1) n_max) of ONE buffer: a block can be generated by one launch)
             self._staged_sets = [torch.empty((K * n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
