@@ -82,7 +82,7 @@ def build_parser():
     ap.add_argument("--step-priority", type=int, default=0,
                     help="A/B: run the steps on a stream of this priority (-1: above the side stream that generates the next episodes' "
                          "ground truths, whose workgroups then only take the slots the step launches leave free)")
-    ap.add_argument("--regions", type=int, default=5,
+    ap.add_argument("--regions", type=int, default=7,
                     help="timed regions of --steps steps each (barrier + sync around every one); `value` is the median region")
     ap.add_argument("--print-args", action="store_true", help="print the workload key used to match PMC summaries, then exit")
     return ap
@@ -406,8 +406,6 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
     ]).to(device)
     env.reset()
     t_idx = 0
-    for _ in range(T):  # pre-roll: reach the stationary mix of episode phases (untimed setup, not warmup)
-        env.step(actions[t_idx]); t_idx += 1
 
     from ipp_rl_amd import _ffi
 
@@ -444,6 +442,19 @@ def run_env_workload(torch, ranks, device, *, grid, envs_local, env_lo, total_en
         order_r = sorted(range(len(regs)), key=lambda i: regs[i][1])
         return regs[order_r[len(order_r) // 2]]
 
+    # pre-roll: reach the stationary mix of episode phases (untimed setup, not warmup) -- issued the way the timed regions issue their
+    # steps (whole runs of `steps` steps without a join), so that whatever the runtime sets up the first time that many launches are in
+    # flight happens here: the first process on a fresh box spent 35 ms of HOST time inside its first timed region otherwise
+    # (1.75 ms per step in a 20-step region; profiles/r06_experiments.txt 15)
+    done = 0
+    while done < T:
+        k = min(max(steps, 1), T - done)
+        if predict_only:  # (the states are built by COMMITTED steps; the predict-only calls of the timed regions write nothing)
+            for _ in range(k):
+                env.step(actions[t_idx]); t_idx += 1
+        else:
+            run_steps(k)
+        done += k
     run_steps(warmup)
     # `regions` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + device sync on both sides; the
     # reported region is the MEDIAN one (by the max-over-ranks time), the spread goes into the record
@@ -778,6 +789,7 @@ def _config_block(args, rec, B, T, total_envs, pinning):
         "timed_regions": len(regs), "value_is": "median timed region",
         "region_ms_first": 1e3 * regs[0] / args.steps,
         "region_ms_per_step": [1e3 * t / args.steps for t in regs],
+        "region_host_issue_ms_per_step": [1e3 * t / args.steps for t in rec["region_issue_s"]],
         "per_rank_ms_per_step": [1e3 * t / args.steps for t in per_rank],
         "per_rank_env_steps_per_s": [B * args.steps / t for t in per_rank],
         "host_issue_ms_per_rank": issue, "own_ms_per_step_per_rank": own,
