@@ -905,17 +905,20 @@ def main(argv=None):
                     and args.window_rows == -1 and not args.predict_only and not args.shuffle_prior and args.tile_threads == 0)
     if default_line:
         extra = []
+        # (the 35-GB arena first: its 1-GiB physical chunks come out of device memory that nothing has carved up yet -- behind configs[2],
+        # whose gigabytes of staging tensors go back to the driver in between, the same workload ran at 0.55-0.57 instead of 0.50 ms per step,
+        # profiles/r06_experiments.txt 16)
         todo = [
+            ("BASELINE configs[3] per-GPU share: 32768 envs, 50x50 grid, 40-step episodes",
+             dict(grid=50, envs_local=32768, episode_steps=40)),
+            ("BASELINE configs[2]: 32768 envs, 100x100 grid, 16-step episodes",
+             dict(grid=100, envs_local=32768, episode_steps=16)),
             ("BASELINE configs[1], window 12 rows (valid for shuffle_prior_cov, the reference's self-play prior)",
              dict(grid=50, envs_local=4096, episode_steps=40, shuffle_prior=True)),
             ("BASELINE configs[1], predict-only calls (simulate_prediction_step, no state write)",
              dict(grid=50, envs_local=4096, episode_steps=40, predict_only=True)),
             ("BASELINE configs[1] with one launch per step on one stream (the schedule of rounds 1-3; frac: bytes / that launch's duration)",
              dict(grid=50, envs_local=4096, episode_steps=40, parts=1, steps=80, warmup=8)),
-            ("BASELINE configs[2]: 32768 envs, 100x100 grid, 16-step episodes",
-             dict(grid=100, envs_local=32768, episode_steps=16)),
-            ("BASELINE configs[3] per-GPU share: 32768 envs, 50x50 grid, 40-step episodes",
-             dict(grid=50, envs_local=32768, episode_steps=40)),
         ]
         for name, kw in todo:
             try:

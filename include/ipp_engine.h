@@ -533,6 +533,11 @@ int ipp_arena_free(void* arena /*[dev], from ipp_arena_alloc*/);
 /* ipp_arena_free of an IPP_ARENA_VMM arena returns its physical memory but keeps its ADDRESS range reserved (a range that is
  * mapped again after a free has been seen to fault on this runtime); this is how many bytes of address space are retired so far. */
 int ipp_arena_retired_bytes(uint64_t* bytes /*[host]*/);
+/* ... and keeps its whole physical chunks in a per-process pool (at most IPP_ARENA_POOL_GIB GiB, default 48; 0: none) for the next VMM arena
+ * of the same chunk size on that device: a chunk that has served a fast arena serves the next one too, while memory the driver has just taken
+ * back comes out in pieces for a while (the second large workload of a process ran 5-25 % slower than in a fresh process).  ipp_arena_trim
+ * hands the pooled chunks of `device` (< 0: every device) back to the driver; released [host] (may be NULL) receives the bytes. */
+int ipp_arena_trim(int device, uint64_t* released /*[host]*/);
 int ipp_arena_probe(int device, const void* arena /*[dev]*/, uint64_t bytes, int32_t items, int32_t rows, int32_t launches,
                     void* stream, double* ms /*[host]*/);
 /* ... and its latency: `waves` single-wave workgroups each follow a chain of `hops` DEPENDENT 512-byte requests to pseudo-random

@@ -135,6 +135,7 @@ PROTOTYPES = {
     "ipp_arena_alloc": (C.c_int, [C.c_int, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(_P)]),
     "ipp_arena_free": (C.c_int, [_P]),
     "ipp_arena_retired_bytes": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "ipp_arena_trim": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "ipp_arena_latency": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     "ipp_arena_probe": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     "ipp_debug_capture": (C.c_int, [_P, C.c_int32]),

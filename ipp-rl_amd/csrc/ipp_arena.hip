@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -33,6 +34,7 @@ struct Mapping {
     void* reserved = nullptr;      // VMM: start and size of the address reservation (the arena is an aligned range inside it)
     uint64_t reserved_bytes = 0;
     int kind;
+    int device = 0;
     uint64_t bytes;      // reserved = mapped size (VMM), requested size (hipMalloc)
     std::vector<hipMemGenericAllocationHandle_t> chunks;
     std::vector<uint64_t> sizes;
@@ -40,6 +42,21 @@ struct Mapping {
 };
 std::mutex g_mu;
 std::map<void*, Mapping> g_arenas;
+// Physical chunks of freed VMM arenas, kept for the next arena of this process (per device and chunk size) instead of going back to the
+// driver: a chunk that has served a fast arena serves the next one as well, whereas memory that the driver has just taken back comes out
+// again in pieces for a while -- the second large workload of a process ran 5-25 % slower than the same workload in a fresh process
+// (profiles/r06_experiments.txt 16).  Bounded by IPP_ARENA_POOL_GIB (default 48, 0: off); ipp_arena_trim hands the memory back.
+struct PoolKey { int device; uint64_t size; bool operator<(const PoolKey& o) const { return device != o.device ? device < o.device : size < o.size; } };
+std::map<PoolKey, std::vector<hipMemGenericAllocationHandle_t>> g_pool;
+uint64_t g_pool_bytes = 0;
+uint64_t pool_cap_bytes() {
+    static const uint64_t cap = [] {
+        const char* e = getenv("IPP_ARENA_POOL_GIB");
+        const long long gib = e ? atoll(e) : 48;
+        return (uint64_t)(gib > 0 ? gib : 0) << 30;
+    }();
+    return cap;
+}
 uint64_t g_retired_bytes = 0;  // address ranges of freed VMM arenas (kept reserved, see ipp_arena_free)
 
 // The row stream of k_step_patch without its arithmetic: item i owns the slot [i, i + 1) x slot_floats of the arena; a wave reads,
@@ -111,7 +128,7 @@ int ipp_arena_alloc(int device, uint64_t bytes, int32_t kind, uint64_t chunk_byt
     *arena = nullptr;
     ARENA_TRY(hipSetDevice(device));
     Mapping m;
-    m.kind = kind; m.bytes = bytes; m.chunk_bytes = 0;
+    m.kind = kind; m.device = device; m.bytes = bytes; m.chunk_bytes = 0;
     void* p = nullptr;
     if (kind == IPP_ARENA_HIPMALLOC) {
         ARENA_TRY(hipMalloc(&p, bytes));
@@ -154,7 +171,18 @@ int ipp_arena_alloc(int device, uint64_t bytes, int32_t kind, uint64_t chunk_byt
         for (uint64_t off = 0; off < total;) {
             const uint64_t sz = (total - off >= chunk) ? chunk : total - off;
             hipMemGenericAllocationHandle_t h;
-            hipError_t e = hipMemCreate(&h, sz, &prop, 0);
+            bool pooled = false;
+            {
+                std::lock_guard<std::mutex> g(g_mu);
+                auto it = g_pool.find(PoolKey{device, sz});
+                if (it != g_pool.end() && !it->second.empty()) {
+                    h = it->second.back();
+                    it->second.pop_back();
+                    g_pool_bytes -= sz;
+                    pooled = true;
+                }
+            }
+            hipError_t e = pooled ? hipSuccess : hipMemCreate(&h, sz, &prop, 0);
             if (e == hipSuccess) {
                 e = hipMemMap((char*)p + off, sz, 0, h, 0);
                 if (e != hipSuccess) (void)hipMemRelease(h);
@@ -203,7 +231,16 @@ int ipp_arena_free(void* arena) {
     uint64_t off = 0;
     for (size_t i = 0; i < m.chunks.size(); ++i) {
         ARENA_TRY(hipMemUnmap((char*)arena + off, m.sizes[i]));
-        ARENA_TRY(hipMemRelease(m.chunks[i]));
+        bool keep = false;
+        if (m.sizes[i] == m.chunk_bytes) {  // (whole chunks only: the tail chunk goes back)
+            std::lock_guard<std::mutex> g(g_mu);
+            if (g_pool_bytes + m.sizes[i] <= pool_cap_bytes()) {
+                g_pool[PoolKey{m.device, m.sizes[i]}].push_back(m.chunks[i]);
+                g_pool_bytes += m.sizes[i];
+                keep = true;
+            }
+        }
+        if (!keep) ARENA_TRY(hipMemRelease(m.chunks[i]));
         off += m.sizes[i];
     }
     // The ADDRESS range stays reserved for the life of the process.  Measured on this runtime (ROCm 7.2, gfx950; tools/arena_modes.py,
@@ -215,6 +252,26 @@ int ipp_arena_free(void* arena) {
         std::lock_guard<std::mutex> g(g_mu);
         g_retired_bytes += m.reserved_bytes;
     }
+    return 0;
+}
+
+int ipp_arena_trim(int device, uint64_t* released) {
+    uint64_t n = 0;
+    std::vector<std::pair<uint64_t, hipMemGenericAllocationHandle_t>> out;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        for (auto& kv : g_pool)
+            if (device < 0 || kv.first.device == device) {
+                for (auto h : kv.second) out.emplace_back(kv.first.size, h);
+                kv.second.clear();
+            }
+        for (auto& x : out) g_pool_bytes -= x.first;
+    }
+    for (auto& x : out) {
+        ARENA_TRY(hipMemRelease(x.second));
+        n += x.first;
+    }
+    if (released) *released = n;
     return 0;
 }
 

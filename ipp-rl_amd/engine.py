@@ -152,6 +152,13 @@ class DeviceArena:
         h.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self._ptr, False), "version": 2}
         return torch.as_tensor(h, device=device)
 
+    @staticmethod
+    def trim(device_index: int = -1) -> int:
+        """Hands the pooled physical chunks of freed "vmm" arenas back to the driver (ipp_arena_trim); returns the bytes released."""
+        n = C.c_uint64(0)
+        _ffi.check(_ffi.load().ipp_arena_trim(int(device_index), C.byref(n)))
+        return int(n.value)
+
     def free(self):
         if getattr(self, "_ptr", None) and os.getpid() != self._pid:
             self._ptr = None  # a forked child: the mapping is the parent's (HIP state does not survive fork)

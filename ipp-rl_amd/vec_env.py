@@ -162,12 +162,15 @@ class VecIPPEnv:
             if os.environ.get("IPP_BLK_K"):  # (A/B: steps per staging block)
                 K = max(1, min(int(os.environ["IPP_BLK_K"]), self.episode_steps // 2))
             self._blk_K = K
-            # (the K fields of a set are rows [j n_max, (j + 1) n_max) of ONE buffer: a block can be generated by one launch)
-            self._staged_sets = [torch.empty((K * n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2)]
-            self._staged = [self._staged_sets[q // K][(q % K) * n_max:(q % K + 1) * n_max] for q in range(2 * K)]
+            # (the K fields of a set are rows [j n_max, (j + 1) n_max) of ONE buffer: a block can be generated by one launch.  The buffers are
+            # allocated on FIRST USE: where the fields go straight into the envs' alternate planes -- every BASELINE config -- nothing ever reads
+            # them, and at configs[2] they are 2 x 1.3 GB + as much white-noise scratch that would go back to the driver when the env closes,
+            # cutting up the device memory the next large arena's 1-GiB chunks come from)
+            self._staged_sets = None
+            self._staged = None
             self._blk_nmax = n_max
             self._blk_ids = {}  # first step of a block mod the episode length -> device int32 [K n_max] row ids (-1: padding)
-            self._staged_white = [torch.empty((n_max, cfg.n_cells), dtype=torch.float32, device=dev) for _ in range(2 * K)]
+            self._staged_white = None
             self._blk_ready = [torch.cuda.Event() for _ in range(2)]
             # (`free` of a buffer set: one event per stream that steps the batch -- the caller's, or one per part)
             self._blk_free = [[torch.cuda.Event() for _ in range(self.parts)] for _ in range(2)]
@@ -281,6 +284,24 @@ class VecIPPEnv:
         """Phase whose envs finish their episode with step index t: env e has done (t + 1 + phase_e) steps."""
         return (self.episode_steps - ((t + 1) % self.episode_steps)) % self.episode_steps
 
+    def _staged_buffers(self):
+        """The two staged buffer sets (K fields of n_max rows each) and their white-noise scratch, allocated on first use."""
+        if self._staged_sets is None:
+            torch, K, nm, N = self.torch, self._blk_K, self._blk_nmax, self.cfg.n_cells
+            self._staged_sets = [torch.empty((K * nm, N), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._staged = [self._staged_sets[q // K][(q % K) * nm:(q % K + 1) * nm] for q in range(2 * K)]
+        return self._staged_sets
+
+    def _staged_field(self, q: int):
+        self._staged_buffers()
+        return self._staged[q]
+
+    def _staged_white_field(self, q: int):
+        if self._staged_white is None:
+            self._staged_white = [self.torch.empty((self._blk_nmax, self.cfg.n_cells), dtype=self.torch.float32, device=self.device)
+                                  for _ in range(2 * self._blk_K)]
+        return self._staged_white[q]
+
     def _stage_block(self, b: int, upto: Optional[int] = None):
         """Start, on the side stream, the ground truths of the resets of the steps [b K, b K + upto) into buffer set b % 2 (upto = K: the
         whole block, then its `ready` event).  Called with growing `upto` it stages a block field by field: the prefetch of the NEXT
@@ -311,13 +332,13 @@ class VecIPPEnv:
                 # (50x50 / 100x100: no [n, N] noise array written and read back), else fill + generate
                 epi = self.episode[self._reset_ids_host[p]]
                 if self._grf_rows is not False and len(epi) and np.all(epi == epi[0]):
-                    self._grf_rows = self.engine.generate_grf_rows(n, self.seed, self.GT_STREAM + int(epi[0]), self._staged[buf][:n],
+                    self._grf_rows = self.engine.generate_grf_rows(n, self.seed, self.GT_STREAM + int(epi[0]), self._staged_field(buf)[:n],
                                                                    row_ids=self._reset_ids_by_phase[p], row_offset=self.env_id_offset,
                                                                    stream=self._side)
                     if self._grf_rows:
                         continue
-                white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white[buf][:n])
-                self.engine.generate_grf(white, out=self._staged[buf][:n], stream=self._side)
+                white = self._white_for(self._reset_ids_by_phase[p], self._reset_ids_host[p], self._staged_white_field(buf)[:n])
+                self.engine.generate_grf(white, out=self._staged_field(buf)[:n], stream=self._side)
             if upto == K:
                 self._blk_ready[set_].record(self._side)
         if upto == K:
@@ -354,7 +375,7 @@ class VecIPPEnv:
         # (2 K > episode_steps: a block is staged when its first step arrives, behind the `free` event of block b - 2 only -- while
         # block b - 1, whose resets flip the very planes this launch would write, may still be running: staged buffers + copies then)
         alt = bool(self._fused_reset) and self._gt_flip_ok and 2 * K <= self.episode_steps
-        ok = self.engine.generate_grf_rows(K * nm, self.seed, self.GT_STREAM, None if alt else self._staged_sets[set_], row_ids=ids,
+        ok = self.engine.generate_grf_rows(K * nm, self.seed, self.GT_STREAM, None if alt else self._staged_buffers()[set_], row_ids=ids,
                                            row_offset=self.env_id_offset, stream=self._side, group_rows=nm, group_subsequence=epi)
         if not ok:
             self._grf_rows = False
@@ -476,7 +497,7 @@ class VecIPPEnv:
         fused = None
         if self._fused_reset and env_ids is None and scheduled is not None:
             p, k, n = scheduled
-            fused = dict(reset_src=self._reset_src(p), reset_gt=None if self._blk_alt[k // self._blk_K] else self._staged[k][:n], init_action=INIT_ACTION)
+            fused = dict(reset_src=self._reset_src(p), reset_gt=None if self._blk_alt[k // self._blk_K] else self._staged_field(k)[:n], init_action=INIT_ACTION)
             if self.shuffle_prior_cov:  # priors of the episodes this launch starts, row i for staged field i
                 self.engine.set_reset_prior(self._prior_scale_scheduled(p))
         if self._orders is not None and env_ids is None:
@@ -498,7 +519,7 @@ class VecIPPEnv:
         if scheduled is not None:
             p, k, n = scheduled
             # (a block that went into the alternate planes has no buffer to copy from: the separate reset draws the same field again)
-            self.reset(gt=None if self._blk_alt[k // self._blk_K] else self._staged[k][:n], _phase=p)
+            self.reset(gt=None if self._blk_alt[k // self._blk_K] else self._staged_field(k)[:n], _phase=p)
         if prefetch is not None:
             self._prefetch_next_block(*prefetch)
         if blk is not None and blk[1]:
@@ -646,7 +667,7 @@ class VecIPPEnv:
         fused = {}
         if scheduled is not None:
             p, k, n = scheduled
-            fused = dict(reset_src=self._reset_src(p), reset_gt=None if self._blk_alt[k // self._blk_K] else self._staged[k][:n], init_action=INIT_ACTION)
+            fused = dict(reset_src=self._reset_src(p), reset_gt=None if self._blk_alt[k // self._blk_K] else self._staged_field(k)[:n], init_action=INIT_ACTION)
             if self.shuffle_prior_cov:
                 self.engine.set_reset_prior(self._prior_scale_scheduled(p))
         self.engine.set_item_order(self._orders_parts[self.t % self.episode_steps])

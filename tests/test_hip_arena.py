@@ -41,11 +41,13 @@ def test_vmm_arena_chunks_tail_alignment_and_reuse():
     import torch
     from ipp_rl_amd.engine import DeviceArena
 
+    DeviceArena.trim()  # (chunks pooled by earlier tests)
     free0 = torch.cuda.mem_get_info()[0]
     # 2 whole chunks of 64 MiB + a tail of 5 MiB + 1 byte -> 3 x the 2-MiB granularity (or whatever the device recommends)
     n = 2 * (64 << 20) + (5 << 20) + 1
     a = DeviceArena(n, 0, kind="vmm", chunk_bytes=64 << 20, align_bytes=64 << 20)
     assert a.data_ptr() % (64 << 20) == 0
+    a0 = a.data_ptr()
     t = a.as_tensor("cuda:0")
     assert t.numel() == n
     t.fill_(7)
@@ -58,6 +60,16 @@ def test_vmm_arena_chunks_tail_alignment_and_reuse():
     del t
     a.free()
     a.free()  # idempotent
+    # the two whole chunks stay in the library's pool for the next arena of this chunk size (the tail chunk went back) ...
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert (128 << 20) <= held < (128 << 20) + (8 << 20)
+    b = DeviceArena(3 * (64 << 20), 0, kind="vmm", chunk_bytes=64 << 20, align_bytes=64 << 20)  # two pooled chunks + one new
+    assert b.data_ptr() != a0 and b.data_ptr() % (64 << 20) == 0  # (never the address range of a freed arena)
+    assert free0 - torch.cuda.mem_get_info()[0] < 3 * (64 << 20) + (8 << 20)
+    tb = b.as_tensor("cuda:0"); tb.fill_(3); assert int(tb[-1]) == 3; del tb
+    b.free()
+    # ... until it is trimmed
+    assert DeviceArena.trim(0) == 3 * (64 << 20) and DeviceArena.trim() == 0
     assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)
     with pytest.raises(ValueError):
         DeviceArena(1 << 20, 0, kind="nope")
