@@ -106,6 +106,8 @@ def test_arena_calls_validate_their_arguments_without_gpu():
     assert lib.ipp_arena_latency(0, None, 1 << 20, 4, 4, None, ctypes.byref(ms)) == -1
     assert lib.ipp_arena_retired_bytes(None) == -1
     assert lib.ipp_arena_retired_bytes(ctypes.byref(n)) == 0 and n.value == 0
+    n.value = 123
+    assert lib.ipp_arena_trim(-1, ctypes.byref(n)) == 0 and n.value == 0 and lib.ipp_arena_trim(0, None) == 0  # (nothing pooled)
     import torch
 
     if not torch.cuda.is_available():
